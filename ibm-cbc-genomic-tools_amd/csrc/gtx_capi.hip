@@ -1,0 +1,420 @@
+// gtx_capi.hip -- implementation of the C ABI declared in include/gtx.h.
+//
+// Host side of the engine: builds the device-resident rank structure from the reference
+// regions (replacing the bin-index construction of UnsortedGenomicRegionSetOverlaps,
+// gtools/genomic_intervals.cpp:5593-5675), enqueues the streaming count / scan kernels of
+// gtx_kernels.hip, and moves buffers.  There is deliberately no CPU implementation of the
+// counting path in this library: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "gtx.h"
+#include "gtx_kernels.h"
+
+typedef unsigned long long u64;
+
+static thread_local std::string g_create_error;
+
+struct gtx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // reference side
+  int64_t nRefs = -1, nValid = 0;
+  int nClasses = 0;
+  int *d_sortedE = nullptr, *d_sortedS = nullptr, *d_segStart = nullptr;
+  int *d_posE = nullptr, *d_posS = nullptr, *d_classBase = nullptr;
+  u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr;
+  int64_t histLen = 0;
+
+  gtx::DevInfo *d_info = nullptr;
+  gtx::DevInfo *h_info = nullptr;       // pinned: [0] = readback, [1] = init pattern
+
+  // staging for the host-buffer entry points
+  void *d_reads = nullptr; int *d_weights = nullptr; size_t capReads = 0;
+  u64 *d_out = nullptr; size_t capOut = 0;
+
+  // scan state
+  u64 *d_micro = nullptr; size_t capMicro = 0;
+  long long *d_scanTab = nullptr; size_t capScanTab = 0;
+  std::vector<long long> scanKey;       // geometry the tables on the device were built for
+  int64_t scanTotalWindows = 0, scanTotalMicro = 0;
+
+  // measurement
+  bool prof = false; bool profValid = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+  int chunksPerWave = 32;
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return GTX_E_HIP; } } while (0)
+
+static int fail(gtx_ctx *c, int code, const char *msg) { c->err = msg; return code; }
+
+template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+extern "C" {
+
+int gtx_version(void) { return 100; }
+
+gtx_ctx *gtx_create(int device_id)
+{
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = std::string("gtx_create: no usable HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                     "); this library has no CPU path";
+    return nullptr;
+  }
+  if (device_id < 0 || device_id >= n) { g_create_error = "gtx_create: device id out of range"; return nullptr; }
+  if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+  gtx_ctx *c = new gtx_ctx();
+  c->device = device_id;
+  if (hipMalloc(&c->d_info, sizeof(gtx::DevInfo)) != hipSuccess || hipHostMalloc(&c->h_info, 2 * sizeof(gtx::DevInfo)) != hipSuccess) {
+    g_create_error = "gtx_create: allocation failed"; delete c; return nullptr;
+  }
+  c->h_info[1].first_unsorted = INT64_MAX; c->h_info[1].n_no_class = 0; c->h_info[1].n_degenerate = 0; c->h_info[1].first_degenerate = INT64_MAX;
+  c->h_info[0] = c->h_info[1];
+  for (auto &ev : c->ev) if (hipEventCreate(&ev) != hipSuccess) { g_create_error = "gtx_create: hipEventCreate failed"; delete c; return nullptr; }
+  const char *cpw = getenv("GTX_CHUNKS_PER_WAVE");
+  if (cpw && atoi(cpw) > 0) c->chunksPerWave = atoi(cpw);
+  return c;
+}
+
+void gtx_destroy(gtx_ctx *c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
+  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_info);
+  dfree(c->d_reads); dfree(c->d_weights); dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
+  if (c->h_info) (void)hipHostFree(c->h_info);
+  for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  delete c;
+}
+
+const char *gtx_last_error(const gtx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int gtx_set_stream(gtx_ctx *c, void *s) { if (!c) return GTX_E_ARG; c->stream = (hipStream_t)s; return GTX_OK; }
+
+int gtx_sync(gtx_ctx *c) { if (!c) return GTX_E_ARG; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return GTX_OK; }
+
+int64_t gtx_n_refs(const gtx_ctx *c) { return c ? c->nRefs : -1; }
+
+// ---------------------------------------------------------------------------------------------
+// reference side
+// ---------------------------------------------------------------------------------------------
+int gtx_set_refs(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses)
+{
+  if (!c || m < 0 || (m > 0 && !tri)) return c ? fail(c, GTX_E_ARG, "gtx_set_refs: bad argument") : GTX_E_ARG;
+  if (m >= (int64_t)INT32_MAX - 4096) return fail(c, GTX_E_ARG, "gtx_set_refs: too many reference regions");
+  HIPCHK(c, hipSetDevice(c->device));
+  int maxc = -1;
+  for (int64_t k = 0; k < m; k++) {
+    int32_t cl = tri[3 * k], s = tri[3 * k + 1], e = tri[3 * k + 2];
+    if (cl < 0) return fail(c, GTX_E_RANGE, "gtx_set_refs: negative class id");
+    if (s >= INT32_MAX - 1 || e >= INT32_MAX - 1) return fail(c, GTX_E_RANGE, "gtx_set_refs: coordinate >= 2^31-2");
+    if (cl > maxc) maxc = cl;
+  }
+  if (nClasses <= 0) nClasses = maxc + 1;
+  if (maxc >= nClasses) return fail(c, GTX_E_RANGE, "gtx_set_refs: class id >= n_classes");
+  if (nClasses < 1) nClasses = 1;
+
+  // valid regions only take part (genomic_intervals.cpp:5659: start>stop or stop<=0 is skipped)
+  std::vector<u64> keyE, keyS;                   // (class, biased coordinate, ordinal) packed for one sort each
+  std::vector<int32_t> ord;
+  ord.reserve(m);
+  for (int64_t k = 0; k < m; k++) { int32_t s = tri[3 * k + 1], e = tri[3 * k + 2]; if (!(s > e || e <= 0)) ord.push_back((int32_t)k); }
+  const int64_t nv = (int64_t)ord.size();
+  struct Item { int32_t cls; int32_t val; int32_t k; };
+  std::vector<Item> itE(nv), itS(nv);
+  for (int64_t i = 0; i < nv; i++) {
+    int32_t k = ord[i];
+    itE[i] = {tri[3 * (int64_t)k], tri[3 * (int64_t)k + 2], k};
+    itS[i] = {tri[3 * (int64_t)k], tri[3 * (int64_t)k + 1], k};
+  }
+  auto cmp = [](const Item &a, const Item &b) { return a.cls != b.cls ? a.cls < b.cls : (a.val != b.val ? a.val < b.val : a.k < b.k); };
+  std::sort(itE.begin(), itE.end(), cmp);
+  std::sort(itS.begin(), itS.end(), cmp);
+
+  std::vector<int32_t> sortedE(nv + 1), sortedS(nv + 1), seg(nClasses + 1, 0), posE(m > 0 ? m : 1, -1), posS(m > 0 ? m : 1, -1), classBase(m > 0 ? m : 1, -1);
+  for (int64_t i = 0; i < nv; i++) seg[itE[i].cls + 1]++;
+  for (int cl = 0; cl < nClasses; cl++) seg[cl + 1] += seg[cl];
+  for (int64_t i = 0; i < nv; i++) {
+    sortedE[i] = itE[i].val; posE[itE[i].k] = (int32_t)(i + itE[i].cls);
+    sortedS[i] = itS[i].val; posS[itS[i].k] = (int32_t)(i + itS[i].cls);
+    classBase[itE[i].k] = seg[itE[i].cls] + itE[i].cls - 1;
+  }
+
+  dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
+  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB);
+  c->nRefs = -1;
+  const int64_t histLen = nv + nClasses;
+  const int nTiles = gtx::scan_tiles(histLen);
+  HIPCHK(c, hipMalloc(&c->d_sortedE, sizeof(int32_t) * (nv + 1)));
+  HIPCHK(c, hipMalloc(&c->d_sortedS, sizeof(int32_t) * (nv + 1)));
+  HIPCHK(c, hipMalloc(&c->d_segStart, sizeof(int32_t) * (nClasses + 1)));
+  HIPCHK(c, hipMalloc(&c->d_posE, sizeof(int32_t) * (m + 1)));
+  HIPCHK(c, hipMalloc(&c->d_posS, sizeof(int32_t) * (m + 1)));
+  HIPCHK(c, hipMalloc(&c->d_classBase, sizeof(int32_t) * (m + 1)));
+  HIPCHK(c, hipMalloc(&c->d_histA, sizeof(u64) * histLen));
+  HIPCHK(c, hipMalloc(&c->d_histB, sizeof(u64) * histLen));
+  HIPCHK(c, hipMalloc(&c->d_partA, sizeof(u64) * (nTiles + 1)));
+  HIPCHK(c, hipMalloc(&c->d_partB, sizeof(u64) * (nTiles + 1)));
+  HIPCHK(c, hipMemcpy(c->d_sortedE, sortedE.data(), sizeof(int32_t) * nv, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_sortedS, sortedS.data(), sizeof(int32_t) * nv, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_segStart, seg.data(), sizeof(int32_t) * (nClasses + 1), hipMemcpyHostToDevice));
+  if (m > 0) {
+    HIPCHK(c, hipMemcpy(c->d_posE, posE.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_posS, posS.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_classBase, classBase.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
+  }
+  c->nRefs = m; c->nValid = nv; c->nClasses = nClasses; c->histLen = histLen;
+  return GTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// count
+// ---------------------------------------------------------------------------------------------
+static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags)
+{
+  gtx::CountArgs a;
+  a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart;
+  a.histA = c->d_histA; a.histB = c->d_histB; a.info = c->d_info;
+  a.nClasses = c->nClasses; a.chunksPerWave = c->chunksPerWave;
+  a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0;
+  return a;
+}
+
+// begin: zero histograms + info; accumulate: one kernel per resident batch; end: prefix + gather
+static int count_begin(gtx_ctx *c)
+{
+  HIPCHK(c, hipMemsetAsync(c->d_histA, 0, sizeof(u64) * c->histLen, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_histB, 0, sizeof(u64) * c->histLen, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_info, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
+  return GTX_OK;
+}
+
+static int count_end(gtx_ctx *c, void *d_hits)
+{
+  HIPCHK(c, gtx::launch_finalize(c->d_histA, c->d_histB, c->histLen, c->d_partA, c->d_partB, c->d_posE, c->d_posS, c->d_classBase,
+                                 c->nRefs, (u64 *)d_hits, c->stream));
+  return GTX_OK;
+}
+
+int gtx_count_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, void *d_hits)
+{
+  if (!c) return GTX_E_ARG;
+  if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_count_device: gtx_set_refs has not been called");
+  if (n < 0 || (n > 0 && !d_reads) || (c->nRefs > 0 && !d_hits)) return fail(c, GTX_E_ARG, "gtx_count_device: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  int rc = count_begin(c); if (rc) return rc;
+  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags), (flags & GTX_READS_SORTED) != 0, c->stream));
+  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  rc = count_end(c, d_hits); if (rc) return rc;
+  if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profValid = true; }
+  return GTX_OK;
+}
+
+static void info_out(const gtx::DevInfo &d, gtx_count_info *o, int64_t base)
+{
+  o->first_unsorted = d.first_unsorted == INT64_MAX ? -1 : d.first_unsorted + base;
+  o->n_no_class = d.n_no_class; o->n_degenerate = d.n_degenerate;
+  o->first_degenerate = d.first_degenerate == INT64_MAX ? -1 : d.first_degenerate + base;
+}
+
+int gtx_last_info(gtx_ctx *c, gtx_count_info *info)
+{
+  if (!c || !info) return GTX_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  info_out(c->h_info[0], info, 0);
+  return GTX_OK;
+}
+
+static int ensure_staging(gtx_ctx *c, size_t nReads, bool weights)
+{
+  if (nReads > c->capReads) {
+    dfree(c->d_reads); dfree(c->d_weights); c->capReads = 0;
+    HIPCHK(c, hipMalloc(&c->d_reads, nReads * 12));
+    HIPCHK(c, hipMalloc(&c->d_weights, nReads * 4));
+    c->capReads = nReads;
+  }
+  (void)weights;
+  return GTX_OK;
+}
+
+static int ensure_out(gtx_ctx *c, size_t n)
+{
+  if (n > c->capOut) { dfree(c->d_out); c->capOut = 0; HIPCHK(c, hipMalloc(&c->d_out, (n + 1) * sizeof(u64))); c->capOut = n; }
+  return GTX_OK;
+}
+
+// Host buffers: the reads are streamed through the device in batches (the histograms simply keep
+// accumulating across batches), so N is bounded by host memory only -- the analogue of the
+// reference never holding the query set in memory (genomic_intervals.cpp:3855-3861).
+int gtx_count(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, uint32_t flags, uint64_t *hits, gtx_count_info *info)
+{
+  if (!c) return GTX_E_ARG;
+  if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_count: gtx_set_refs has not been called");
+  if (n < 0 || (n > 0 && !reads) || (c->nRefs > 0 && !hits)) return fail(c, GTX_E_ARG, "gtx_count: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t batch = 64ll << 20;              // 64 Mi reads = 768 MiB of triples per batch
+  int rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
+  rc = ensure_out(c, (size_t)c->nRefs); if (rc) return rc;
+  rc = count_begin(c); if (rc) return rc;
+  gtx::DevInfo total = c->h_info[1];
+  for (int64_t off = 0; off < n; off += batch) {
+    const int64_t cnt = std::min(batch, n - off);
+    HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
+    if (weights) HIPCHK(c, hipMemcpyAsync(c->d_weights, weights + off, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, gtx::launch_count(c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags), (flags & GTX_READS_SORTED) != 0, c->stream));
+    if (n > batch) {
+      // fold this batch's info (indices are batch-relative) and reset for the next one
+      HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      const gtx::DevInfo &d = c->h_info[0];
+      if (d.first_unsorted != INT64_MAX && total.first_unsorted == INT64_MAX) total.first_unsorted = d.first_unsorted + off;
+      if (d.first_degenerate != INT64_MAX && total.first_degenerate == INT64_MAX) total.first_degenerate = d.first_degenerate + off;
+      total.n_no_class += d.n_no_class; total.n_degenerate += d.n_degenerate;
+      if ((flags & GTX_CHECK_SORTED) && off > 0 && total.first_unsorted == INT64_MAX) {
+        const int32_t *p = reads + 3 * (off - 1), *q = reads + 3 * off;
+        if (q[0] < p[0] || (q[0] == p[0] && q[1] < p[1])) total.first_unsorted = off;
+      }
+      HIPCHK(c, hipMemcpyAsync(c->d_info, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
+    }
+  }
+  rc = count_end(c, c->d_out); if (rc) return rc;
+  if (c->nRefs > 0) HIPCHK(c, hipMemcpyAsync(hits, c->d_out, sizeof(u64) * c->nRefs, hipMemcpyDeviceToHost, c->stream));
+  if (n <= batch) {
+    HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    total = c->h_info[0];
+  } else HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (info) info_out(total, info, 0);
+  return GTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan
+// ---------------------------------------------------------------------------------------------
+int64_t gtx_scan_n_windows(int64_t len, int64_t step, int64_t size)
+{
+  if (step <= 0 || size <= 0 || len < 0) return 0;
+  int64_t n = len / step, comb = size / step;
+  return n < comb ? 0 : n - comb + 1;
+}
+
+static int scan_prepare(gtx_ctx *c, const int32_t *classLen, int nClasses, int step, int size, const int64_t *classOff, gtx::ScanArgs *out)
+{
+  if (nClasses < 1 || !classLen || !classOff) return fail(c, GTX_E_ARG, "gtx_scan: bad class table");
+  if (step <= 0 || size <= 0 || size % step) return fail(c, GTX_E_ARG, "gtx_scan: window size must be a positive multiple of window step");
+  std::vector<long long> key;
+  key.push_back(nClasses); key.push_back(step); key.push_back(size);
+  for (int i = 0; i < nClasses; i++) { key.push_back(classLen[i]); key.push_back(classOff[i]); }
+  const size_t tabLen = (size_t)4 * nClasses + 1;
+  if (key != c->scanKey) {
+    std::vector<long long> tab(tabLen);
+    long long *microOff = tab.data(), *nMicro = microOff + nClasses, *winOff = nMicro + nClasses, *outOff = winOff + nClasses + 1;
+    long long mo = 0, wo = 0;
+    for (int i = 0; i < nClasses; i++) {
+      long long nm = classLen[i] < 0 ? 0 : classLen[i] / step;
+      microOff[i] = mo; nMicro[i] = nm; winOff[i] = wo; outOff[i] = classOff[i];
+      mo += nm; wo += gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size);
+    }
+    winOff[nClasses] = wo;
+    if (tabLen > c->capScanTab) { dfree(c->d_scanTab); c->capScanTab = 0; HIPCHK(c, hipMalloc(&c->d_scanTab, tabLen * sizeof(long long))); c->capScanTab = tabLen; }
+    if ((size_t)mo + 1 > c->capMicro) { dfree(c->d_micro); c->capMicro = 0; HIPCHK(c, hipMalloc(&c->d_micro, ((size_t)mo + 1) * sizeof(u64))); c->capMicro = (size_t)mo + 1; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->d_scanTab, tab.data(), tabLen * sizeof(long long), hipMemcpyHostToDevice));
+    c->scanKey = key; c->scanTotalMicro = mo; c->scanTotalWindows = wo;
+  }
+  out->micro = c->d_micro; out->microOff = c->d_scanTab; out->nMicro = c->d_scanTab + nClasses;
+  out->winOff = c->d_scanTab + 2 * nClasses; out->outOff = c->d_scanTab + 3 * nClasses + 1;
+  out->nClasses = nClasses; out->winStep = step; out->comb = size / step;
+  return GTX_OK;
+}
+
+int gtx_scan_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, const int32_t *classLen, int32_t nClasses,
+                    int32_t step, int32_t size, char prep, uint32_t flags, void *d_out, const int64_t *classOff)
+{
+  (void)flags;
+  if (!c) return GTX_E_ARG;
+  if (n < 0 || (n > 0 && !d_reads)) return fail(c, GTX_E_ARG, "gtx_scan_device: bad argument");
+  if (prep != '1' && prep != 'c') return fail(c, GTX_E_ARG, "gtx_scan_device: preprocess operator must be '1' or 'c'");
+  HIPCHK(c, hipSetDevice(c->device));
+  gtx::ScanArgs a;
+  int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
+  a.center = prep == 'c';
+  if (c->scanTotalWindows > 0 && !d_out) return fail(c, GTX_E_ARG, "gtx_scan_device: null output");
+  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * sizeof(u64), c->stream));
+  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream));
+  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, a, c->scanTotalWindows, (u64 *)d_out, c->stream));
+  if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profValid = true; }
+  return GTX_OK;
+}
+
+int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, const int32_t *classLen, int32_t nClasses,
+             int32_t step, int32_t size, char prep, uint32_t flags, uint64_t *out, const int64_t *classOff)
+{
+  if (!c) return GTX_E_ARG;
+  if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_scan: bad argument");
+  if (prep != '1' && prep != 'c') return fail(c, GTX_E_ARG, "gtx_scan: preprocess operator must be '1' or 'c'");
+  HIPCHK(c, hipSetDevice(c->device));
+  gtx::ScanArgs a;
+  int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
+  a.center = prep == 'c';
+  // output layout in the caller's buffer is given by class_offsets: find its extent
+  int64_t extent = 0;
+  for (int i = 0; i < nClasses; i++) extent = std::max<int64_t>(extent, classOff[i] + gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size));
+  if (extent > 0 && !out) return fail(c, GTX_E_ARG, "gtx_scan: null output");
+  rc = ensure_out(c, (size_t)extent); if (rc) return rc;
+  const int64_t batch = 64ll << 20;
+  rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
+  if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * sizeof(u64), c->stream));
+  for (int64_t off = 0; off < n; off += batch) {
+    const int64_t cnt = std::min(batch, n - off);
+    HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
+    if (weights) HIPCHK(c, hipMemcpyAsync(c->d_weights, weights + off, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, gtx::launch_scan_hist(c->d_reads, weights ? c->d_weights : nullptr, cnt, a, c->stream));
+    if (n > batch) HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (extent > 0) HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)extent * sizeof(u64), c->stream));
+  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, a, c->scanTotalWindows, c->d_out, c->stream));
+  if (extent > 0) HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)extent * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------------------------
+int gtx_profile_enable(gtx_ctx *c, int on) { if (!c) return GTX_E_ARG; c->prof = on != 0; c->profValid = false; return GTX_OK; }
+
+int gtx_profile_last(gtx_ctx *c, float *msKernel, float *msTotal)
+{
+  if (!c) return GTX_E_ARG;
+  if (!c->profValid) return fail(c, GTX_E_STATE, "gtx_profile_last: no profiled call");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(c->ev[3]));
+  float a = 0, b = 0;
+  HIPCHK(c, hipEventElapsedTime(&a, c->ev[1], c->ev[2]));
+  HIPCHK(c, hipEventElapsedTime(&b, c->ev[0], c->ev[3]));
+  if (msKernel) *msKernel = a;
+  if (msTotal) *msTotal = b;
+  return GTX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,52 @@
+// gtx_kernels.h -- launch interface between the C ABI (gtx_capi.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gtx {
+
+// device-side mirror of gtx_count_info (include/gtx.h)
+struct DevInfo {
+  long long first_unsorted;
+  long long n_no_class;
+  long long n_degenerate;
+  long long first_degenerate;
+};
+
+struct CountArgs {
+  const int *sortedE;            // reference ends, sorted by (class, value)
+  const int *sortedS;            // reference starts, sorted by (class, value)
+  const int *segStart;           // [nClasses+1] class segments in both arrays
+  unsigned long long *histA;     // [nValid + nClasses] rank histogram over sortedE
+  unsigned long long *histB;     // same over sortedS
+  DevInfo *info;
+  int nClasses;
+  int chunksPerWave;             // 64-read chunks one wave streams
+  int checkSorted;               // verify (class >> sortClassShift, start) order
+  int sortClassShift;
+};
+
+struct ScanArgs {
+  unsigned long long *micro;     // micro-window histogram, all classes
+  const long long *microOff;     // [nClasses] offset of class c in micro
+  const long long *nMicro;       // [nClasses] micro-windows of class c (len / step)
+  const long long *winOff;       // [nClasses+1] prefix of window counts (launch order)
+  const long long *outOff;       // [nClasses] caller's class_offsets
+  int nClasses;
+  int winStep;
+  int comb;                      // win_size / win_step
+  int center;                    // preprocess 'c'
+};
+
+int scan_tiles(long long len);
+
+hipError_t launch_count(const void *reads, const void *weights, long long n, const CountArgs &a, bool sortedHint, hipStream_t st);
+hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB, long long histLen,
+                           unsigned long long *partA, unsigned long long *partB,
+                           const int *posE, const int *posS, const int *classBase, long long m,
+                           unsigned long long *hits, hipStream_t st);
+hipError_t launch_scan_hist(const void *reads, const void *weights, long long n, const ScanArgs &a, hipStream_t st);
+hipError_t launch_scan_windows(const unsigned long long *micro, const ScanArgs &a, long long totalWindows,
+                               unsigned long long *out, hipStream_t st);
+
+} // namespace gtx

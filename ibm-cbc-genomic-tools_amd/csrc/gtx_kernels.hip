@@ -1,0 +1,520 @@
+// gtx_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the interval-overlap engine.
+//
+// What is computed (reference: GenomicRegionSetOverlaps::CountIndexOverlaps,
+// gtools/genomic_intervals.cpp:5304-5317 over GetOverlap :5224-5248 and
+// GenomicInterval::OverlapsWith :624-630), for single-interval regions inside one class
+// (chromosome, or chromosome+strand):
+//
+//     hits[k] = sum_q w_q * [s_q <= E_k  and  e_q >= S_k]
+//             = sum_q w_q [s_q <= E_k]  -  sum_q w_q [e_q < S_k]          (s_q <= e_q, S_k <= E_k)
+//
+// so one streaming pass over the reads fills two histograms over *ranks*:
+//     HA[#{E_j < s_q}] += w_q        (E sorted ascending inside the class)
+//     HB[#{S_j < e_q + 1}] += w_q    (S sorted ascending inside the class)
+// and  hits[k] = prefix(HA)[posE(k)] - prefix(HB)[posS(k)].  Integer adds commute, so any
+// execution order is bit-exact.
+//
+// The streaming kernel is wave-autonomous (no LDS, no barriers): a wave64 owns a contiguous span
+// of reads, takes 64 of them at a time (one 12-byte triple per lane, one coalesced 768-byte
+// request), and "walks" a 63-slot window of sorted boundaries that lives in one VGPR across the
+// wave.  For a boundary value W (wave-uniform, read with v_readlane) the number of reads of the
+// chunk at or below it is popcount(ballot(key <= W)): one v_cmp + a few scalar ops per boundary
+// crossed, nothing per read.  Sorted input crosses ~M/(N/64) boundaries per chunk, so the kernel
+// is bound by the HBM read of the triples.  Any input order is handled exactly (backward walk,
+// re-seek by wave-cooperative 64-ary search, per-lane binary search for scattered chunks); only
+// the speed depends on the order.  No MFMA: this is integer indexing, not a contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "gtx_kernels.h"
+
+namespace gtx {
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+static constexpr int kHi = 0x7fffffff;          // +inf sentinel (coordinates are < 2^31-1)
+static constexpr int kLo = (int)0x80000000;     // -inf sentinel
+static constexpr int kSlots = 63;               // slots per register window (lane 0 holds the boundary below slot 0)
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
+  return rfl(v);
+}
+
+__device__ __forceinline__ i64 wave_sum(i64 v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return __shfl(v, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One boundary array being walked by one wave.  Uniform members live in SGPRs; W, Wn, acc are
+// per-lane.  Lane L of W holds arr[base-1+L] (kLo below the class segment, kHi above it); slot j
+// (global rank base+j) is bounded below by lane j and above by lane j+1.
+// ---------------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+struct Walk {
+  typedef typename std::conditional<WEIGHTED, i64, unsigned>::type acc_t;
+  const int *arr;       // sorted boundaries of all classes
+  u64 *hist;            // rank histogram, index = rank + class id
+  int segStart, segEnd; // class segment [segStart, segEnd) in arr
+  int shift;            // class id (slot shift)
+  int base;             // global rank of slot 0
+  int j;                // current slot 0..62
+  int prevW, curW;      // arr[base+j-1], arr[base+j]
+  acc_t pend;           // weight pending for slot j
+  int W, Wn;            // window and the prefetched next window
+  acc_t acc;            // per-lane accumulator (lane L <-> slot L-1)
+  bool valid;
+
+  __device__ __forceinline__ int load_window(int b, int lane) const
+  {
+    int idx = b - 1 + lane;
+    int v = idx < segStart ? kLo : kHi;
+    if (idx >= segStart && idx < segEnd) v = arr[idx];
+    return v;
+  }
+
+  __device__ __forceinline__ void deposit(int lane)
+  {
+    if (pend != 0) { if (lane == j + 1) acc += pend; pend = 0; }
+  }
+
+  __device__ __forceinline__ void flush(int lane)
+  {
+    deposit(lane);
+    if (acc != 0) atomicAdd(&hist[(i64)base - 1 + lane + shift], (u64)(i64)acc);
+    acc = 0;
+  }
+
+  __device__ __forceinline__ void set_class(int s0, int s1, int cls, int lane)
+  {
+    if (valid) flush(lane);
+    segStart = s0; segEnd = s1; shift = cls; valid = false;
+  }
+
+  // position slot 0 at rank p
+  __device__ __forceinline__ void place(int p, int lane)
+  {
+    if (valid) flush(lane);
+    base = p; j = 0; pend = 0; acc = 0;
+    W = load_window(base, lane);
+    Wn = load_window(base + kSlots, lane);
+    prevW = rdlane(W, 0); curW = rdlane(W, 1);
+    valid = true;
+  }
+
+  // wave-cooperative 64-ary lower bound: #{arr[segStart..segEnd) < key} + segStart
+  __device__ __forceinline__ int lower_bound(int key, int lane) const
+  {
+    int lo = segStart, hi = segEnd;
+    while (hi - lo > 64) {
+      int step = (hi - lo + 63) >> 6;
+      i64 idx = (i64)lo + (i64)lane * step;
+      int v = idx < hi ? arr[idx] : kHi;
+      int nless = __popcll(__ballot(v < key));
+      if (nless == 0) { hi = lo; break; }
+      int nlo = lo + (nless - 1) * step + 1;
+      i64 nhi = (i64)lo + (i64)nless * step;
+      lo = nlo; if (nhi < hi) hi = (int)nhi;
+    }
+    int idx = lo + lane;
+    int v = idx < hi ? arr[idx] : kHi;
+    return lo + __popcll(__ballot(v < key));
+  }
+
+  __device__ __forceinline__ void seek(int key, u64 m, int lane)
+  {
+    int k = wave_min(((m >> lane) & 1) ? key : kHi);
+    place(lower_bound(k, lane), lane);
+  }
+
+  // returns true when the register window was exchanged
+  __device__ __forceinline__ bool move_fwd(int lane)
+  {
+    deposit(lane);
+    bool sw = false;
+    if (++j == kSlots) {
+      flush(lane);
+      base += kSlots; j = 0; W = Wn; Wn = load_window(base + kSlots, lane); sw = true;
+    }
+    prevW = curW; curW = rdlane(W, j + 1);
+    return sw;
+  }
+
+  __device__ __forceinline__ void move_back(int lane)
+  {
+    deposit(lane);
+    if (--j < 0) {
+      flush(lane);
+      base -= kSlots; j = kSlots - 1; Wn = W; W = load_window(base, lane);
+    }
+    curW = prevW; prevW = rdlane(W, j);
+  }
+
+  // scattered lanes: individual binary search + atomic
+  __device__ __forceinline__ void slow(int key, i64 w, u64 m, int lane)
+  {
+    if ((m >> lane) & 1) {
+      int lo = segStart, hi = segEnd;
+      while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (arr[mid] < key) lo = mid + 1; else hi = mid; }
+      atomicAdd(&hist[(i64)lo + shift], (u64)w);
+    }
+  }
+
+  // Add the lanes of m (keys `key`, weights `w`) to the histogram.
+  __device__ __forceinline__ void walk(int key, i64 w, u64 m, int lane)
+  {
+    if (!valid) seek(key, m, lane);
+    // backward: some key at or below the boundary under the current slot
+    int back = 0;
+    while (__ballot(key <= prevW) & m) {
+      if (++back > 6) { seek(key, m, lane); break; }
+      move_back(lane);
+    }
+    // forward: lanes at or below curW belong to slots <= j; the rest is still ahead
+    u64 done = 0; int adv = 0;
+    for (;;) {
+      u64 le = __ballot(key <= curW) & m;
+      u64 fresh = le & ~done;
+      if (fresh) {
+        if (WEIGHTED) pend += (acc_t)wave_sum(((fresh >> lane) & 1) ? w : 0);
+        else pend += (acc_t)__popcll(fresh);
+      }
+      done = le;
+      if (le == m) break;
+      if (move_fwd(lane) && ++adv > 2) {
+        slow(key, w, m & ~done, lane);        // keys spread over many windows: finish them one by one
+        break;
+      }
+    }
+  }
+};
+
+struct __attribute__((packed, aligned(4))) Tri { int c, s, e; };
+
+// ---------------------------------------------------------------------------------------------
+// Streaming count kernel ("walk").  One wave = chunksPerWave consecutive chunks of 64 reads.
+// ---------------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n,
+                                                         CountArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const i64 nChunks = (n + 63) >> 6;
+  i64 chunk = wave * a.chunksPerWave;
+  if (chunk >= nChunks) return;
+  i64 chunkEnd = chunk + a.chunksPerWave; if (chunkEnd > nChunks) chunkEnd = nChunks;
+
+  Walk<WEIGHTED> A, B;
+  A.arr = a.sortedE; A.hist = a.histA; A.valid = false; A.acc = 0; A.pend = 0; A.j = 0; A.base = 0; A.segStart = A.segEnd = 0; A.shift = 0;
+  B.arr = a.sortedS; B.hist = a.histB; B.valid = false; B.acc = 0; B.pend = 0; B.j = 0; B.base = 0; B.segStart = B.segEnd = 0; B.shift = 0;
+  A.W = A.Wn = B.W = B.Wn = kHi; A.prevW = B.prevW = kLo; A.curW = B.curW = kHi;
+  int curClass = -1;
+  i64 nNoClass = 0, nDegen = 0, firstDegen = INT64_MAX, firstUnsorted = INT64_MAX;
+
+  // order check state: the read just before this wave's span
+  int pc = kLo, ps = kLo;
+  const bool check = a.checkSorted;
+  if (check && chunk > 0) { Tri p = reads[chunk * 64 - 1]; pc = rfl(p.c) >> a.sortClassShift; ps = rfl(p.s); }
+
+  i64 i = chunk * 64 + lane;
+  Tri t; t.c = -1; t.s = 0; t.e = 0; int w = 1;
+  if (i < n) { t = reads[i]; if (WEIGHTED) w = weights[i]; }
+
+  for (; chunk < chunkEnd; ++chunk) {
+    // prefetch the next chunk while this one is processed
+    i64 ni = i + 64;
+    Tri nt; nt.c = -1; nt.s = 0; nt.e = 0; int nw = 1;
+    if (chunk + 1 < chunkEnd && ni < n) { nt = reads[ni]; if (WEIGHTED) nw = weights[ni]; }
+
+    const u64 active = __ballot(i < n);
+
+    if (check) {
+      int cc = t.c >> a.sortClassShift;
+      int upc = __shfl_up(cc, 1), ups = __shfl_up(t.s, 1);
+      if (lane == 0) { upc = pc; ups = ps; }
+      u64 bad = __ballot(cc < upc || (cc == upc && t.s < ups)) & active;
+      if (bad) { i64 at = chunk * 64 + (__ffsll((unsigned long long)bad) - 1); if (at < firstUnsorted) firstUnsorted = at; }
+      int last = 63 - __clzll(active);
+      pc = rdlane(cc, last); ps = rdlane(t.s, last);
+    }
+
+    u64 rem = active;
+    while (rem) {
+      const int c0 = rdlane(t.c, __ffsll((unsigned long long)rem) - 1);
+      u64 g = __ballot(t.c == c0) & rem;
+      rem &= ~g;
+      if ((unsigned)c0 >= (unsigned)a.nClasses) { nNoClass += __popcll(g); continue; }
+      u64 dg = __ballot(t.s > t.e) & g;
+      if (dg) {
+        nDegen += __popcll(dg);
+        i64 at = chunk * 64 + (__ffsll((unsigned long long)dg) - 1); if (at < firstDegen) firstDegen = at;
+        g &= ~dg; if (!g) continue;
+      }
+      if (c0 != curClass) {
+        int s0 = a.segStart[c0], s1 = a.segStart[c0 + 1];
+        A.set_class(s0, s1, c0, lane); B.set_class(s0, s1, c0, lane);
+        curClass = c0;
+      }
+      if (A.segStart == A.segEnd) continue;      // class without reference regions
+      A.walk(t.s, w, g, lane);
+      B.walk(t.e + 1, w, g, lane);
+    }
+    t = nt; w = nw; i = ni;
+  }
+  if (A.valid) A.flush(lane);
+  if (B.valid) B.flush(lane);
+  if (lane == 0) {
+    if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
+    if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen); }
+    if (firstUnsorted != INT64_MAX) atomicMin((i64 *)&a.info->first_unsorted, firstUnsorted);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Order-agnostic count kernel ("search"): every read does two binary searches in the (L2 /
+// Infinity-Cache resident) boundary arrays.  Used when the caller does not claim sorted reads.
+// ---------------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void count_search_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n,
+                                                           CountArgs a)
+{
+  i64 nNoClass = 0, nDegen = 0, firstDegen = INT64_MAX;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    Tri t = reads[i];
+    i64 w = WEIGHTED ? (i64)weights[i] : 1;
+    if ((unsigned)t.c >= (unsigned)a.nClasses) { nNoClass++; continue; }
+    if (t.s > t.e) { nDegen++; if (i < firstDegen) firstDegen = i; continue; }
+    int s0 = a.segStart[t.c], s1 = a.segStart[t.c + 1];
+    if (s0 == s1) continue;
+    int lo = s0, hi = s1;
+    while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (a.sortedE[mid] < t.s) lo = mid + 1; else hi = mid; }
+    atomicAdd(&a.histA[(i64)lo + t.c], (u64)w);
+    lo = s0; hi = s1;
+    while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (a.sortedS[mid] <= t.e) lo = mid + 1; else hi = mid; }
+    atomicAdd(&a.histB[(i64)lo + t.c], (u64)w);
+  }
+  if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
+  if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Finalize: inclusive prefix sums of both histograms (3-phase block scan), then the gather
+//   hits[k] = (PA[posE[k]] - PA[classBase[k]]) - (PB[posS[k]] - PB[classBase[k]])
+// ---------------------------------------------------------------------------------------------
+static constexpr int kScanThreads = 256;
+static constexpr int kScanItems = 16;                       // per thread
+static constexpr int kScanTile = kScanThreads * kScanItems; // 4096 per block
+
+__device__ __forceinline__ u64 block_sum(u64 v, u64 *lds)
+{
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane == 0) lds[wv] = v;
+  __syncthreads();
+  u64 s = 0;
+  for (int k = 0; k < (int)(blockDim.x >> 6); k++) s += lds[k];
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(const u64 *__restrict__ ha, const u64 *__restrict__ hb, i64 len,
+                                                                     u64 *__restrict__ pa, u64 *__restrict__ pb)
+{
+  __shared__ u64 lds[8];
+  i64 b0 = (i64)blockIdx.x * kScanTile;
+  u64 sa = 0, sb = 0;
+  for (int k = 0; k < kScanItems; k++) {
+    i64 i = b0 + (i64)k * kScanThreads + threadIdx.x;
+    if (i < len) { sa += ha[i]; sb += hb[i]; }
+  }
+  sa = block_sum(sa, lds); sb = block_sum(sb, lds);
+  if (threadIdx.x == 0) { pa[blockIdx.x] = sa; pb[blockIdx.x] = sb; }
+}
+
+// single block: exclusive scan of the per-tile partial sums (nb <= a few thousand)
+__global__ __launch_bounds__(1024) void scan_top_kernel(u64 *__restrict__ pa, u64 *__restrict__ pb, int nb)
+{
+  __shared__ u64 la[1024], lb[1024];
+  __shared__ u64 carry[2];
+  if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += 1024) {
+    int i = b0 + threadIdx.x;
+    u64 va = i < nb ? pa[i] : 0, vb = i < nb ? pb[i] : 0;
+    la[threadIdx.x] = va; lb[threadIdx.x] = vb;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      u64 xa = threadIdx.x >= o ? la[threadIdx.x - o] : 0, xb = threadIdx.x >= o ? lb[threadIdx.x - o] : 0;
+      __syncthreads();
+      la[threadIdx.x] += xa; lb[threadIdx.x] += xb;
+      __syncthreads();
+    }
+    if (i < nb) { pa[i] = carry[0] + la[threadIdx.x] - va; pb[i] = carry[1] + lb[threadIdx.x] - vb; }
+    __syncthreads();
+    if (threadIdx.x == 1023) { carry[0] += la[1023]; carry[1] += lb[1023]; }
+    __syncthreads();
+  }
+}
+
+// in place: histogram -> inclusive prefix.  Thread t owns kScanItems consecutive elements.
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(u64 *__restrict__ ha, u64 *__restrict__ hb, i64 len,
+                                                                  const u64 *__restrict__ pa, const u64 *__restrict__ pb)
+{
+  __shared__ u64 wsum[2][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  i64 b0 = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
+  u64 va[kScanItems], vb[kScanItems];
+  u64 sa = 0, sb = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    i64 i = b0 + k;
+    va[k] = i < len ? ha[i] : 0; vb[k] = i < len ? hb[i] : 0;
+    sa += va[k]; va[k] = sa; sb += vb[k]; vb[k] = sb;
+  }
+  // exclusive scan of the per-thread totals across the block
+  u64 xa = sa, xb = sb;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    u64 ta = __shfl_up(xa, o), tb = __shfl_up(xb, o);
+    if (lane >= o) { xa += ta; xb += tb; }
+  }
+  if (lane == 63) { wsum[0][wv] = xa; wsum[1][wv] = xb; }
+  __syncthreads();
+  u64 oa = pa[blockIdx.x] + xa - sa, ob = pb[blockIdx.x] + xb - sb;
+  for (int k = 0; k < wv; k++) { oa += wsum[0][k]; ob += wsum[1][k]; }
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    i64 i = b0 + k;
+    if (i < len) { ha[i] = va[k] + oa; hb[i] = vb[k] + ob; }
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict__ pa, const u64 *__restrict__ pb,
+                                                          const int *__restrict__ posE, const int *__restrict__ posS,
+                                                          const int *__restrict__ classBase, i64 m, u64 *__restrict__ hits)
+{
+  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  int pe = posE[k];
+  u64 h = 0;
+  if (pe >= 0) {
+    int cb = classBase[k];                       // slot just below the class's first slot, -1 if none
+    u64 ba = cb >= 0 ? pa[cb] : 0, bb = cb >= 0 ? pb[cb] : 0;
+    h = (pa[pe] - ba) - (pb[posS[k]] - bb);
+  }
+  hits[k] = h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// genomic_scans counts: micro-window histogram (UnsortedGenomicRegionSetScanner ctor,
+// genomic_intervals.cpp:5036-5055) and sliding sums (:5058-5075).
+// Sorted reads put runs of equal micro-window index in neighbouring lanes: one atomic per run.
+// ---------------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, ScanArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  for (i64 i0 = ((i64)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n; i0 += (i64)gridDim.x * blockDim.x) {
+    i64 i = i0 + lane;
+    i64 slot = -1; i64 w = 1;
+    if (i < n) {
+      Tri t = reads[i];
+      if (WEIGHTED) w = weights[i];
+      if ((unsigned)t.c < (unsigned)a.nClasses && t.s <= t.e && t.e > 0) {
+        i64 pos = a.center ? (i64)t.s + ((i64)t.e - t.s) / 2 : (i64)t.s;
+        i64 mw = (pos - 1) / a.winStep;             // 0-based micro-window (C division: pos>=1 checked next)
+        if (pos >= 1 && mw < a.nMicro[t.c]) slot = a.microOff[t.c] + mw;
+      }
+    }
+    // run-length aggregation across the wave
+    i64 up = __shfl_up(slot, 1);
+    bool head = lane == 0 || up != slot;
+    u64 heads = __ballot(head);
+    if (!WEIGHTED) {
+      if (head && slot >= 0) {
+        u64 later = lane == 63 ? 0 : (heads >> (lane + 1));
+        int run = later ? __ffsll((unsigned long long)later) : 64 - lane;
+        atomicAdd(&a.micro[slot], (u64)run);
+      }
+    } else if (slot >= 0) atomicAdd(&a.micro[slot], (u64)w);   // weighted: one atomic per read
+  }
+}
+
+// out[off_out[c] + k] = sum_{j<comb} micro[off_in[c] + k + j]; one thread per output window.
+__global__ __launch_bounds__(256) void scan_window_kernel(const u64 *__restrict__ micro, ScanArgs a, i64 totalWindows, u64 *__restrict__ out)
+{
+  i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= totalWindows) return;
+  // find class by scanning the (small) class table
+  int c = 0;
+  while (c + 1 < a.nClasses && g >= a.winOff[c + 1]) c++;
+  i64 k = g - a.winOff[c];
+  const u64 *src = micro + a.microOff[c] + k;
+  u64 s = 0;
+  for (int j = 0; j < a.comb; j++) s += src[j];
+  out[a.outOff[c] + k] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+int scan_tiles(i64 len) { return (int)((len + kScanTile - 1) / kScanTile); }
+
+hipError_t launch_count(const void *reads, const void *weights, i64 n, const CountArgs &a, bool sortedHint, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  if (sortedHint) {
+    const i64 nChunks = (n + 63) >> 6;
+    const i64 waves = (nChunks + a.chunksPerWave - 1) / a.chunksPerWave;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    if (weights) count_walk_kernel<true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else count_walk_kernel<false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  } else {
+    i64 blocks = (n + 255) / 256; if (blocks > 256 * 32) blocks = 256 * 32;
+    if (weights) count_search_kernel<true><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else count_search_kernel<false><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *partA, u64 *partB,
+                           const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, hipStream_t st)
+{
+  const int nb = scan_tiles(histLen);
+  if (nb > 0) {
+    scan_partials_kernel<<<nb, kScanThreads, 0, st>>>(histA, histB, histLen, partA, partB);
+    scan_top_kernel<<<1, 1024, 0, st>>>(partA, partB, nb);
+    scan_apply_kernel<<<nb, kScanThreads, 0, st>>>(histA, histB, histLen, partA, partB);
+  }
+  if (m > 0) gather_hits_kernel<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(histA, histB, posE, posS, classBase, m, hits);
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_hist(const void *reads, const void *weights, i64 n, const ScanArgs &a, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  i64 blocks = (n + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16;
+  if (weights) scan_hist_kernel<true><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  else scan_hist_kernel<false><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_windows(const u64 *micro, const ScanArgs &a, i64 totalWindows, u64 *out, hipStream_t st)
+{
+  if (totalWindows <= 0) return hipSuccess;
+  scan_window_kernel<<<(unsigned)((totalWindows + 255) / 256), 256, 0, st>>>(micro, a, totalWindows, out);
+  return hipGetLastError();
+}
+
+} // namespace gtx

@@ -1,0 +1,182 @@
+"""ctypes binding of libgtx.so (include/gtx.h) -- the MI355X interval-overlap engine.
+
+Host language note: the reference is C++, so the product's host side is C++ (csrc/); this
+module only exposes the C ABI to Python for the parity tests and bench.py.  It never computes
+counts itself and has no CPU path: if libgtx.so is missing or no HIP device is usable it raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgtx.so")
+
+READS_SORTED = 1
+CHECK_SORTED = 2
+
+_lib = None
+
+
+class GtxError(RuntimeError):
+    pass
+
+
+class CountInfo(ctypes.Structure):
+    _fields_ = [("first_unsorted", ctypes.c_int64), ("n_no_class", ctypes.c_int64),
+                ("n_degenerate", ctypes.c_int64), ("first_degenerate", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+# name -> (restype, argtypes); must list every symbol include/gtx.h declares
+ABI = {
+    "gtx_version": (ctypes.c_int, []),
+    "gtx_create": (ctypes.c_void_p, [ctypes.c_int]),
+    "gtx_destroy": (None, [ctypes.c_void_p]),
+    "gtx_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "gtx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_set_refs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]),
+    "gtx_n_refs": (ctypes.c_int64, [ctypes.c_void_p]),
+    "gtx_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32,
+                                 ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_count_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32,
+                                        ctypes.c_void_p]),
+    "gtx_last_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_scan_n_windows": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
+    "gtx_scan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32,
+                                ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_scan_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32,
+                                       ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "gtx_profile_last": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+}
+
+
+def load():
+    """dlopen libgtx.so and type its entry points; raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GtxError("%s not found: build it with `make -C %s` (python __graft_entry__.py does)"
+                           % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7 (same soname as
+        # /opt/rocm's).  If torch is going to be used for device buffers / torch.distributed, its
+        # runtime has to be the one that is loaded first, otherwise torch finds no GPU.
+        if not os.environ.get("GTX_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in ABI.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    return ctypes.c_void_p(int(a))          # raw device/host address
+
+
+def _triples(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError("expected an (n, 3) int32 array of (class, start, end)")
+    return a
+
+
+def scan_layout(class_len, win_step, win_size):
+    """(offsets, total) of the concatenated per-class window vector gtx_scan fills."""
+    lib = load()
+    off, tot = [], 0
+    for ln in class_len:
+        off.append(tot)
+        tot += lib.gtx_scan_n_windows(int(ln), int(win_step), int(win_size))
+    return np.asarray(off, dtype=np.int64), tot
+
+
+class Engine:
+    """One context on one GPU (one per process in multi-GPU runs)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.ctx = self.lib.gtx_create(int(device))
+        if not self.ctx:
+            raise GtxError(self.lib.gtx_last_error(None).decode())
+        self.n_refs = 0
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.gtx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise GtxError("gtx error %d: %s" % (rc, self.lib.gtx_last_error(self.ctx).decode()))
+
+    def set_stream(self, stream_handle):
+        self._chk(self.lib.gtx_set_stream(self.ctx, ctypes.c_void_p(int(stream_handle))))
+
+    def sync(self):
+        self._chk(self.lib.gtx_sync(self.ctx))
+
+    def set_refs(self, refs, n_classes=0):
+        refs = _triples(refs)
+        self._chk(self.lib.gtx_set_refs(self.ctx, _ptr(refs), refs.shape[0], int(n_classes)))
+        self.n_refs = refs.shape[0]
+
+    def count(self, reads, weights=None, flags=READS_SORTED):
+        reads = _triples(reads)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.int32)
+        hits = np.zeros(max(self.n_refs, 1), dtype=np.uint64)
+        info = CountInfo()
+        self._chk(self.lib.gtx_count(self.ctx, _ptr(reads), _ptr(w), reads.shape[0], int(flags), _ptr(hits), ctypes.byref(info)))
+        return hits[:self.n_refs], info.as_dict()
+
+    def count_device(self, d_reads, n_reads, d_hits, d_weights=None, flags=READS_SORTED):
+        """reads/weights/hits are raw device addresses (e.g. torch tensor .data_ptr()); asynchronous."""
+        self._chk(self.lib.gtx_count_device(self.ctx, _ptr(d_reads), _ptr(d_weights), int(n_reads), int(flags), _ptr(d_hits)))
+
+    def last_info(self):
+        info = CountInfo()
+        self._chk(self.lib.gtx_last_info(self.ctx, ctypes.byref(info)))
+        return info.as_dict()
+
+    def scan(self, reads, class_len, win_step, win_size, preprocess="1", weights=None, flags=0):
+        reads = _triples(reads)
+        cl = np.ascontiguousarray(class_len, dtype=np.int32)
+        off, tot = scan_layout(cl, win_step, win_size)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.int32)
+        out = np.zeros(max(tot, 1), dtype=np.uint64)
+        self._chk(self.lib.gtx_scan(self.ctx, _ptr(reads), _ptr(w), reads.shape[0], _ptr(cl), len(cl), int(win_step), int(win_size),
+                                    preprocess.encode()[0:1], int(flags), _ptr(out), _ptr(off)))
+        return out[:tot], off
+
+    def scan_device(self, d_reads, n_reads, class_len, win_step, win_size, d_out, preprocess="1", d_weights=None, flags=0):
+        cl = np.ascontiguousarray(class_len, dtype=np.int32)
+        off, tot = scan_layout(cl, win_step, win_size)
+        self._chk(self.lib.gtx_scan_device(self.ctx, _ptr(d_reads), _ptr(d_weights), int(n_reads), _ptr(cl), len(cl), int(win_step),
+                                           int(win_size), preprocess.encode()[0:1], int(flags), _ptr(d_out), _ptr(off)))
+        return off, tot
+
+    def profile(self, on=True):
+        self._chk(self.lib.gtx_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_last(self):
+        a, b = ctypes.c_float(), ctypes.c_float()
+        self._chk(self.lib.gtx_profile_last(self.ctx, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,154 @@
+/*
+ * gtx.h -- C ABI of the MI355X interval-overlap engine (libgtx.so).
+ *
+ * This is the drop-in boundary for the GenomicTools hot path
+ *     genomic_overlaps count / rpkm      and      genomic_scans counts.
+ * The reference has no FFI layer of its own: its boundary is the C++ class API of
+ * gtools/genomic_intervals.h, called by in-tree main()s.  Each entry point below therefore
+ * cites the reference method whose work it replaces; the C++ classes with the reference's
+ * own names (GenomicRegionSetOverlaps, ...Scanner; see csrc/genomic_intervals.h of the
+ * package) are thin shims over these calls, and INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++/torch types; status-code returns: 0 = ok, <0 = error
+ *     (gtx_last_error() has the text).  No exceptions cross the boundary.
+ *   - regions are packed int32 triples (class_id, start, end), 1-based inclusive coordinates,
+ *     exactly what GenomicRegionBED::Read produces from a BED3..BED6 line
+ *     (genomic_intervals.cpp:2157-2172: start = atol(col2)+1, stop = atol(col3)).
+ *     Coordinates must be < 2^31-1.
+ *   - class_id = rank of the chromosome name in strcmp order (genomic_intervals.cpp:1227), so
+ *     id order == the sort order -S expects; for strand-aware runs the caller folds the strand
+ *     into the id (any injective mapping works; (strand, chrom) major order keeps a
+ *     position-sorted stream class-sorted).  Two regions can overlap only inside one class
+ *     (genomic_intervals.cpp:624-630).  Reads whose class has no reference region -- or lies
+ *     outside [0, n_classes) -- match nothing, as an unknown chromosome does in the reference
+ *     (genomic_intervals.cpp:5719-5720).
+ *   - one gtx_ctx per GPU and per caller thread (the reference is single-threaded and
+ *     non-reentrant, genomic_intervals.cpp:5732); multi-GPU = one process per GPU, each with
+ *     its own context, partial count vectors summed by the caller (RCCL all-reduce).
+ *   - the library never falls back to a CPU implementation: without a usable HIP device
+ *     gtx_create() fails.
+ */
+#ifndef GTX_H
+#define GTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gtx_ctx gtx_ctx;
+
+/* error codes */
+#define GTX_OK              0
+#define GTX_E_ARG          -1   /* bad argument                                         */
+#define GTX_E_HIP          -2   /* HIP runtime error (text in gtx_last_error)           */
+#define GTX_E_STATE        -3   /* call order (e.g. count before set_refs)              */
+#define GTX_E_RANGE        -4   /* coordinate >= 2^31-1 or negative class id in refs    */
+
+/* flags for gtx_count* / gtx_scan* */
+#define GTX_READS_SORTED    1u  /* hint: reads are sorted by (class, start) -- the streaming
+                                   wave-ballot kernel is used; it is exact for ANY order, only
+                                   slower on unsorted input.  Without the hint the per-read
+                                   binary-search kernel runs.                                  */
+#define GTX_CHECK_SORTED    2u  /* also verify the order the sorted merge requires
+                                   (SortedGenomicRegionSetOverlaps::NextQuery,
+                                   genomic_intervals.cpp:5889-5898) and report the first
+                                   violation in gtx_count_info.first_unsorted                  */
+
+/* what one count/scan call observed; valid after the call's stream has been synchronised
+ * (gtx_count/gtx_scan synchronise themselves; after a *_device call use gtx_sync). */
+typedef struct {
+  int64_t first_unsorted;    /* index of first read that sorts before its predecessor, -1 if none
+                                (only with GTX_CHECK_SORTED)                                   */
+  int64_t n_no_class;        /* reads whose class is outside [0,n_classes): ignored            */
+  int64_t n_degenerate;      /* reads with start > end: NOT counted by the device path; the
+                                caller applies the reference's rule for them (error exit in the
+                                unsorted algorithm, genomic_intervals.cpp:5740-5741)           */
+  int64_t first_degenerate;  /* index of the first such read, -1 if none                       */
+} gtx_count_info;
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* Binds a context to one HIP device.  Fails (NULL) when no HIP device is usable. */
+gtx_ctx    *gtx_create(int device_id);
+void        gtx_destroy(gtx_ctx *ctx);
+/* Text of the last error on this context (or of a failed gtx_create when ctx == NULL). */
+const char *gtx_last_error(const gtx_ctx *ctx);
+/* All later work is enqueued on this hipStream_t (NULL = the default stream). */
+int         gtx_set_stream(gtx_ctx *ctx, void *hip_stream);
+/* hipStreamSynchronize on the context's stream. */
+int         gtx_sync(gtx_ctx *ctx);
+
+/* ---- index side ------------------------------------------------------------------------- */
+
+/* Replaces the index construction of UnsortedGenomicRegionSetOverlaps
+ * (genomic_intervals.cpp:5593-5675) / the IRegBuffer of SortedGenomicRegionSetOverlaps
+ * (:5844-5873): takes the M single-interval reference regions in FILE order and builds the
+ * device-resident rank structure (two boundary arrays sorted by (class, coordinate)).
+ * Regions with start > end or end <= 0 stay in the numbering but never match, as at :5659.
+ * n_classes <= 0 means "max class id + 1". */
+int gtx_set_refs(gtx_ctx *ctx, const int32_t *ref_triples, int64_t n_refs, int32_t n_classes);
+int64_t gtx_n_refs(const gtx_ctx *ctx);
+
+/* ---- genomic_overlaps count ------------------------------------------------------------- */
+
+/* Replaces GenomicRegionSetOverlaps::CountIndexOverlaps (genomic_intervals.cpp:5304-5317,
+ * decl genomic_intervals.h:2471) for single-interval regions with match_gaps = false:
+ *     hits[k] = sum over reads q of w_q * [q overlaps reference k]
+ * in reference FILE order, 64-bit unsigned wrap-around arithmetic like the reference's
+ * `unsigned long`.  weights == NULL means w_q = 1 (--max-label-value <= 1,
+ * genomic_intervals.cpp:1081-1085); otherwise weights[q] is the already clamped label value.
+ * Host buffers in, host buffer out; copies + kernels + sync inside. */
+int gtx_count(gtx_ctx *ctx, const int32_t *read_triples, const int32_t *weights, int64_t n_reads,
+              uint32_t flags, uint64_t *hits_out /* n_refs */, gtx_count_info *info /* may be NULL */);
+
+/* Same with reads (and weights) already resident in this device's HBM and the count vector
+ * left in HBM (d_hits_out: uint64[n_refs], overwritten).  Asynchronous on the context's stream.
+ * This is the entry the benchmark times and the one a multi-GPU caller reduces from. */
+int gtx_count_device(gtx_ctx *ctx, const void *d_read_triples, const void *d_weights, int64_t n_reads,
+                     uint32_t flags, void *d_hits_out);
+/* Result of the most recent *_device call (synchronises the stream). */
+int gtx_last_info(gtx_ctx *ctx, gtx_count_info *info);
+
+/* ---- genomic_scans counts --------------------------------------------------------------- */
+
+/* Number of sliding windows the scanners report for a chromosome of length `len`
+ * (genomic_intervals.cpp:5025, :5061-5064): n = len/win_step micro-windows, c = win_size/win_step,
+ * max(0, n - c + 1) windows; window k (0-based) is [win_step*k + 1, win_step*k + win_size] (:5111). */
+int64_t gtx_scan_n_windows(int64_t len, int64_t win_step, int64_t win_size);
+
+/* Replaces the UnsortedGenomicRegionSetScanner constructor (genomic_intervals.cpp:5019-5080)
+ * -- equivalently the window sums SortedGenomicRegionSetScanner::Next (:4928-4957) yields:
+ * per class c, micro-window histogram v[(pos-1)/win_step] += w_q for reads with start <= end,
+ * end > 0, pos >= 1 inside the first class_len[c]/win_step micro-windows
+ * (pos = start for preprocess '1', start + (end-start)/2 for 'c'), then sums of
+ * win_size/win_step consecutive micro-windows.  windows_out is the concatenation over classes,
+ * class c at class_offsets[c], gtx_scan_n_windows(class_len[c],..) entries each. */
+int gtx_scan(gtx_ctx *ctx, const int32_t *read_triples, const int32_t *weights, int64_t n_reads,
+             const int32_t *class_len, int32_t n_classes, int32_t win_step, int32_t win_size, char preprocess,
+             uint32_t flags, uint64_t *windows_out, const int64_t *class_offsets);
+
+/* Device-resident form: d_windows_out uint64[total windows] in HBM; asynchronous. */
+int gtx_scan_device(gtx_ctx *ctx, const void *d_read_triples, const void *d_weights, int64_t n_reads,
+                    const int32_t *class_len, int32_t n_classes, int32_t win_step, int32_t win_size, char preprocess,
+                    uint32_t flags, void *d_windows_out, const int64_t *class_offsets);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+
+/* When enabled, every *_device call brackets its dominant kernel (and the whole call) with
+ * HIP events on the context's stream. */
+int gtx_profile_enable(gtx_ctx *ctx, int on);
+/* Elapsed ms of the last profiled call: the streaming kernel alone, and the whole enqueue
+ * (memsets + stream kernel + finalize kernels).  Synchronises the stream. */
+int gtx_profile_last(gtx_ctx *ctx, float *ms_stream_kernel, float *ms_total);
+
+/* Library/ABI version, e.g. 100 = 1.0.0 */
+int gtx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTX_H */
