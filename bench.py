@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: overlap-counted reads/sec, 100M reads x 1M ref intervals (config 3).
+
+One step = one pass of the hot path (gtx_count_device: memsets + streaming count kernel + prefix /
+gather kernels) over one batch of 100M synthetic 50 bp reads, sorted by (chromosome, start), already
+resident in HBM, against 1M reference intervals spread over the 24 hg38 chromosomes, strand ignored
+(`genomic_overlaps count -S -i`).  N GPUs = one process per GPU (torch.distributed / RCCL): the
+chromosomes are dealt to the ranks (LPT), every rank counts its own 100M reads on its chromosomes
+against the replicated reference set, and the per-region count vector is summed with one all-reduce
+over xGMI per step (entries of different ranks are disjoint, so the sum is the global vector).
+Weak scaling: per-GPU work is fixed.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the streaming count kernel: algorithmic bytes
+(12 B per read) / its mean duration measured with HIP events on the launch stream inside the timed
+loop.  `cpu_baseline` is the CPU oracle (sorted-merge restatement of the reference) on a bounded
+sample of the same reads, single thread, on this box's host cores; its counts are also compared
+with the GPU's (full-size parity check of the sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "ibm-cbc-genomic-tools_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import gtx  # noqa: E402
+from gtx import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+READ_LEN = 50
+
+
+def make_reads_on_device(n, chrom_ids, seed, device):
+    """n reads of READ_LEN bp on the given chromosomes (proportional to length), sorted by (class, start)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    per = synth.apportion(n, synth.CHROM_LEN[chrom_ids])
+    out = torch.empty((n, 3), dtype=torch.int32, device=device)
+    at = 0
+    for ci, cnt in zip(chrom_ids, per):
+        cnt = int(cnt)
+        if cnt == 0:
+            continue
+        s = torch.randint(1, int(synth.CHROM_LEN[ci]) - READ_LEN - 1, (cnt,), device=device, generator=g, dtype=torch.int32)
+        s, _ = torch.sort(s)
+        out[at:at + cnt, 0] = int(ci)
+        out[at:at + cnt, 1] = s
+        out[at:at + cnt, 2] = s + (READ_LEN - 1)
+        at += cnt
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
+    ap.add_argument("--refs", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="reads given to the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---- workload -------------------------------------------------------------------------------
+    refs = synth.genome_intervals(args.refs, 43, 50, 2000)                 # 1M refs, all chromosomes, every rank
+    shards = synth.lpt_shards(synth.CHROM_LEN, world)                      # chromosomes -> ranks
+    my_chroms = np.asarray(shards[rank], dtype=np.int64)
+    reads = make_reads_on_device(args.reads, my_chroms, 1000 + rank, device)
+    n = reads.shape[0]
+    hits = torch.zeros(len(refs), dtype=torch.int64, device=device)        # uint64 bit pattern; int64 for RCCL sum
+
+    eng = gtx.Engine(local)
+    eng.set_refs(refs, synth.n_classes())
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+    flags = gtx.READS_SORTED
+
+    def step():
+        eng.count_device(reads.data_ptr(), n, hits.data_ptr(), None, flags)
+        if world > 1:
+            dist.all_reduce(hits, op=dist.ReduceOp.SUM)                    # RCCL over xGMI: the per-region count vector
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    k_ms = [eng.profile_last(b)[0] for b in range(min(args.steps, 64))]
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(np.mean(k_ms))
+    alg_bytes = 12.0 * n                                                    # the triples the kernel must read once
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    value = world * n * args.steps / elapsed
+
+    # ---- CPU baseline + parity on the sample (rank 0, N=1 only) -----------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle import orc
+        ns = min(args.cpu_sample, n)
+        sample = reads[:ns].cpu().numpy()
+        t1 = time.perf_counter()
+        want = orc.count(refs, sample, algo=orc.SORTED_MERGE)
+        cpu_s = time.perf_counter() - t1
+        eng.count_device(reads.data_ptr(), ns, hits.data_ptr(), None, flags)
+        eng.sync()
+        got = hits.cpu().numpy().view(np.uint64)
+        if not np.array_equal(got, want):
+            sys.exit("PARITY FAILURE: GPU counts differ from the CPU oracle on the %d-read sample" % ns)
+        cpu = {"value": ns / cpu_s, "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "first %d reads of the same workload vs all %d refs, packed triples in memory, "
+                         "sorted-merge restatement (oracle/gtx_oracle.c); counts bit-equal to the GPU's" % (ns, len(refs))}
+
+    if rank == 0:
+        line = {
+            "metric": "overlap-counted reads/sec, 100M reads x 1M ref intervals",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: %d 50bp reads/GPU sorted by (chrom,start) x %d ref intervals over 24 hg38 "
+                                   "chromosomes, strand ignored (genomic_overlaps count -S -i); reads resident in HBM" % (n, len(refs)),
+                       "reads_per_gpu": n, "refs": len(refs),
+                       "parallelism": "chromosome shards (LPT) x%d, all-reduce(sum) of the uint64 count vector" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "count_walk_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

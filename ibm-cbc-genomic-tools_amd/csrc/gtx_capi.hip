@@ -46,8 +46,10 @@ struct gtx_ctx {
   int64_t scanTotalWindows = 0, scanTotalMicro = 0;
 
   // measurement
-  bool prof = false; bool profValid = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int kProfSlots = 64;   // ring: the last 64 profiled calls can be read back
+  bool prof = false; long long profCalls = 0;
+  hipEvent_t evRing[kProfSlots][4] = {};
+  hipEvent_t *ev = evRing[0];
 
   int chunksPerWave = 32;
 };
@@ -81,7 +83,7 @@ gtx_ctx *gtx_create(int device_id)
   }
   c->h_info[1].first_unsorted = INT64_MAX; c->h_info[1].n_no_class = 0; c->h_info[1].n_degenerate = 0; c->h_info[1].first_degenerate = INT64_MAX;
   c->h_info[0] = c->h_info[1];
-  for (auto &ev : c->ev) if (hipEventCreate(&ev) != hipSuccess) { g_create_error = "gtx_create: hipEventCreate failed"; delete c; return nullptr; }
+  for (auto &slot : c->evRing) for (auto &ev : slot) if (hipEventCreate(&ev) != hipSuccess) { g_create_error = "gtx_create: hipEventCreate failed"; delete c; return nullptr; }
   const char *cpw = getenv("GTX_CHUNKS_PER_WAVE");
   if (cpw && atoi(cpw) > 0) c->chunksPerWave = atoi(cpw);
   return c;
@@ -95,7 +97,7 @@ void gtx_destroy(gtx_ctx *c)
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_info);
   dfree(c->d_reads); dfree(c->d_weights); dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
   if (c->h_info) (void)hipHostFree(c->h_info);
-  for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto &slot : c->evRing) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
   delete c;
 }
 
@@ -214,13 +216,13 @@ int gtx_count_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int
   if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_count_device: gtx_set_refs has not been called");
   if (n < 0 || (n > 0 && !d_reads) || (c->nRefs > 0 && !d_hits)) return fail(c, GTX_E_ARG, "gtx_count_device: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[0], c->stream)); }
   int rc = count_begin(c); if (rc) return rc;
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags), (flags & GTX_READS_SORTED) != 0, c->stream));
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   rc = count_end(c, d_hits); if (rc) return rc;
-  if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profValid = true; }
+  if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   return GTX_OK;
 }
 
@@ -356,13 +358,13 @@ int gtx_scan_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int6
   int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
   a.center = prep == 'c';
   if (c->scanTotalWindows > 0 && !d_out) return fail(c, GTX_E_ARG, "gtx_scan_device: null output");
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[0], c->stream)); }
   if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * sizeof(u64), c->stream));
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream));
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, gtx::launch_scan_windows(c->d_micro, a, c->scanTotalWindows, (u64 *)d_out, c->stream));
-  if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profValid = true; }
+  if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   return GTX_OK;
 }
 
@@ -401,20 +403,23 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
 // ---------------------------------------------------------------------------------------------
 // measurement
 // ---------------------------------------------------------------------------------------------
-int gtx_profile_enable(gtx_ctx *c, int on) { if (!c) return GTX_E_ARG; c->prof = on != 0; c->profValid = false; return GTX_OK; }
+int gtx_profile_enable(gtx_ctx *c, int on) { if (!c) return GTX_E_ARG; c->prof = on != 0; c->profCalls = 0; return GTX_OK; }
 
-int gtx_profile_last(gtx_ctx *c, float *msKernel, float *msTotal)
+int gtx_profile_read(gtx_ctx *c, int back, float *msKernel, float *msTotal)
 {
   if (!c) return GTX_E_ARG;
-  if (!c->profValid) return fail(c, GTX_E_STATE, "gtx_profile_last: no profiled call");
+  if (back < 0 || back >= gtx_ctx::kProfSlots || back >= c->profCalls) return fail(c, GTX_E_STATE, "gtx_profile_read: no such profiled call");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipEventSynchronize(c->ev[3]));
+  hipEvent_t *ev = c->evRing[(c->profCalls - 1 - back) % gtx_ctx::kProfSlots];
+  HIPCHK(c, hipEventSynchronize(ev[3]));
   float a = 0, b = 0;
-  HIPCHK(c, hipEventElapsedTime(&a, c->ev[1], c->ev[2]));
-  HIPCHK(c, hipEventElapsedTime(&b, c->ev[0], c->ev[3]));
+  HIPCHK(c, hipEventElapsedTime(&a, ev[1], ev[2]));
+  HIPCHK(c, hipEventElapsedTime(&b, ev[0], ev[3]));
   if (msKernel) *msKernel = a;
   if (msTotal) *msTotal = b;
   return GTX_OK;
 }
+
+int gtx_profile_last(gtx_ctx *c, float *msKernel, float *msTotal) { return gtx_profile_read(c, 0, msKernel, msTotal); }
 
 } // extern "C"

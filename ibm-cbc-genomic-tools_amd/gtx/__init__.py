@@ -54,6 +54,7 @@ ABI = {
                                        ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gtx_profile_last": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
 
@@ -176,7 +177,8 @@ class Engine:
     def profile(self, on=True):
         self._chk(self.lib.gtx_profile_enable(self.ctx, 1 if on else 0))
 
-    def profile_last(self):
+    def profile_last(self, back=0):
+        """(ms of the streaming kernel, ms of the whole call) of the call `back` calls before the last profiled one."""
         a, b = ctypes.c_float(), ctypes.c_float()
-        self._chk(self.lib.gtx_profile_last(self.ctx, ctypes.byref(a), ctypes.byref(b)))
+        self._chk(self.lib.gtx_profile_read(self.ctx, int(back), ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value

@@ -142,8 +142,11 @@ int gtx_scan_device(gtx_ctx *ctx, const void *d_read_triples, const void *d_weig
  * HIP events on the context's stream. */
 int gtx_profile_enable(gtx_ctx *ctx, int on);
 /* Elapsed ms of the last profiled call: the streaming kernel alone, and the whole enqueue
- * (memsets + stream kernel + finalize kernels).  Synchronises the stream. */
+ * (memsets + stream kernel + finalize kernels).  Waits for that call to finish. */
 int gtx_profile_last(gtx_ctx *ctx, float *ms_stream_kernel, float *ms_total);
+/* Same for the call `back` calls before the last one (0 = last); the last 64 profiled calls
+ * are kept, so a timed loop can be read back after it ends without synchronising inside it. */
+int gtx_profile_read(gtx_ctx *ctx, int back, float *ms_stream_kernel, float *ms_total);
 
 /* Library/ABI version, e.g. 100 = 1.0.0 */
 int gtx_version(void);

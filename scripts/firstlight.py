@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0,'ibm-cbc-genomic-tools_amd'); sys.path.insert(0,'.')
+import os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,os.path.join(R,'ibm-cbc-genomic-tools_amd')); sys.path.insert(0,R)
 import numpy as np, torch, gtx
 from gtx import synth
 e = gtx.Engine(0)
