@@ -51,7 +51,8 @@ struct gtx_ctx {
   hipEvent_t evRing[kProfSlots][4] = {};
   hipEvent_t *ev = evRing[0];
 
-  int chunksPerWave = 32;
+  int chunksPerWave = 0;                // 0 = choose per call from the number of reads
+  int prefetch = 4;                     // reads per lane per step (R) of the streaming kernel
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -86,6 +87,8 @@ gtx_ctx *gtx_create(int device_id)
   for (auto &slot : c->evRing) for (auto &ev : slot) if (hipEventCreate(&ev) != hipSuccess) { g_create_error = "gtx_create: hipEventCreate failed"; delete c; return nullptr; }
   const char *cpw = getenv("GTX_CHUNKS_PER_WAVE");
   if (cpw && atoi(cpw) > 0) c->chunksPerWave = atoi(cpw);
+  const char *pf = getenv("GTX_PREFETCH");
+  if (pf && atoi(pf) > 0) c->prefetch = atoi(pf);
   return c;
 }
 
@@ -184,13 +187,19 @@ int gtx_set_refs(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses)
 // ---------------------------------------------------------------------------------------------
 // count
 // ---------------------------------------------------------------------------------------------
-static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags)
+static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
 {
   gtx::CountArgs a;
   a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart;
   a.histA = c->d_histA; a.histB = c->d_histB; a.info = c->d_info;
-  a.nClasses = c->nClasses; a.chunksPerWave = c->chunksPerWave;
-  a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0;
+  a.nClasses = c->nClasses;
+  // span of one wave: long enough to amortise the two window seeks at its start, short enough that
+  // the grid has >= ~2 rounds of the 8192 wave slots of the chip (256 CUs x 32 waves)
+  int cpw = c->chunksPerWave;
+  if (cpw <= 0) { int64_t nChunks = (nReads + 63) >> 6; cpw = (int)std::min<int64_t>(128, std::max<int64_t>(8, nChunks / 16384)); }
+  const int r = std::max(1, std::min(4, c->prefetch));
+  a.chunksPerWave = (cpw + r - 1) / r * r;
+  a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0; a.prefetch = c->prefetch;
   return a;
 }
 
@@ -219,7 +228,7 @@ int gtx_count_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int
   if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[0], c->stream)); }
   int rc = count_begin(c); if (rc) return rc;
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags), (flags & GTX_READS_SORTED) != 0, c->stream));
+  HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), (flags & GTX_READS_SORTED) != 0, c->stream));
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   rc = count_end(c, d_hits); if (rc) return rc;
   if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
@@ -279,7 +288,7 @@ int gtx_count(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t 
     const int64_t cnt = std::min(batch, n - off);
     HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
     if (weights) HIPCHK(c, hipMemcpyAsync(c->d_weights, weights + off, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, gtx::launch_count(c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags), (flags & GTX_READS_SORTED) != 0, c->stream));
+    HIPCHK(c, gtx::launch_count(c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags, cnt), (flags & GTX_READS_SORTED) != 0, c->stream));
     if (n > batch) {
       // fold this batch's info (indices are batch-relative) and reset for the next one
       HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));

@@ -24,6 +24,7 @@ struct CountArgs {
   int chunksPerWave;             // 64-read chunks one wave streams
   int checkSorted;               // verify (class >> sortClassShift, start) order
   int sortClassShift;
+  int prefetch;                  // chunks kept in flight per wave (1..4)
 };
 
 struct ScanArgs {

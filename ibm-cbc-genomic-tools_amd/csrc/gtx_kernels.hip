@@ -57,28 +57,35 @@ __device__ __forceinline__ i64 wave_sum(i64 v)
 // ---------------------------------------------------------------------------------------------
 // One boundary array being walked by one wave.  Uniform members live in SGPRs; W, Wn, acc are
 // per-lane.  Lane L of W holds arr[base-1+L] (kLo below the class segment, kHi above it); slot j
-// (global rank base+j) is bounded below by lane j and above by lane j+1.
+// (global rank base+j) is bounded below by lane j (prevW) and above by lane j+1 (curW).
+//
+// A key x belongs to the slots at or below boundary W iff  below(x, W):
+//   STRICT = false (ends array E, keys = read starts):  x <= W      rank = #{E_j <  x}
+//   STRICT = true  (starts array S, keys = read ends):  x <  W      rank = #{S_j <= x}
 // ---------------------------------------------------------------------------------------------
-template <bool WEIGHTED>
-struct Walk {
+struct Seg { int start, end, cls; };            // class segment [start,end) of both boundary arrays
+
+template <bool WEIGHTED, bool STRICT>
+struct Win {
   typedef typename std::conditional<WEIGHTED, i64, unsigned>::type acc_t;
   const int *arr;       // sorted boundaries of all classes
   u64 *hist;            // rank histogram, index = rank + class id
-  int segStart, segEnd; // class segment [segStart, segEnd) in arr
-  int shift;            // class id (slot shift)
   int base;             // global rank of slot 0
   int j;                // current slot 0..62
   int prevW, curW;      // arr[base+j-1], arr[base+j]
   acc_t pend;           // weight pending for slot j
   int W, Wn;            // window and the prefetched next window
   acc_t acc;            // per-lane accumulator (lane L <-> slot L-1)
-  bool valid;
 
-  __device__ __forceinline__ int load_window(int b, int lane) const
+  static __device__ __forceinline__ bool below(int x, int w) { return STRICT ? x < w : x <= w; }
+  // boundary v sorts before key x  (v counts towards x's rank)
+  static __device__ __forceinline__ bool before(int v, int x) { return STRICT ? v <= x : v < x; }
+
+  __device__ __forceinline__ int load_window(const Seg &sg, int b, int lane) const
   {
     int idx = b - 1 + lane;
-    int v = idx < segStart ? kLo : kHi;
-    if (idx >= segStart && idx < segEnd) v = arr[idx];
+    int v = idx < sg.start ? kLo : kHi;
+    if (idx >= sg.start && idx < sg.end) v = arr[idx];
     return v;
   }
 
@@ -87,39 +94,31 @@ struct Walk {
     if (pend != 0) { if (lane == j + 1) acc += pend; pend = 0; }
   }
 
-  __device__ __forceinline__ void flush(int lane)
+  __device__ __forceinline__ void flush(const Seg &sg, int lane)
   {
     deposit(lane);
-    if (acc != 0) atomicAdd(&hist[(i64)base - 1 + lane + shift], (u64)(i64)acc);
+    if (acc != 0) atomicAdd(&hist[(i64)base - 1 + lane + sg.cls], (u64)(i64)acc);
     acc = 0;
   }
 
-  __device__ __forceinline__ void set_class(int s0, int s1, int cls, int lane)
+  // position slot 0 at rank p (the caller has flushed)
+  __device__ __forceinline__ void place(const Seg &sg, int p, int lane)
   {
-    if (valid) flush(lane);
-    segStart = s0; segEnd = s1; shift = cls; valid = false;
-  }
-
-  // position slot 0 at rank p
-  __device__ __forceinline__ void place(int p, int lane)
-  {
-    if (valid) flush(lane);
     base = p; j = 0; pend = 0; acc = 0;
-    W = load_window(base, lane);
-    Wn = load_window(base + kSlots, lane);
+    W = load_window(sg, base, lane);
+    Wn = load_window(sg, base + kSlots, lane);
     prevW = rdlane(W, 0); curW = rdlane(W, 1);
-    valid = true;
   }
 
-  // wave-cooperative 64-ary lower bound: #{arr[segStart..segEnd) < key} + segStart
-  __device__ __forceinline__ int lower_bound(int key, int lane) const
+  // wave-cooperative 64-ary search: sg.start + #{v in arr[sg.start..sg.end) : before(v, key)}
+  __device__ __forceinline__ int rank_of(const Seg &sg, int key, int lane) const
   {
-    int lo = segStart, hi = segEnd;
+    int lo = sg.start, hi = sg.end;
     while (hi - lo > 64) {
       int step = (hi - lo + 63) >> 6;
       i64 idx = (i64)lo + (i64)lane * step;
       int v = idx < hi ? arr[idx] : kHi;
-      int nless = __popcll(__ballot(v < key));
+      int nless = __popcll(__ballot(idx < hi && before(v, key)));
       if (nless == 0) { hi = lo; break; }
       int nlo = lo + (nless - 1) * step + 1;
       i64 nhi = (i64)lo + (i64)nless * step;
@@ -127,156 +126,264 @@ struct Walk {
     }
     int idx = lo + lane;
     int v = idx < hi ? arr[idx] : kHi;
-    return lo + __popcll(__ballot(v < key));
+    return lo + __popcll(__ballot(idx < hi && before(v, key)));
   }
 
-  __device__ __forceinline__ void seek(int key, u64 m, int lane)
+  __device__ __forceinline__ void seek(const Seg &sg, int key, u64 m, int lane)
   {
     int k = wave_min(((m >> lane) & 1) ? key : kHi);
-    place(lower_bound(k, lane), lane);
+    place(sg, rank_of(sg, k, lane), lane);
   }
 
   // returns true when the register window was exchanged
-  __device__ __forceinline__ bool move_fwd(int lane)
+  __device__ __forceinline__ bool fwd(const Seg &sg, int lane)
   {
     deposit(lane);
     bool sw = false;
     if (++j == kSlots) {
-      flush(lane);
-      base += kSlots; j = 0; W = Wn; Wn = load_window(base + kSlots, lane); sw = true;
+      flush(sg, lane);
+      base += kSlots; j = 0; W = Wn; Wn = load_window(sg, base + kSlots, lane); sw = true;
     }
     prevW = curW; curW = rdlane(W, j + 1);
     return sw;
   }
 
-  __device__ __forceinline__ void move_back(int lane)
+  __device__ __forceinline__ void back(const Seg &sg, int lane)
   {
     deposit(lane);
     if (--j < 0) {
-      flush(lane);
-      base -= kSlots; j = kSlots - 1; Wn = W; W = load_window(base, lane);
+      flush(sg, lane);
+      base -= kSlots; j = kSlots - 1; Wn = W; W = load_window(sg, base, lane);
     }
     curW = prevW; prevW = rdlane(W, j);
   }
 
-  // scattered lanes: individual binary search + atomic
-  __device__ __forceinline__ void slow(int key, i64 w, u64 m, int lane)
+  // one lane on its own: binary search + atomic
+  __device__ __forceinline__ void lane_add(const Seg &sg, int key, i64 w) const
   {
-    if ((m >> lane) & 1) {
-      int lo = segStart, hi = segEnd;
-      while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (arr[mid] < key) lo = mid + 1; else hi = mid; }
-      atomicAdd(&hist[(i64)lo + shift], (u64)w);
-    }
+    int lo = sg.start, hi = sg.end;
+    while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (before(arr[mid], key)) lo = mid + 1; else hi = mid; }
+    atomicAdd(&hist[(i64)lo + sg.cls], (u64)w);
   }
 
-  // Add the lanes of m (keys `key`, weights `w`) to the histogram.
-  __device__ __forceinline__ void walk(int key, i64 w, u64 m, int lane)
+  // Add the lanes of m (keys `key`, weights `w`) to the histogram; returns the lanes it left
+  // for lane_add() because their keys are spread over too many windows (then `valid` is dropped).
+  __device__ __forceinline__ u64 walk(const Seg &sg, int key, int w, u64 m, int lane, bool &valid)
   {
-    if (!valid) seek(key, m, lane);
+    if (!valid) { seek(sg, key, m, lane); valid = true; }
     // backward: some key at or below the boundary under the current slot
-    int back = 0;
-    while (__ballot(key <= prevW) & m) {
-      if (++back > 6) { seek(key, m, lane); break; }
-      move_back(lane);
+    int nback = 0;
+    while (__ballot(below(key, prevW)) & m) {
+      if (++nback > 6) { flush(sg, lane); seek(sg, key, m, lane); break; }
+      back(sg, lane);
     }
     // forward: lanes at or below curW belong to slots <= j; the rest is still ahead
     u64 done = 0; int adv = 0;
     for (;;) {
-      u64 le = __ballot(key <= curW) & m;
+      u64 le = __ballot(below(key, curW)) & m;
       u64 fresh = le & ~done;
       if (fresh) {
-        if (WEIGHTED) pend += (acc_t)wave_sum(((fresh >> lane) & 1) ? w : 0);
+        if (WEIGHTED) pend += (acc_t)wave_sum(((fresh >> lane) & 1) ? (i64)w : 0);
         else pend += (acc_t)__popcll(fresh);
       }
       done = le;
-      if (le == m) break;
-      if (move_fwd(lane) && ++adv > 2) {
-        slow(key, w, m & ~done, lane);        // keys spread over many windows: finish them one by one
-        break;
-      }
+      if (le == m) return 0;
+      if (fwd(sg, lane) && ++adv > 2) { flush(sg, lane); valid = false; return m & ~done; }
     }
   }
 };
 
 struct __attribute__((packed, aligned(4))) Tri { int c, s, e; };
 
-// ---------------------------------------------------------------------------------------------
-// Streaming count kernel ("walk").  One wave = chunksPerWave consecutive chunks of 64 reads.
-// ---------------------------------------------------------------------------------------------
+// per-wave running state of the streaming kernel (all wave-uniform except the windows inside A, B)
 template <bool WEIGHTED>
+struct WaveState {
+  Win<WEIGHTED, false> A;                       // ends array, keyed by read start
+  Win<WEIGHTED, true> B;                        // starts array, keyed by read end
+  bool validA, validB;
+  Seg sg;
+  int nNoClass, nDegen;
+  i64 firstDegen, firstUnsorted;
+  int pc, ps;                                   // order check: class/start of the previous read
+};
+
+// General path: one chunk of 64 reads (lane-resident in t, w); `active` masks a partial chunk.
+// Lanes whose read is of the wave's current class go through the two register windows; any other
+// lane (class change inside a chunk, interleaved classes, keys scattered over many windows) adds
+// itself with two binary searches.  Reads of an unknown class or with start > end are only counted
+// into gtx_count_info.
+template <bool WEIGHTED>
+__device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountArgs &a, const Tri &t, int w, u64 active, i64 firstIndex, int lane)
+{
+  if (a.checkSorted) {
+    int cc = t.c >> a.sortClassShift;
+    int upc = __shfl_up(cc, 1), ups = __shfl_up(t.s, 1);
+    if (lane == 0) { upc = st.pc; ups = st.ps; }
+    u64 bad = __ballot(cc < upc || (cc == upc && t.s < ups)) & active;
+    if (bad) { i64 at = firstIndex + (__ffsll((unsigned long long)bad) - 1); if (at < st.firstUnsorted) st.firstUnsorted = at; }
+    int last = 63 - __clzll(active);
+    st.pc = rdlane(cc, last); st.ps = rdlane(t.s, last);
+  }
+
+  // the wave follows the class of its first read
+  const int c0 = rdlane(t.c, 0);
+  if (c0 != st.sg.cls && (unsigned)c0 < (unsigned)a.nClasses) {
+    if (st.validA) st.A.flush(st.sg, lane);
+    if (st.validB) st.B.flush(st.sg, lane);
+    st.validA = st.validB = false;
+    st.sg.start = rfl(a.segStart[c0]); st.sg.end = rfl(a.segStart[c0 + 1]); st.sg.cls = c0;
+  }
+  const u64 degen = __ballot(t.s > t.e) & active;
+  const u64 noclass = __ballot((unsigned)t.c >= (unsigned)a.nClasses) & active;
+  const u64 mine = __ballot(t.c == st.sg.cls) & active & ~degen & ~noclass;
+  const u64 other = active & ~mine & ~degen & ~noclass;      // valid reads of another class
+  if (degen | noclass) {
+    st.nNoClass += __popcll(noclass);
+    u64 dg = degen & ~noclass;
+    if (dg) { st.nDegen += __popcll(dg); i64 at = firstIndex + (__ffsll((unsigned long long)dg) - 1); if (at < st.firstDegen) st.firstDegen = at; }
+  }
+  if (mine && st.sg.start != st.sg.end) {
+    u64 ra = st.A.walk(st.sg, t.s, w, mine, lane, st.validA);
+    u64 rb = st.B.walk(st.sg, t.e, w, mine, lane, st.validB);
+    if (ra | rb) {
+      if ((ra >> lane) & 1) st.A.lane_add(st.sg, t.s, w);
+      if ((rb >> lane) & 1) st.B.lane_add(st.sg, t.e, w);
+    }
+  }
+  if (other) {
+    if ((other >> lane) & 1) {
+      Seg so; so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c;
+      if (so.start != so.end) { st.A.lane_add(so, t.s, w); st.B.lane_add(so, t.e, w); }
+    }
+  }
+}
+
+// Fast path for R x 64 reads of the current class, all valid, unweighted, window placed and no key
+// behind the current slot.  k[r] are the keys.  Returns false (having changed nothing) when the
+// general path must take the step.
+template <int R, class WIN>
+__device__ __forceinline__ bool walk_fast(WIN &X, const Seg &sg, const int (&k)[R], int lane, bool &valid)
+{
+  int kmin = k[0], kmax = k[0];
+#pragma unroll
+  for (int r = 1; r < R; ++r) { kmin = k[r] < kmin ? k[r] : kmin; kmax = k[r] > kmax ? k[r] : kmax; }
+  if (__ballot(WIN::below(kmin, X.prevW))) return false;                 // something behind the slot
+  if (__ballot(WIN::below(kmax, X.curW)) == ~0ull) { X.pend += 64u * R; return true; }   // no boundary crossed
+  unsigned cprev = 0; int adv = 0;
+  for (;;) {
+    unsigned c = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) c += (unsigned)__popcll(__ballot(WIN::below(k[r], X.curW)));
+    X.pend += c - cprev; cprev = c;
+    if (c == 64u * R) return true;
+    if (X.fwd(sg, lane) && ++adv > 2) {
+      // keys spread over many windows: every key above the boundary just passed adds itself
+#pragma unroll
+      for (int r = 0; r < R; ++r) if (!WIN::below(k[r], X.prevW)) X.lane_add(sg, k[r], 1);
+      X.flush(sg, lane); valid = false;
+      return true;
+    }
+  }
+}
+
+// One wave owns chunksPerWave*64 consecutive reads and takes them in steps of R x 64 (register r of
+// lane l holds read 64 r + l of the step: R coalesced 768-byte requests).  The scalar work per step
+// (loop control, class / validity test, two "did anything cross a boundary" tests) is amortised over
+// R x 64 reads; one step is kept in flight while the previous one is processed, so a CU has
+// 32 waves x R x 768 B of HBM reads outstanding.
+template <bool WEIGHTED, int R>
 __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n,
                                                          CountArgs a)
 {
   const int lane = threadIdx.x & 63;
-  const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const i64 nChunks = (n + 63) >> 6;
-  i64 chunk = wave * a.chunksPerWave;
-  if (chunk >= nChunks) return;
-  i64 chunkEnd = chunk + a.chunksPerWave; if (chunkEnd > nChunks) chunkEnd = nChunks;
+  const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + rfl(threadIdx.x >> 6);
+  const i64 first = wave * (i64)a.chunksPerWave * 64;          // first read of this wave's span
+  if (first >= n) return;
+  i64 cnt = n - first; if (cnt > (i64)a.chunksPerWave * 64) cnt = (i64)a.chunksPerWave * 64;
+  const int nMine = (int)cnt;                                  // reads in this span
+  const int nSteps = (nMine + 64 * R - 1) / (64 * R);
 
-  Walk<WEIGHTED> A, B;
-  A.arr = a.sortedE; A.hist = a.histA; A.valid = false; A.acc = 0; A.pend = 0; A.j = 0; A.base = 0; A.segStart = A.segEnd = 0; A.shift = 0;
-  B.arr = a.sortedS; B.hist = a.histB; B.valid = false; B.acc = 0; B.pend = 0; B.j = 0; B.base = 0; B.segStart = B.segEnd = 0; B.shift = 0;
-  A.W = A.Wn = B.W = B.Wn = kHi; A.prevW = B.prevW = kLo; A.curW = B.curW = kHi;
-  int curClass = -1;
-  i64 nNoClass = 0, nDegen = 0, firstDegen = INT64_MAX, firstUnsorted = INT64_MAX;
+  WaveState<WEIGHTED> st;
+  st.A.arr = a.sortedE; st.A.hist = a.histA; st.B.arr = a.sortedS; st.B.hist = a.histB;
+  st.A.acc = st.B.acc = 0; st.A.pend = st.B.pend = 0; st.A.j = st.B.j = 0; st.A.base = st.B.base = 0;
+  st.A.W = st.A.Wn = st.B.W = st.B.Wn = kHi; st.A.prevW = st.B.prevW = kLo; st.A.curW = st.B.curW = kHi;
+  st.validA = st.validB = false;
+  st.sg.start = 0; st.sg.end = 0; st.sg.cls = -1;
+  st.nNoClass = 0; st.nDegen = 0; st.firstDegen = INT64_MAX; st.firstUnsorted = INT64_MAX;
+  st.pc = kLo; st.ps = kLo;
+  if (a.checkSorted && first > 0) { Tri p = reads[first - 1]; st.pc = rfl(p.c) >> a.sortClassShift; st.ps = rfl(p.s); }
 
-  // order check state: the read just before this wave's span
-  int pc = kLo, ps = kLo;
-  const bool check = a.checkSorted;
-  if (check && chunk > 0) { Tri p = reads[chunk * 64 - 1]; pc = rfl(p.c) >> a.sortClassShift; ps = rfl(p.s); }
+  const char *base = (const char *)(reads + first);            // wave-uniform
+  const int *wbase = WEIGHTED ? weights + first : nullptr;
+  const unsigned loff = (unsigned)lane * 12u;
 
-  i64 i = chunk * 64 + lane;
-  Tri t; t.c = -1; t.s = 0; t.e = 0; int w = 1;
-  if (i < n) { t = reads[i]; if (WEIGHTED) w = weights[i]; }
-
-  for (; chunk < chunkEnd; ++chunk) {
-    // prefetch the next chunk while this one is processed
-    i64 ni = i + 64;
-    Tri nt; nt.c = -1; nt.s = 0; nt.e = 0; int nw = 1;
-    if (chunk + 1 < chunkEnd && ni < n) { nt = reads[ni]; if (WEIGHTED) nw = weights[ni]; }
-
-    const u64 active = __ballot(i < n);
-
-    if (check) {
-      int cc = t.c >> a.sortClassShift;
-      int upc = __shfl_up(cc, 1), ups = __shfl_up(t.s, 1);
-      if (lane == 0) { upc = pc; ups = ps; }
-      u64 bad = __ballot(cc < upc || (cc == upc && t.s < ups)) & active;
-      if (bad) { i64 at = chunk * 64 + (__ffsll((unsigned long long)bad) - 1); if (at < firstUnsorted) firstUnsorted = at; }
-      int last = 63 - __clzll(active);
-      pc = rdlane(cc, last); ps = rdlane(t.s, last);
-    }
-
-    u64 rem = active;
-    while (rem) {
-      const int c0 = rdlane(t.c, __ffsll((unsigned long long)rem) - 1);
-      u64 g = __ballot(t.c == c0) & rem;
-      rem &= ~g;
-      if ((unsigned)c0 >= (unsigned)a.nClasses) { nNoClass += __popcll(g); continue; }
-      u64 dg = __ballot(t.s > t.e) & g;
-      if (dg) {
-        nDegen += __popcll(dg);
-        i64 at = chunk * 64 + (__ffsll((unsigned long long)dg) - 1); if (at < firstDegen) firstDegen = at;
-        g &= ~dg; if (!g) continue;
+  Tri nx[R]; int nxw[R];
+  // load step `s` into nx (lanes past the end of the span get class -1)
+  auto load_step = [&](int s) {
+    const int at = s * 64 * R;
+    if (at + 64 * R <= nMine) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { nx[r] = *(const Tri *)(base + (size_t)(at + 64 * r) * 12 + loff); nxw[r] = WEIGHTED ? wbase[at + 64 * r + lane] : 1; }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        nx[r].c = -1; nx[r].s = 0; nx[r].e = 0; nxw[r] = 1;
+        if (at + 64 * r + lane < nMine) { nx[r] = *(const Tri *)(base + (size_t)(at + 64 * r) * 12 + loff); if (WEIGHTED) nxw[r] = wbase[at + 64 * r + lane]; }
       }
-      if (c0 != curClass) {
-        int s0 = a.segStart[c0], s1 = a.segStart[c0 + 1];
-        A.set_class(s0, s1, c0, lane); B.set_class(s0, s1, c0, lane);
-        curClass = c0;
-      }
-      if (A.segStart == A.segEnd) continue;      // class without reference regions
-      A.walk(t.s, w, g, lane);
-      B.walk(t.e + 1, w, g, lane);
     }
-    t = nt; w = nw; i = ni;
+  };
+  load_step(0);
+
+  for (int s = 0; s < nSteps; ++s) {
+    Tri t[R]; int w[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { t[r] = nx[r]; w[r] = nxw[r]; }
+    if (s + 1 < nSteps) load_step(s + 1);
+
+    const int at = s * 64 * R;
+    bool handled = false;
+    if (!WEIGHTED && !a.checkSorted && at + 64 * R <= nMine && st.validA && st.validB) {
+      // every read of the step: current class and start <= end ?
+      int odd = 0, dg = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { odd |= t[r].c ^ st.sg.cls; dg += t[r].s > t[r].e ? 1 : 0; }
+      if (__ballot((odd | dg) != 0) == 0) {
+        int ks[R], ke[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { ks[r] = t[r].s; ke[r] = t[r].e; }
+        // both windows must be able to take the step; test B's precondition before A changes state
+        int kemin = ke[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) kemin = ke[r] < kemin ? ke[r] : kemin;
+        if (__ballot(Win<WEIGHTED, true>::below(kemin, st.B.prevW)) == 0 && walk_fast<R>(st.A, st.sg, ks, lane, st.validA)) {
+          if (st.validB) { bool ok = walk_fast<R>(st.B, st.sg, ke, lane, st.validB); (void)ok; }
+          else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) st.B.lane_add(st.sg, ke[r], 1);
+          }
+          handled = true;
+        }
+      }
+    }
+    if (!handled) {
+#pragma unroll 1
+      for (int r = 0; r < R; ++r) {
+        const int left = nMine - (at + 64 * r);
+        if (left <= 0) break;
+        Tri tt = t[0]; int ww = w[0];
+#pragma unroll
+        for (int q = 1; q < R; ++q) if (r == q) { tt = t[q]; ww = w[q]; }
+        const u64 active = left >= 64 ? ~0ull : ((1ull << left) - 1);
+        walk_chunk<WEIGHTED>(st, a, tt, ww, active, first + at + 64 * r, lane);
+      }
+    }
   }
-  if (A.valid) A.flush(lane);
-  if (B.valid) B.flush(lane);
+  if (st.validA) st.A.flush(st.sg, lane);
+  if (st.validB) st.B.flush(st.sg, lane);
   if (lane == 0) {
-    if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
-    if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen); }
-    if (firstUnsorted != INT64_MAX) atomicMin((i64 *)&a.info->first_unsorted, firstUnsorted);
+    if (st.nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)st.nNoClass);
+    if (st.nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)st.nDegen); atomicMin((i64 *)&a.info->first_degenerate, st.firstDegen); }
+    if (st.firstUnsorted != INT64_MAX) atomicMin((i64 *)&a.info->first_unsorted, st.firstUnsorted);
   }
 }
 
@@ -478,8 +585,12 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
     const i64 nChunks = (n + 63) >> 6;
     const i64 waves = (nChunks + a.chunksPerWave - 1) / a.chunksPerWave;
     const unsigned grid = (unsigned)((waves + 3) / 4);
-    if (weights) count_walk_kernel<true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-    else count_walk_kernel<false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    // a.prefetch = reads per lane per step (R)
+    if (weights) count_walk_kernel<true, 2><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (a.prefetch <= 1) count_walk_kernel<false, 1><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (a.prefetch == 2) count_walk_kernel<false, 2><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (a.prefetch == 3) count_walk_kernel<false, 3><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else count_walk_kernel<false, 4><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   } else {
     i64 blocks = (n + 255) / 256; if (blocks > 256 * 32) blocks = 256 * 32;
     if (weights) count_search_kernel<true><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
