@@ -1,0 +1,535 @@
+// genomic_intervals.cpp -- see genomic_intervals.h.  Host side only: ingest, option semantics,
+// error messages; every reduction is a call into libgtx.so (include/gtx.h).
+#include "genomic_intervals.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <iostream>
+
+#include "gtx.h"
+#include "gtx_bed.h"
+
+using gtxhost::BedPacker;
+using gtxhost::ChromTable;
+using gtxhost::LineSource;
+using gtxhost::PackedBatch;
+using gtxhost::PackError;
+using gtxhost::PackOptions;
+
+bool _MESSAGES_ = false;
+
+static char *CopyString(const char *s) { size_t n = strlen(s) + 1; char *p = new char[n]; memcpy(p, s, n); return p; }
+
+static void DieLine(long int n_line, const std::string &msg)
+{
+  fflush(stdout);
+  fprintf(stderr, "\n");
+  fprintf(stderr, "Error: Line %ld: %s\n", n_line, msg.c_str());
+  exit(1);
+}
+
+static void DiePack(const PackError &e)
+{
+  if (e.no_prefix) { fflush(stdout); fprintf(stderr, "%s\n", e.msg.c_str()); exit(1); }
+  DieLine(e.line, e.msg);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GenomicInterval / GenomicRegion
+// ---------------------------------------------------------------------------------------------------
+GenomicInterval::GenomicInterval(const char *chromosome, char strand, long int start, long int stop, long int n_line)
+{
+  CHROMOSOME = CopyString(chromosome); STRAND = strand; START = start; STOP = stop; this->n_line = n_line;
+}
+
+GenomicInterval::~GenomicInterval() { delete[] CHROMOSOME; }
+
+void GenomicInterval::PrintInterval() { printf("%s %c %ld %ld", CHROMOSOME, STRAND, START, STOP); }
+void GenomicInterval::PrintInterval(FILE *f) { fprintf(f, "%s %c %ld %ld", CHROMOSOME, STRAND, START, STOP); }
+
+GenomicRegion::GenomicRegion() : n_line(0), LABEL(NULL) {}
+
+GenomicRegion::~GenomicRegion()
+{
+  delete[] LABEL;
+  for (size_t k = 0; k < I.size(); k++) delete I[k];
+}
+
+void GenomicRegion::PrintError(std::string error_msg) { DieLine(n_line, error_msg); }
+
+size_t GenomicRegion::GetSize(bool skip_gaps)
+{
+  if (!skip_gaps) return (size_t)(I.back()->STOP - I.front()->START + 1);
+  size_t size = 0;
+  for (size_t k = 0; k < I.size(); k++) size += I[k]->GetSize();
+  return size;
+}
+
+long int GenomicRegion::GetLabelValue(long int max_label_value)
+{
+  if (max_label_value <= 1) return 1;
+  return std::min(max_label_value, atol(LABEL));
+}
+
+bool GenomicRegion::IsBefore(GenomicRegion *r, bool sorted_by_strand)
+{
+  GenomicInterval *a = I.front(), *b = r->I.front();
+  int d = strcmp(a->CHROMOSOME, b->CHROMOSOME);
+  if (d != 0) return d < 0;
+  if (sorted_by_strand && a->STRAND != b->STRAND) return a->STRAND < b->STRAND;
+  return a->START < b->START;
+}
+
+GenomicRegionBED::GenomicRegionBED(char *inp, long int n_line)
+{
+  this->n_line = n_line;
+  gtxhost::BedFields f; char *bad = NULL;
+  gtxhost::BedStatus st = gtxhost::ParseBedLine(inp, &f, &bad);
+  if (st == gtxhost::BED_TOO_FEW_TOKENS) PrintError("number of tokens should be at least 3 for BED format!");
+  if (st == gtxhost::BED_BAD_STRAND) { fflush(stdout); std::cerr << "Error: invalid strand '" << bad << "'!\n"; exit(1); }
+  n_tokens = f.n_tokens;
+  if (n_tokens == 12) PrintError("multi-interval (BED12) regions are outside the MI355X counting path!");
+  LABEL = CopyString(f.label ? f.label : "_");
+  I.push_back(new GenomicInterval(f.chrom, f.strand, f.start, f.stop, n_line));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GenomicRegionSet
+// ---------------------------------------------------------------------------------------------------
+GenomicRegionSet::GenomicRegionSet(char *file, unsigned long int buffer_size, bool verbose, bool load_in_memory, bool hide_header)
+{
+  this->file = file == NULL ? NULL : CopyString(file);
+  this->buffer_size = buffer_size;
+  this->verbose = verbose;
+  this->from_stdin = file == NULL;
+  this->load_in_memory = from_stdin ? false : load_in_memory;
+  this->hide_header = hide_header;
+  this->src = NULL; this->R = NULL; this->n_regions = 0; this->r_index = 0;
+  Init();
+}
+
+GenomicRegionSet::~GenomicRegionSet()
+{
+  delete[] file;
+  delete src;
+  if (R) {
+    long int n = load_in_memory ? n_regions : 1;
+    for (long int k = 0; k < n; k++) delete R[k];
+    delete[] R;
+  }
+}
+
+void GenomicRegionSet::PrintError(std::string error_msg)
+{
+  fflush(stdout);
+  fprintf(stderr, "\n");
+  fprintf(stderr, "Error: %s\n", error_msg.c_str());
+  exit(1);
+}
+
+// genomic_intervals.cpp:3736-3759: by the number of TAB-separated tokens of the first data line
+void GenomicRegionSet::DetectFormat(const char *line)
+{
+  if (line[0] == '>' || line[0] == '@' || (line[0] == '#' && line[1] == '#')) PrintError("unsupported input format!\n");
+  int nt = gtxhost::CountTokensLike(line, '\t');
+  bool bed = nt == 1 || (nt >= 3 && nt <= 6);
+  if (!bed && nt >= 6) {
+    std::string copy(line);
+    const char *p = copy.c_str(); int tabs = 0;
+    while (*p && tabs < 5) { if (*p == '\t') tabs++; p++; }
+    std::string tok(p, strcspn(p, "\t"));
+    bed = tok.find('+') != std::string::npos || tok.find('-') != std::string::npos;
+  }
+  if (!bed) PrintError("unsupported input format!\n");     // REG / SAM / GFF are outside the path
+  format = "BED";
+}
+
+void GenomicRegionSet::Init()
+{
+  std::string err;
+  src = LineSource::Open(file, &err);
+  if (!src) { fprintf(stderr, "%s\n", err.c_str()); exit(1); }
+  char *line = src->Next();
+  while (line && (strncmp(line, "browser ", 8) == 0 || strncmp(line, "track ", 6) == 0)) {
+    if (!hide_header) printf("%s\n", line);
+    line = src->Next();
+  }
+  if (!line) { format = "EMPTY"; n_regions = 0; }
+  else DetectFormat(line);
+
+  if (load_in_memory) {
+    std::vector<GenomicRegion *> regs;
+    for (; line; line = src->Next()) regs.push_back(new GenomicRegionBED(line, src->line_no()));
+    n_regions = (long int)regs.size();
+    R = n_regions > 0 ? new GenomicRegion *[n_regions] : NULL;
+    for (long int k = 0; k < n_regions; k++) R[k] = regs[k];
+  } else if (line) {
+    n_regions = 1;
+    cur_raw = line;
+    R = new GenomicRegion *[1];
+    R[0] = new GenomicRegionBED(line, src->line_no());
+  }
+  if (verbose) {
+    std::cerr << "Reading from '" << (file == NULL ? "<standard input>" : file) << "'; ";
+    std::cerr << "read-from-stdin = " << (from_stdin ? "true" : "false") << "; ";
+    std::cerr << "load-in-memory = " << (load_in_memory ? "true" : "false") << "; ";
+    std::cerr << "number of regions = " << n_regions << "; ";
+    std::cerr << "format = " << format << "\n";
+  }
+  r_index = 0;
+}
+
+void GenomicRegionSet::Reset()
+{
+  if (from_stdin) PrintError("stdin cannot be reset!\n");
+  if (load_in_memory) { r_index = 0; return; }
+  if (R) { delete R[0]; delete[] R; R = NULL; }
+  delete src; src = NULL;
+  Init();
+}
+
+GenomicRegion *GenomicRegionSet::Get()
+{
+  if (n_regions == 0) return NULL;
+  return !load_in_memory ? R[0] : (r_index >= n_regions ? NULL : R[r_index]);
+}
+
+GenomicRegion *GenomicRegionSet::Next(bool retain_current)
+{
+  if (load_in_memory) { ++r_index; return r_index >= n_regions ? NULL : R[r_index]; }
+  if (n_regions == 0 || !src) return NULL;
+  char *line = src->Next();
+  if (!line) return NULL;
+  if (R[0] && !retain_current) delete R[0];
+  cur_raw = line;
+  R[0] = new GenomicRegionBED(line, src->line_no());
+  return R[0];
+}
+
+LineSource *GenomicRegionSet::DetachStream(std::string *current_line, long int *current_line_no)
+{
+  if (load_in_memory) PrintError("[DetachStream] the set is loaded in memory!");
+  *current_line = n_regions > 0 ? cur_raw : std::string();
+  *current_line_no = n_regions > 0 ? R[0]->n_line : 0;
+  if (n_regions > 0) { delete R[0]; R[0] = NULL; }
+  n_regions = 0;
+  return src;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GPU context shared by the classes of this file
+// ---------------------------------------------------------------------------------------------------
+static gtx_ctx *Device()
+{
+  static gtx_ctx *ctx = NULL;
+  if (!ctx) {
+    const char *d = getenv("GTX_DEVICE");
+    ctx = gtx_create(d ? atoi(d) : 0);
+    if (!ctx) { fflush(stdout); fprintf(stderr, "\nError: %s\n", gtx_last_error(NULL)); exit(1); }
+  }
+  return ctx;
+}
+
+static void CheckGtx(gtx_ctx *c, int rc)
+{
+  if (rc != GTX_OK) { fflush(stdout); fprintf(stderr, "\nError: [gtx %d] %s\n", rc, gtx_last_error(c)); exit(1); }
+}
+
+// Packs the rest of a query/input set batch by batch and hands every batch to `sink`.
+// In-memory sets are walked region by region with the same rules.
+template <class Sink>
+static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
+{
+  const size_t batch_reads = 32u << 20;
+  PackedBatch batch; PackError err;
+  if (!set->load_in_memory) {
+    std::string first; long int first_no = 0;
+    LineSource *src = set->DetachStream(&first, &first_no);
+    BedPacker packer(src, opt);
+    if (first_no > 0) packer.Prime(first, first_no);
+    for (;;) {
+      bool more = packer.NextBatch(&batch, batch_reads, &err);
+      if (err.set) DiePack(err);
+      if (!batch.tri.empty()) sink(batch);
+      if (!more) break;
+    }
+    return;
+  }
+  // in-memory set: re-emit its regions as lines through the same packer rules
+  std::string text;
+  for (GenomicRegion *r = set->Get(); r != NULL; r = set->Next()) {
+    GenomicInterval *i = r->I.front();
+    char buf[64];
+    text += i->CHROMOSOME; text += '\t';
+    snprintf(buf, sizeof buf, "%ld\t%ld\t", i->START - 1, i->STOP); text += buf;
+    text += r->LABEL; text += "\t0\t"; text += i->STRAND; text += '\n';
+  }
+  BedPacker packer(NULL, opt);
+  packer.PrimeBlock(text, 1);
+  for (;;) {
+    bool more = packer.NextBatch(&batch, batch_reads, &err);
+    if (err.set) DiePack(err);
+    if (!batch.tri.empty()) sink(batch);
+    if (!more) break;
+  }
+}
+
+// quick order hint for the kernel choice (a wrong hint only costs speed): sample adjacent pairs
+static bool LooksSorted(const std::vector<int32_t> &tri)
+{
+  const size_t n = tri.size() / 3;
+  if (n < 2) return true;
+  const size_t stride = n > 4096 ? n / 4096 : 1;
+  for (size_t i = 0; i + 1 < n; i += stride) {
+    const int32_t *a = &tri[3 * i], *b = a + 3;
+    if (b[0] < a[0] || (b[0] == a[0] && b[1] < a[1])) return false;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GenomicRegionSetOverlaps
+// ---------------------------------------------------------------------------------------------------
+GenomicRegionSetOverlaps::GenomicRegionSetOverlaps(GenomicRegionSet *QuerySet, GenomicRegionSet *IndexSet)
+{
+  this->QuerySet = QuerySet; this->IndexSet = IndexSet; current_qreg = NULL; current_ireg = NULL;
+}
+
+GenomicRegionSetOverlaps::~GenomicRegionSetOverlaps() {}
+
+unsigned long int *GenomicRegionSetOverlaps::CountIndexOverlaps(bool match_gaps, bool ignore_strand, long int max_label_value)
+{
+  (void)match_gaps;   // single-interval regions have no gaps: both settings select the same pairs (genomic_intervals.cpp:5226)
+  if (IndexSet->load_in_memory == false) {
+    fprintf(stderr, "[GenomicRegionSetOverlaps::CountIndexOverlaps]: index set must be loaded in memory for this operation!\n");
+    exit(1);
+  }
+  const long int M = IndexSet->n_regions;
+  const bool sorted = UsesSortedMerge(), by_strand = SortedByStrand();
+  for (long int k = 0; k < M; k++) IndexSet->R[k]->n_line = k;                       // :5309
+
+  // ---- index side ----
+  ChromTable chroms;
+  for (long int k = 0; k < M; k++) {
+    GenomicInterval *i = IndexSet->R[k]->I.front();
+    if (!sorted && (i->START > i->STOP || i->STOP <= 0)) continue;                 // :5609, :5659
+    chroms.Add(i->CHROMOSOME);
+  }
+  chroms.Freeze();
+  const int n_chrom = chroms.size();
+  const bool strand_aware = !ignore_strand;
+  bool zero_length_refs = false;
+  std::vector<int32_t> refs((size_t)3 * (M > 0 ? M : 1));
+  for (long int k = 0; k < M; k++) {
+    GenomicRegion *r = IndexSet->R[k];
+    GenomicInterval *i = r->I.front();
+    if (sorted) {
+      if (k > 0 && r->IsBefore(IndexSet->R[k - 1], by_strand))                    // :5868 (checked here for the whole set)
+        r->PrintError(std::string("index regions are not sorted (sorted-by-strand = ") + (by_strand ? "true" : "false") + ")!");
+      if (i->START > i->STOP + 1) r->PrintError("inverted interval (end < start) is outside the MI355X counting path!");
+      if (i->START == i->STOP + 1) zero_length_refs = true;
+    }
+    if (i->START >= INT_MAX - 1 || i->STOP >= INT_MAX - 1 || i->START <= INT_MIN + 1 || i->STOP <= INT_MIN + 1)
+      r->PrintError("coordinate does not fit the packed 32-bit representation of the MI355X path!");
+    int id = chroms.Find(i->CHROMOSOME);
+    if (id < 0) { refs[3 * k] = 0; refs[3 * k + 1] = 1; refs[3 * k + 2] = 0; continue; }   // invalid region: never matches
+    refs[3 * k] = id + ((strand_aware && i->STRAND == '-') ? n_chrom : 0);
+    refs[3 * k + 1] = (int32_t)i->START; refs[3 * k + 2] = (int32_t)i->STOP;
+  }
+  gtx_ctx *ctx = Device();
+  const int n_classes = std::max(1, n_chrom * (strand_aware ? 2 : 1));
+  CheckGtx(ctx, gtx_set_refs_ex(ctx, refs.data(), M, n_classes, sorted ? GTX_REFS_KEEP_ZERO_LENGTH : 0));
+
+  // ---- query side: stream -> packed batches -> device ----
+  PackOptions opt;
+  opt.mode = sorted ? gtxhost::PACK_OVERLAPS_SORTED : gtxhost::PACK_OVERLAPS_UNSORTED;
+  opt.chroms = &chroms; opt.strand_aware = strand_aware; opt.sorted_by_strand = by_strand;
+  opt.max_label_value = max_label_value; opt.collect_zero_length = sorted && zero_length_refs;
+  std::vector<int32_t> zero_len;
+  CheckGtx(ctx, gtx_count_begin(ctx));
+  const uint32_t mode_flags = sorted ? GTX_ZERO_LENGTH_OK : 0;
+  DrainSet(QuerySet, opt, [&](const PackedBatch &b) {
+    uint32_t flags = mode_flags | (LooksSorted(b.tri) ? GTX_READS_SORTED : 0);
+    CheckGtx(ctx, gtx_count_add(ctx, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), flags));
+    zero_len.insert(zero_len.end(), b.zero_len.begin(), b.zero_len.end());
+  });
+  unsigned long int *hits = new unsigned long int[M > 0 ? M : 1];
+  gtx_count_info info;
+  CheckGtx(ctx, gtx_count_end(ctx, (uint64_t *)hits, &info));
+  if (info.n_degenerate != 0) { fflush(stdout); fprintf(stderr, "\nError: internal: the packer let %ld degenerate reads through\n", (long)info.n_degenerate); exit(1); }
+
+  // sorted merge only: a zero-length read never overlaps a zero-length region at the same spot
+  // (rS <= qE and rE >= qS cannot both hold), while the rank difference counts it as -1: undo that.
+  if (!zero_len.empty()) {
+    for (long int k = 0; k < M; k++) {
+      if (refs[3 * k + 1] != refs[3 * k + 2] + 1) continue;
+      for (size_t z = 0; z + 2 < zero_len.size(); z += 3)
+        if (zero_len[z] == refs[3 * k] && zero_len[z + 1] == refs[3 * k + 1]) hits[k] += (unsigned long int)(long int)zero_len[z + 2];
+    }
+  }
+  return hits;
+}
+
+static void NoEnumeration()
+{
+  fflush(stdout);
+  fprintf(stderr, "\nError: per-pair overlap enumeration (GetMatch/NextMatch) is outside the MI355X counting path!\n");
+  exit(1);
+}
+
+UnsortedGenomicRegionSetOverlaps::UnsortedGenomicRegionSetOverlaps(GenomicRegionSet *QuerySet, GenomicRegionSet *IndexSet, const char *bin_bits)
+    : GenomicRegionSetOverlaps(QuerySet, IndexSet)
+{
+  (void)bin_bits;     // -B tunes the reference's bin index; the rank structure on the device has no bins
+  if (IndexSet->load_in_memory == false) { fprintf(stderr, "Error: [UnsortedGenomicRegionSetOverlaps] index regions must be loaded in memory!\n"); exit(1); }
+}
+UnsortedGenomicRegionSetOverlaps::~UnsortedGenomicRegionSetOverlaps() {}
+GenomicRegion *UnsortedGenomicRegionSetOverlaps::GetQuery() { return current_qreg = QuerySet->Get(); }
+GenomicRegion *UnsortedGenomicRegionSetOverlaps::NextQuery() { return current_qreg = QuerySet->Next(); }
+GenomicRegion *UnsortedGenomicRegionSetOverlaps::GetMatch() { NoEnumeration(); return NULL; }
+GenomicRegion *UnsortedGenomicRegionSetOverlaps::NextMatch() { NoEnumeration(); return NULL; }
+bool UnsortedGenomicRegionSetOverlaps::Done() { return current_qreg == NULL; }
+
+SortedGenomicRegionSetOverlaps::SortedGenomicRegionSetOverlaps(GenomicRegionSet *QuerySet, GenomicRegionSet *IndexSet, bool sorted_by_strand)
+    : GenomicRegionSetOverlaps(QuerySet, IndexSet)
+{
+  this->sorted_by_strand = sorted_by_strand;
+  current_qreg = QuerySet->Get();
+  current_ireg = IndexSet->Get();
+}
+SortedGenomicRegionSetOverlaps::~SortedGenomicRegionSetOverlaps() {}
+GenomicRegion *SortedGenomicRegionSetOverlaps::GetQuery() { return current_qreg = QuerySet->Get(); }
+GenomicRegion *SortedGenomicRegionSetOverlaps::NextQuery()
+{
+  GenomicRegion *prev = QuerySet->Get();
+  GenomicRegion *next = QuerySet->Next(true);
+  if (next != NULL && prev != NULL && next->IsBefore(prev, sorted_by_strand))
+    next->PrintError(std::string("query regions are not sorted (sorted-by-strand = ") + (sorted_by_strand ? "true" : "false") + ")!");
+  if (!QuerySet->load_in_memory && next != NULL) delete prev;
+  return current_qreg = next;
+}
+GenomicRegion *SortedGenomicRegionSetOverlaps::GetMatch() { NoEnumeration(); return NULL; }
+GenomicRegion *SortedGenomicRegionSetOverlaps::NextMatch() { NoEnumeration(); return NULL; }
+bool SortedGenomicRegionSetOverlaps::Done() { return current_qreg == NULL; }
+
+// ---------------------------------------------------------------------------------------------------
+// scanners
+// ---------------------------------------------------------------------------------------------------
+GenomicRegionSetScanner::GenomicRegionSetScanner(GenomicRegionSet *R, StringLIntMap *bounds, long int win_step, long int win_size,
+                                                 long int max_label_value, bool ignore_strand, char preprocess)
+{
+  if (R->format == "SEQ") { std::cerr << "Error: this operation does not accept SEQ format!\n"; exit(1); }
+  if (bounds == NULL) { std::cerr << "Error: this operation requires genomic bounds!\n"; exit(1); }
+  this->R = R; this->bounds = bounds; this->win_step = win_step; this->win_size = win_size;
+  this->max_label_value = max_label_value; this->ignore_strand = ignore_strand; this->preprocess = preprocess;
+  if (win_step <= 0 || win_size % win_step != 0) { std::cerr << "Error: window size must be a multiple of window step in 'GenomicRegionSetScanner'!\n"; exit(1); }
+  n_win_combine = win_size / win_step;
+  cur_block = 0; cur_win = 0; computed = false;
+}
+
+GenomicRegionSetScanner::~GenomicRegionSetScanner() {}
+
+void GenomicRegionSetScanner::Compute(bool sorted_rules)
+{
+  computed = true;
+  if (win_step > INT_MAX || win_size > INT_MAX) { std::cerr << "Error: window geometry does not fit the MI355X path!\n"; exit(1); }
+  ChromTable chroms;
+  for (StringLIntMap::iterator p = bounds->begin(); p != bounds->end(); p++) chroms.Add(p->first.c_str());
+  chroms.Freeze();
+  const int n_chrom = chroms.size(), ns = ignore_strand ? 1 : 2;
+  // iteration order of the reference: chromosomes in map order, '+' block then '-' block
+  std::vector<int32_t> class_len((size_t)std::max(1, n_chrom * ns));
+  std::vector<int64_t> class_off((size_t)std::max(1, n_chrom * ns));
+  long long total = 0;
+  chrom_names.clear(); n_windows.clear(); block_offset.clear();
+  for (int r = 0; r < n_chrom; r++) {
+    long int len = (*bounds)[chroms.name(r)];
+    if (len >= INT_MAX - 1) { std::cerr << "Error: chromosome length does not fit the MI355X path!\n"; exit(1); }
+    chrom_names.push_back(chroms.name(r));
+    for (int s = 0; s < ns; s++) {
+      long long nw = gtx_scan_n_windows(len < 0 ? 0 : len, win_step, win_size);
+      class_len[(size_t)(s * n_chrom + r)] = (int32_t)(len < 0 ? 0 : len);
+      class_off[(size_t)(s * n_chrom + r)] = total;
+      n_windows.push_back((long int)nw); block_offset.push_back(total);
+      total += nw;
+    }
+  }
+  values.assign((size_t)std::max<long long>(total, 1), 0);
+  if (n_chrom == 0) return;
+
+  PackOptions opt;
+  opt.mode = sorted_rules ? gtxhost::PACK_SCAN_SORTED : gtxhost::PACK_SCAN_UNSORTED;
+  opt.chroms = &chroms; opt.strand_aware = !ignore_strand; opt.sorted_by_strand = !ignore_strand;
+  opt.max_label_value = max_label_value;
+  std::vector<int32_t> tri, w;
+  DrainSet(R, opt, [&](const PackedBatch &b) {
+    if (sorted_rules && preprocess != '1') { fprintf(stderr, "Error: [SortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
+    if (!sorted_rules && preprocess != '1' && preprocess != 'c') { fprintf(stderr, "Error: [UnsortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
+    tri.insert(tri.end(), b.tri.begin(), b.tri.end());
+    w.insert(w.end(), b.w.begin(), b.w.end());
+  });
+  gtx_ctx *ctx = Device();
+  const char prep = (preprocess == 'c' && !sorted_rules) ? 'c' : '1';
+  CheckGtx(ctx, gtx_scan(ctx, tri.data(), w.empty() ? NULL : w.data(), (int64_t)(tri.size() / 3), class_len.data(), n_chrom * ns,
+                         (int32_t)win_step, (int32_t)win_size, prep, sorted_rules ? GTX_ZERO_LENGTH_OK : 0,
+                         (uint64_t *)values.data(), class_off.data()));
+}
+
+long int GenomicRegionSetScanner::Next()
+{
+  if (!computed) Compute(false);
+  while (cur_block < n_windows.size()) {
+    if (cur_win < n_windows[cur_block]) { cur_win++; return (long int)values[(size_t)(block_offset[cur_block] + cur_win - 1)]; }
+    cur_block++; cur_win = 0;
+  }
+  return -1;
+}
+
+void GenomicRegionSetScanner::PrintInterval(FILE *out_file)
+{
+  const int ns = ignore_strand ? 1 : 2;
+  fprintf(out_file, "%s %c %ld %ld", chrom_names[cur_block / ns].c_str(), (cur_block % ns) ? '-' : '+', win_step * (cur_win - 1) + 1,
+          win_step * (cur_win - 1) + win_size);
+}
+
+GenomicInterval *GenomicRegionSetScanner::GetInterval()
+{
+  const int ns = ignore_strand ? 1 : 2;
+  return new GenomicInterval(chrom_names[cur_block / ns].c_str(), (cur_block % ns) ? '-' : '+', win_step * (cur_win - 1) + 1,
+                             win_step * (cur_win - 1) + win_size);
+}
+
+SortedGenomicRegionSetScanner::SortedGenomicRegionSetScanner(GenomicRegionSet *R, StringLIntMap *bounds, long int win_step, long int win_size,
+                                                             long int max_label_value, bool ignore_strand, char preprocess)
+    : GenomicRegionSetScanner(R, bounds, win_step, win_size, max_label_value, ignore_strand, preprocess)
+{
+  Compute(true);
+}
+
+UnsortedGenomicRegionSetScanner::UnsortedGenomicRegionSetScanner(GenomicRegionSet *R, StringLIntMap *bounds, long int win_step, long int win_size,
+                                                                 long int max_label_value, bool ignore_strand, char preprocess)
+    : GenomicRegionSetScanner(R, bounds, win_step, win_size, max_label_value, ignore_strand, preprocess)
+{
+  Compute(false);
+}
+
+// ---------------------------------------------------------------------------------------------------
+StringLIntMap *ReadBounds(char *genome_reg_file, bool verbose)
+{
+  if (genome_reg_file == NULL || strlen(genome_reg_file) == 0) { std::cerr << "Error: genome region file is necessary for this operation!\n"; exit(1); }
+  StringLIntMap *bounds = new StringLIntMap();
+  GenomicRegionSet RegSet(genome_reg_file, 10000, verbose, false, true);
+  long int line = 1;
+  for (GenomicRegion *r = RegSet.Get(); r != NULL; r = RegSet.Next(), line++) {
+    std::string chr = r->I.front()->CHROMOSOME;
+    if (bounds->find(chr) == bounds->end()) (*bounds)[chr] = r->I.front()->STOP;
+    else if ((*bounds)[chr] != r->I.front()->STOP) {
+      std::cerr << "Error: chromosome " << chr << " has multiple lengths in genome file '" << genome_reg_file << "' line " << line << "!\n";
+      exit(1);
+    }
+  }
+  return bounds;
+}

@@ -1,0 +1,212 @@
+// genomic_intervals.h -- the GenomicTools class API for the count / scan hot path, MI355X edition.
+//
+// Same class names, constructor signatures, public members and error behaviour as the reference's
+// gtools/genomic_intervals.h for the classes on the path (file:line of each counterpart is given
+// at the declaration), so that callers written like gtools/genomic_overlaps.cpp:408-431 or
+// gtools/genomic_scans.cpp:399-436 recompile against this header unchanged.  Underneath nothing
+// is shared with the reference: region sets keep their input as a line stream that is parsed in
+// bulk by a thread pool into packed int32 triples (gtx_bed.h), and the reductions
+// (CountIndexOverlaps, the scanners' window sums) are one call each into the C ABI of libgtx.so
+// (include/gtx.h), i.e. HIP kernels on the MI355X.  There is no CPU implementation of those
+// reductions here; without a GPU they fail with an error message and exit(1), like every other
+// error of the reference (genomic_intervals.cpp:1001-1006).
+//
+// Scope: BED3..BED6 single-interval regions.  REG/SAM/GFF/SEQ input, BED12
+// blocks, the ~45 Run*/Print* text transforms of GenomicRegionSet, GenomicRegionSetIndex and the
+// per-pair enumeration (GetMatch/NextMatch) are outside the path.
+#ifndef GTX_GENOMIC_INTERVALS_H
+#define GTX_GENOMIC_INTERVALS_H
+
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace gtxhost { class LineSource; }
+
+typedef std::map<std::string, long int> StringLIntMap;          // genomic_intervals.h:41
+
+extern bool _MESSAGES_;                                          // verbose switch (core.h; set from -v)
+
+// ---- GenomicInterval (genomic_intervals.h:91) ---------------------------------------------------------
+class GenomicInterval
+{
+ public:
+  GenomicInterval(const char *chromosome, char strand, long int start, long int stop, long int n_line = 0);
+  ~GenomicInterval();
+  void PrintInterval();
+  void PrintInterval(FILE *file_ptr);
+  size_t GetSize() { return (size_t)(STOP - START + 1); }
+
+  char *CHROMOSOME;
+  char STRAND;
+  long int START, STOP;          // 1-based, inclusive
+  long int n_line;
+};
+
+typedef std::vector<GenomicInterval *> GenomicIntervalSet;        // genomic_intervals.h:46
+
+// ---- GenomicRegion (genomic_intervals.h:591) / GenomicRegionBED (:1112) ------------------------------
+class GenomicRegion
+{
+ public:
+  GenomicRegion();
+  virtual ~GenomicRegion();
+  void PrintError(std::string error_msg);                         // "\nError: Line N: msg\n", exit(1)
+  char *GetChromosome() { return I.front()->CHROMOSOME; }
+  size_t GetSize(bool skip_gaps);                                 // genomic_intervals.cpp:1049-1058
+  long int GetLabelValue(long int max_label_value);               // :1081-1085
+  bool IsBefore(GenomicRegion *r, bool sorted_by_strand);         // :1177-1180
+
+  long int n_line;
+  char *LABEL;
+  GenomicIntervalSet I;
+};
+
+class GenomicRegionBED : public GenomicRegion
+{
+ public:
+  // parses one BED line (the line is modified); genomic_intervals.cpp:2157-2182
+  GenomicRegionBED(char *inp, long int n_line);
+  long int n_tokens;
+};
+
+// ---- GenomicRegionSet (genomic_intervals.h:1828) ------------------------------------------------------
+class GenomicRegionSet
+{
+ public:
+  GenomicRegionSet(char *file, unsigned long int buffer_size, bool verbose, bool load_in_memory, bool hide_header = true);
+  ~GenomicRegionSet();
+
+  GenomicRegion *Get();                                           // genomic_intervals.cpp:3845-3849
+  GenomicRegion *Next(bool retain_current = false);               // :3855-3867
+  void Reset();
+  void PrintError(std::string error_msg);                         // "\nError: msg\n", exit(1)
+
+  // MI355X path: hands the not yet consumed part of a streaming set (the current region's raw
+  // line first) to the bulk packer.  After this call Get()/Next() report the end of the set.
+  gtxhost::LineSource *DetachStream(std::string *current_line, long int *current_line_no);
+
+  char *file;
+  unsigned long int buffer_size;
+  bool verbose, load_in_memory, from_stdin, hide_header;
+  long int n_regions;
+  std::string format;                                              // "BED" or "EMPTY"
+  GenomicRegion **R;
+
+ private:
+  void Init();
+  void DetectFormat(const char *first_line);
+  gtxhost::LineSource *src;
+  std::string cur_raw;                                             // unparsed copy of the current line (streaming mode)
+  long int r_index;
+};
+
+// ---- GenomicRegionSetOverlaps (genomic_intervals.h:2387) ----------------------------------------------
+class GenomicRegionSetOverlaps
+{
+ public:
+  GenomicRegionSetOverlaps(GenomicRegionSet *QuerySet, GenomicRegionSet *IndexSet);
+  virtual ~GenomicRegionSetOverlaps();
+
+  virtual GenomicRegion *GetQuery() = 0;
+  virtual GenomicRegion *NextQuery() = 0;
+  virtual GenomicRegion *GetMatch() = 0;
+  virtual GenomicRegion *NextMatch() = 0;
+  virtual bool Done() = 0;
+
+  // hits[k] = sum over query regions q of w_q * [q overlaps index region k], index FILE order;
+  // a new[] array the caller releases (genomic_intervals.cpp:5304-5317).  Runs on the GPU.
+  unsigned long int *CountIndexOverlaps(bool match_gaps, bool ignore_strand, long int max_label_value);
+
+  GenomicRegionSet *QuerySet;
+  GenomicRegionSet *IndexSet;
+  GenomicRegion *current_qreg;
+  GenomicRegion *current_ireg;
+
+ protected:
+  virtual bool UsesSortedMerge() const = 0;      // which reference algorithm's input rules apply
+  virtual bool SortedByStrand() const { return false; }
+};
+
+// genomic_intervals.h:2607 -- query rules of the bin-index algorithm (any order; a query with
+// stop <= 0 or start > stop on a known chromosome is an error, :5740-5741)
+class UnsortedGenomicRegionSetOverlaps : public GenomicRegionSetOverlaps
+{
+ public:
+  UnsortedGenomicRegionSetOverlaps(GenomicRegionSet *QuerySet, GenomicRegionSet *IndexSet, const char *bin_bits = NULL);
+  ~UnsortedGenomicRegionSetOverlaps();
+  GenomicRegion *GetQuery();
+  GenomicRegion *NextQuery();
+  GenomicRegion *GetMatch();
+  GenomicRegion *NextMatch();
+  bool Done();
+ protected:
+  bool UsesSortedMerge() const { return false; }
+};
+
+// genomic_intervals.h:2733 -- rules of the sorted merge (both sets sorted by chromosome[, strand],
+// start; violations are errors, :5868, :5894)
+class SortedGenomicRegionSetOverlaps : public GenomicRegionSetOverlaps
+{
+ public:
+  SortedGenomicRegionSetOverlaps(GenomicRegionSet *QuerySet, GenomicRegionSet *IndexSet, bool sorted_by_strand);
+  ~SortedGenomicRegionSetOverlaps();
+  GenomicRegion *GetQuery();
+  GenomicRegion *NextQuery();
+  GenomicRegion *GetMatch();
+  GenomicRegion *NextMatch();
+  bool Done();
+ protected:
+  bool UsesSortedMerge() const { return true; }
+  bool SortedByStrand() const { return sorted_by_strand; }
+  bool sorted_by_strand;
+};
+
+// ---- scanners (genomic_intervals.h:2196, 2274, 2330) ---------------------------------------------------
+class GenomicRegionSetScanner
+{
+ public:
+  GenomicRegionSetScanner(GenomicRegionSet *R, StringLIntMap *bounds, long int win_step, long int win_size, long int max_label_value,
+                          bool ignore_strand, char preprocess);
+  virtual ~GenomicRegionSetScanner();
+
+  void PrintInterval(FILE *out_file = stdout);                    // "chr strand start stop" of the current window
+  GenomicInterval *GetInterval();                                 // heap object owned by the caller
+  long int Next();                                                // next window's value, -1 at the end
+
+  GenomicRegionSet *R;
+  StringLIntMap *bounds;
+  long int win_step, win_size, max_label_value, n_win_combine;
+  bool ignore_strand;
+  char preprocess;
+
+ protected:
+  void Compute(bool sorted_rules);                                // runs the GPU scan over the whole input
+  std::vector<std::string> chrom_names;                           // bounds in std::map (strcmp) order
+  std::vector<long int> n_windows;                                // per (chromosome, strand) block, iteration order
+  std::vector<long long> block_offset;
+  std::vector<unsigned long long> values;
+  size_t cur_block;
+  long int cur_win;                                               // 1-based inside the block
+  bool computed;
+};
+
+class SortedGenomicRegionSetScanner : public GenomicRegionSetScanner
+{
+ public:
+  SortedGenomicRegionSetScanner(GenomicRegionSet *R, StringLIntMap *bounds, long int win_step, long int win_size, long int max_label_value,
+                                bool ignore_strand, char preprocess);
+};
+
+class UnsortedGenomicRegionSetScanner : public GenomicRegionSetScanner
+{
+ public:
+  UnsortedGenomicRegionSetScanner(GenomicRegionSet *R, StringLIntMap *bounds, long int win_step, long int win_size, long int max_label_value,
+                                  bool ignore_strand, char preprocess);
+};
+
+// chromosome -> length from a genome region file (genomic_intervals.cpp:5997-6015)
+StringLIntMap *ReadBounds(char *genome_reg_file, bool verbose = false);
+
+#endif

@@ -1,0 +1,373 @@
+// gtx_bed.cpp -- see gtx_bed.h
+#include "gtx_bed.h"
+
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <thread>
+
+namespace gtxhost {
+
+// ---------------------------------------------------------------------------------------------------
+// LineSource
+// ---------------------------------------------------------------------------------------------------
+LineSource *LineSource::Open(const char *path, std::string *err)
+{
+  LineSource *s = new LineSource();
+  s->buf_.resize(8u << 20);
+  if (!path) { s->fp_ = stdin; s->is_stdin_ = true; return s; }
+  FILE *f = fopen(path, "rb");
+  if (!f) { *err = std::string("[CreateFileBuffer] Error: cannot open file '") + path + "'!"; delete s; return nullptr; }
+  int b1 = fgetc(f), b2 = fgetc(f);
+  fclose(f);
+  if (b1 == 0x1f && b2 == 0x8b) {                        // gzip magic
+    s->gz_ = gzopen(path, "rb");
+    if (s->gz_) gzbuffer(s->gz_, 1u << 20);
+  } else s->fp_ = fopen(path, "rb");
+  if (!s->gz_ && !s->fp_) { *err = std::string("[CreateFileBuffer] Error: cannot open file '") + path + "'!"; delete s; return nullptr; }
+  return s;
+}
+
+LineSource::~LineSource()
+{
+  if (gz_) gzclose(gz_);
+  if (fp_ && !is_stdin_) fclose(fp_);
+}
+
+size_t LineSource::Fill()
+{
+  if (eof_) return 0;
+  if (pos_ > 0) { memmove(buf_.data(), buf_.data() + pos_, end_ - pos_); end_ -= pos_; pos_ = 0; }
+  if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
+  size_t room = buf_.size() - end_, got;
+  if (gz_) { int g = gzread(gz_, buf_.data() + end_, (unsigned)std::min<size_t>(room, 1u << 30)); got = g > 0 ? (size_t)g : 0; }
+  else got = fread(buf_.data() + end_, 1, room, fp_);
+  if (got == 0) eof_ = true;
+  end_ += got;
+  return got;
+}
+
+char *LineSource::Next()
+{
+  for (;;) {
+    char *nl = pos_ < end_ ? (char *)memchr(buf_.data() + pos_, '\n', end_ - pos_) : nullptr;
+    if (nl) {
+      char *line = buf_.data() + pos_;
+      *nl = 0;
+      pos_ = (size_t)(nl - buf_.data()) + 1;
+      line_no_++;
+      return line;
+    }
+    if (Fill() == 0) return nullptr;                     // EOF: a last line without '\n' is dropped
+  }
+}
+
+size_t LineSource::NextBlock(std::vector<char> &block, size_t target, long *first_line)
+{
+  *first_line = line_no_ + 1;
+  for (;;) {
+    size_t have = end_ - pos_;
+    if (have >= target || eof_) {
+      // last newline inside the first `target` bytes (or inside everything we have)
+      size_t span = std::min(have, target);
+      char *base = buf_.data() + pos_;
+      char *nl = span ? (char *)memrchr(base, '\n', span) : nullptr;
+      if (!nl && have > span) nl = (char *)memchr(base + span, '\n', have - span);
+      if (nl) {
+        size_t n = (size_t)(nl - base) + 1;
+        block.assign(base, base + n);
+        pos_ += n;
+        return n;
+      }
+      if (eof_) return 0;                                // only an unterminated tail is left
+    }
+    Fill();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tokenising and one BED line
+// ---------------------------------------------------------------------------------------------------
+int CountTokensLike(const char *s, char delim)
+{
+  if (!s) return 0;
+  while (*s == ' ') s++;
+  int n = 0;
+  while (*s) {
+    while (*s && *s != delim) s++;
+    if (*s == delim) s++;
+    n++;
+    while (*s == ' ') s++;
+  }
+  return n;
+}
+
+static inline char *TakeToken(char **cur, char delim)
+{
+  char *b = *cur;
+  while (*b == ' ') b++;
+  char *e = b;
+  while (*e && *e != delim) e++;
+  if (*e) { *e = 0; *cur = e + 1; } else *cur = e;
+  return b;
+}
+
+// atol for the plain decimal tokens BED carries (leading blanks, optional sign, digits)
+static inline long FastAtol(const char *p)
+{
+  while (*p == ' ' || (*p >= '\t' && *p <= '\r')) p++;
+  bool neg = false;
+  if (*p == '-') { neg = true; p++; } else if (*p == '+') p++;
+  unsigned long v = 0;
+  while (*p >= '0' && *p <= '9') { v = v * 10 + (unsigned long)(*p - '0'); p++; }
+  return neg ? -(long)v : (long)v;
+}
+
+BedStatus ParseBedLine(char *line, BedFields *o, char **bad)
+{
+  const char sep = strchr(line, '\t') ? '\t' : ' ';
+  o->n_tokens = CountTokensLike(line, sep);
+  if (o->n_tokens < 3) return BED_TOO_FEW_TOKENS;
+  char *cur = line;
+  o->chrom = TakeToken(&cur, sep);
+  o->start = FastAtol(TakeToken(&cur, sep)) + 1;
+  o->stop = FastAtol(TakeToken(&cur, sep));
+  o->strand = '+';
+  o->label = o->n_tokens == 3 ? nullptr : TakeToken(&cur, sep);
+  if (o->n_tokens >= 5) (void)TakeToken(&cur, sep);     // score
+  if (o->n_tokens >= 6) {
+    char *t = TakeToken(&cur, sep);
+    if (!strcmp(t, "1") || !strcmp(t, "+") || !strcmp(t, ".")) o->strand = '+';
+    else if (!strcmp(t, "-1") || !strcmp(t, "-")) o->strand = '-';
+    else { *bad = t; return BED_BAD_STRAND; }
+  }
+  return BED_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ChromTable
+// ---------------------------------------------------------------------------------------------------
+void ChromTable::Add(const char *name)
+{
+  for (const std::string &n : names_) if (n == name) return;
+  names_.push_back(name);
+  frozen_ = false;
+}
+
+void ChromTable::Freeze()
+{
+  std::sort(names_.begin(), names_.end(), [](const std::string &a, const std::string &b) { return strcmp(a.c_str(), b.c_str()) < 0; });
+  frozen_ = true;
+}
+
+int ChromTable::Find(const char *name) const
+{
+  int lo = 0, hi = (int)names_.size();
+  while (lo < hi) {
+    int mid = (lo + hi) / 2;
+    int d = strcmp(names_[mid].c_str(), name);
+    if (d == 0) return mid;
+    if (d < 0) lo = mid + 1; else hi = mid;
+  }
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BedPacker
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct Piece {                       // one thread's share of a block
+  char *begin = nullptr, *end = nullptr;
+  long first_line = 0; long n_lines = 0;
+  std::vector<int32_t> tri, w, zero_len;
+  PackError err;
+  // order-check context of the regions in this piece
+  bool any = false;
+  std::string first_chrom, last_chrom; char first_strand = '+', last_strand = '+';
+  long first_start = 0, last_start = 0, first_region_line = 0;
+};
+
+// true when (chrom, [strand,] start) sorts before the previous region's key (genomic_intervals.cpp:396-401)
+inline bool SortsBefore(const char *chrom, char strand, long start, const char *pchrom, char pstrand, long pstart, bool by_strand)
+{
+  int d = strcmp(chrom, pchrom);
+  if (d) return d < 0;
+  if (by_strand && strand != pstrand) return strand < pstrand;
+  return start < pstart;
+}
+
+inline void SetErr(PackError *e, long line, const std::string &msg, bool no_prefix = false)
+{
+  if (!e->set) { e->set = true; e->line = line; e->msg = msg; e->no_prefix = no_prefix; }
+}
+
+const char *NotSortedMsg(const PackOptions &o)
+{
+  const bool overlaps = o.mode == PACK_OVERLAPS_SORTED;
+  if (overlaps) return o.sorted_by_strand ? "query regions are not sorted (sorted-by-strand = true)!" : "query regions are not sorted (sorted-by-strand = false)!";
+  return o.sorted_by_strand ? "input regions are not sorted (sorted-by-strand = true)!" : "input regions are not sorted (sorted-by-strand = false)!";
+}
+
+void ParsePiece(Piece *p, const PackOptions &o)
+{
+  const bool sorted_mode = o.mode == PACK_OVERLAPS_SORTED || o.mode == PACK_SCAN_SORTED;
+  const bool weighted = o.max_label_value > 1;
+  const int n_chrom = o.chroms->size();
+  // last chromosome looked up (sorted input repeats it millions of times)
+  std::string cache_name; int cache_id = -2;
+  long line_no = p->first_line - 1;
+  char *cur = p->begin;
+  size_t est = (size_t)(p->end - p->begin) / 20 + 16;
+  p->tri.reserve(est * 3);
+  if (weighted) p->w.reserve(est);
+  while (cur < p->end) {
+    char *nl = (char *)memchr(cur, '\n', (size_t)(p->end - cur));
+    if (!nl) break;
+    *nl = 0;
+    char *line = cur;
+    cur = nl + 1;
+    line_no++;
+    BedFields f; char *bad = nullptr;
+    BedStatus st = ParseBedLine(line, &f, &bad);
+    if (st == BED_TOO_FEW_TOKENS) { SetErr(&p->err, line_no, "number of tokens should be at least 3 for BED format!"); break; }
+    if (st == BED_BAD_STRAND) { SetErr(&p->err, line_no, std::string("Error: invalid strand '") + bad + "'!", true); break; }
+    if (f.n_tokens == 12) { SetErr(&p->err, line_no, "multi-interval (BED12) regions are outside the MI355X counting path!"); break; }
+    if (f.start >= INT_MAX - 1 || f.stop >= INT_MAX - 1 || f.start <= INT_MIN + 1 || f.stop <= INT_MIN + 1) {
+      SetErr(&p->err, line_no, "coordinate does not fit the packed 32-bit representation of the MI355X path!"); break;
+    }
+    if (sorted_mode) {
+      if (p->any && SortsBefore(f.chrom, f.strand, f.start, p->last_chrom.c_str(), p->last_strand, p->last_start, o.sorted_by_strand)) {
+        SetErr(&p->err, line_no, NotSortedMsg(o)); break;
+      }
+      if (!p->any) { p->first_chrom = f.chrom; p->first_strand = f.strand; p->first_start = f.start; p->first_region_line = line_no; }
+      if (p->last_chrom != f.chrom) p->last_chrom = f.chrom;
+      p->last_strand = f.strand; p->last_start = f.start; p->any = true;
+    }
+    if (cache_id == -2 || cache_name != f.chrom) { cache_name = f.chrom; cache_id = o.chroms->Find(f.chrom); }
+    const int id = cache_id;
+    bool zero_len = false;
+    switch (o.mode) {
+      case PACK_OVERLAPS_UNSORTED:
+        if (id < 0) continue;                                            // unknown chromosome: never validated
+        if (f.stop <= 0) { SetErr(&p->err, line_no, "stop position must be positive!"); break; }
+        if (f.start > f.stop) { SetErr(&p->err, line_no, "start position cannot be greater than stop position!"); break; }
+        break;
+      case PACK_OVERLAPS_SORTED:
+        if (id < 0) continue;
+        if (f.start > f.stop + 1) { SetErr(&p->err, line_no, "inverted interval (end < start) is outside the MI355X counting path!"); break; }
+        zero_len = f.start == f.stop + 1;
+        break;
+      case PACK_SCAN_UNSORTED:
+        if (f.start > f.stop || f.stop <= 0) continue;
+        if (id < 0) continue;
+        break;
+      case PACK_SCAN_SORTED:
+        if (id < 0) continue;
+        break;
+    }
+    if (p->err.set) break;
+    const int32_t cls = (int32_t)(id + ((o.strand_aware && f.strand == '-') ? n_chrom : 0));
+    p->tri.push_back(cls); p->tri.push_back((int32_t)f.start); p->tri.push_back((int32_t)f.stop);
+    long wv = 1;
+    if (weighted) { long v = f.label ? FastAtol(f.label) : 0; wv = v < o.max_label_value ? v : o.max_label_value; p->w.push_back((int32_t)wv); }
+    if (zero_len && o.collect_zero_length) { p->zero_len.push_back(cls); p->zero_len.push_back((int32_t)f.start); p->zero_len.push_back((int32_t)wv); }
+  }
+  p->n_lines = line_no - (p->first_line - 1);
+}
+
+long CountLines(const char *b, const char *e)
+{
+  long n = 0;
+  while (b < e) { const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b)); if (!nl) break; n++; b = nl + 1; }
+  return n;
+}
+
+}  // namespace
+
+BedPacker::BedPacker(LineSource *src, const PackOptions &opt) : src_(src), opt_(opt)
+{
+  if (opt_.threads <= 0) { unsigned hc = std::thread::hardware_concurrency(); opt_.threads = hc ? (int)std::min(hc, 32u) : 4; }
+}
+
+void BedPacker::Prime(const std::string &line, long line_no)
+{
+  primed_.assign(line.begin(), line.end()); primed_.push_back('\n');
+  primed_first_line_ = line_no; primed_set_ = true;
+}
+
+void BedPacker::PrimeBlock(const std::string &lines, long first_line)
+{
+  primed_.assign(lines.begin(), lines.end());
+  primed_first_line_ = first_line; primed_set_ = !lines.empty();
+}
+
+// parse one block of complete lines with the thread pool and append the result to *out
+bool BedPacker::PackBlock(std::vector<char> &block, size_t got, long first_line, PackedBatch *out, PackError *err)
+{
+  const bool sorted_mode = opt_.mode == PACK_OVERLAPS_SORTED || opt_.mode == PACK_SCAN_SORTED;
+  // cut the block into pieces at line ends
+  int T = (int)std::min<size_t>((size_t)opt_.threads, got / (256u << 10) + 1);
+  std::vector<Piece> pieces(T);
+  char *b = block.data(), *e = block.data() + got;
+  for (int t = 0; t < T; t++) {
+    char *pe = t == T - 1 ? e : b + (size_t)(e - b) / (size_t)(T - t);
+    if (t != T - 1) { char *nl = (char *)memchr(pe, '\n', (size_t)(e - pe)); pe = nl ? nl + 1 : e; }
+    pieces[t].begin = b; pieces[t].end = pe; b = pe;
+  }
+  // line numbers: count in parallel, prefix, then parse in parallel
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back([&pieces, t] { pieces[t].n_lines = CountLines(pieces[t].begin, pieces[t].end); });
+    pieces[0].n_lines = CountLines(pieces[0].begin, pieces[0].end);
+    for (auto &x : th) x.join();
+  }
+  long ln = first_line;
+  for (int t = 0; t < T; t++) { pieces[t].first_line = ln; ln += pieces[t].n_lines; }
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back([&pieces, t, this] { ParsePiece(&pieces[t], opt_); });
+    ParsePiece(&pieces[0], opt_);
+    for (auto &x : th) x.join();
+  }
+  // merge in file order; the first error in file order wins
+  for (int t = 0; t < T; t++) {
+    Piece &p = pieces[t];
+    if (sorted_mode && p.any && have_prev_ &&
+        SortsBefore(p.first_chrom.c_str(), p.first_strand, p.first_start, prev_chrom_.c_str(), prev_strand_, prev_start_, opt_.sorted_by_strand)) {
+      if (!p.err.set || p.err.line > p.first_region_line) { p.err = PackError(); SetErr(&p.err, p.first_region_line, NotSortedMsg(opt_)); }
+    }
+    if (p.err.set) { *err = p.err; return false; }
+    if (sorted_mode && p.any) { have_prev_ = true; prev_chrom_ = p.last_chrom; prev_strand_ = p.last_strand; prev_start_ = p.last_start; }
+    out->tri.insert(out->tri.end(), p.tri.begin(), p.tri.end());
+    out->w.insert(out->w.end(), p.w.begin(), p.w.end());
+    out->zero_len.insert(out->zero_len.end(), p.zero_len.begin(), p.zero_len.end());
+    out->n_lines += p.n_lines;
+  }
+  return true;
+}
+
+bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
+{
+  out->tri.clear(); out->w.clear(); out->zero_len.clear(); out->n_lines = 0;
+  if (primed_set_) {
+    primed_set_ = false;
+    if (!PackBlock(primed_, primed_.size(), primed_first_line_, out, err)) return false;
+  }
+  if (!src_) return false;
+  std::vector<char> block;
+  const size_t block_bytes = 48u << 20;
+  while (out->tri.size() / 3 < target_reads) {
+    long first_line = 0;
+    size_t got = src_->NextBlock(block, block_bytes, &first_line);
+    if (got == 0) return false;
+    const int64_t before = out->n_lines;
+    bool ok = PackBlock(block, got, first_line, out, err);
+    src_->AdvanceLines((long)(out->n_lines - before));
+    if (!ok) return false;
+  }
+  return true;
+}
+
+}  // namespace gtxhost

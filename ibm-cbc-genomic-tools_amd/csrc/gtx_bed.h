@@ -1,0 +1,127 @@
+// gtx_bed.h -- host-side BED ingest for the MI355X path: text / .gz / stdin -> packed int32 triples.
+//
+// Behaviour follows the reference's reader exactly where it is observable:
+//   - line delivery: a line counts only if it ended in '\n' (gtools/core.cpp:241-259, 331-349);
+//   - gzip sniffing by magic bytes (core.cpp:1757-1775); "browser "/"track " header lines are
+//     skipped at the top of the file (genomic_intervals.cpp:3713-3720);
+//   - tokenising: separator is TAB if the line has one, else SPACE; blanks before a token are
+//     skipped (core.cpp:577-625, genomic_intervals.cpp:2159);
+//   - BED3..BED6 fields: start = atol(col2)+1, stop = atol(col3), label = col4 or "_",
+//     strand = col6 through ProcessStrand (genomic_intervals.cpp:2157-2172, 5956-5962).
+// What is new is the shape of the work: blocks of complete lines are parsed by a pool of
+// threads straight into (class, start, end[, weight]) arrays that go to the GPU.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <zlib.h>
+
+namespace gtxhost {
+
+// ---- lines ------------------------------------------------------------------------------------
+class LineSource {
+ public:
+  // path == NULL reads stdin.  On failure returns NULL and sets *err to the reference's message.
+  static LineSource *Open(const char *path, std::string *err);
+  ~LineSource();
+
+  // Next complete line as a mutable NUL-terminated string (valid until the next call), or NULL at
+  // the end.  line_no() is its 1-based number in the file.
+  char *Next();
+  long line_no() const { return line_no_; }
+
+  // Bulk: the rest of the input as blocks of complete lines.  Returns the number of bytes put in
+  // `block` (0 at the end); *first_line receives the file line number of the block's first line.
+  // The caller counts the lines of the block and reports them with AdvanceLines().
+  size_t NextBlock(std::vector<char> &block, size_t target_bytes, long *first_line);
+  void AdvanceLines(long n) { line_no_ += n; }
+
+ private:
+  LineSource() {}
+  size_t Fill();                     // read more raw bytes into buf_; 0 at EOF
+  FILE *fp_ = nullptr; gzFile gz_ = nullptr; bool is_stdin_ = false;
+  std::vector<char> buf_;            // raw bytes [pos_, end_) not yet handed out
+  size_t pos_ = 0, end_ = 0;
+  bool eof_ = false;
+  long line_no_ = 0;
+};
+
+// ---- one BED line ---------------------------------------------------------------------------------
+struct BedFields {
+  char *chrom; char *label;          // label == NULL means "_" (3-column line)
+  long start, stop;                  // 1-based inclusive
+  char strand;
+  int n_tokens;
+};
+enum BedStatus { BED_OK = 0, BED_TOO_FEW_TOKENS, BED_BAD_STRAND };
+// Parses in place (the line is cut into tokens).  On BED_BAD_STRAND *bad points at the strand token.
+BedStatus ParseBedLine(char *line, BedFields *out, char **bad);
+// Number of `delim`-separated tokens as the reference counts them (core.cpp:577-593).
+int CountTokensLike(const char *s, char delim);
+
+// ---- chromosome table: names in strcmp order, id = rank ------------------------------------------
+class ChromTable {
+ public:
+  void Add(const char *name);        // collect (duplicates ignored); call Freeze() before Find()
+  void Freeze();
+  int Find(const char *name) const;  // rank or -1
+  int size() const { return (int)names_.size(); }
+  const std::string &name(int id) const { return names_[id]; }
+ private:
+  std::vector<std::string> names_;
+  bool frozen_ = false;
+};
+
+// ---- bulk packing ---------------------------------------------------------------------------------
+enum PackMode {
+  PACK_OVERLAPS_UNSORTED,   // UnsortedGenomicRegionSetOverlaps query rules (genomic_intervals.cpp:5717-5764)
+  PACK_OVERLAPS_SORTED,     // SortedGenomicRegionSetOverlaps query rules (:5889-5898)
+  PACK_SCAN_UNSORTED,       // UnsortedGenomicRegionSetScanner (:5036-5055)
+  PACK_SCAN_SORTED          // SortedGenomicRegionSetScanner (:4928-4957)
+};
+
+struct PackOptions {
+  PackMode mode = PACK_OVERLAPS_UNSORTED;
+  const ChromTable *chroms = nullptr;
+  bool strand_aware = false;         // class = strand * n_chrom + chrom rank
+  bool sorted_by_strand = false;     // order check uses (chrom, strand, start) instead of (chrom, start)
+  long max_label_value = 1;          // > 1: emit weights = min(max, atol(label))
+  bool collect_zero_length = false;  // keep (class, start, weight) of zero-length reads (sorted mode correction)
+  int threads = 0;                   // 0 = hardware concurrency
+};
+
+struct PackError {
+  bool set = false;
+  long line = 0;                     // file line number of the offending line
+  bool no_prefix = false;            // message is printed as is (no "Error: Line N: " in front)
+  std::string msg;                   // what the reference prints after "Error: Line N: "
+};
+
+struct PackedBatch {
+  std::vector<int32_t> tri;          // 3 per read
+  std::vector<int32_t> w;            // empty unless max_label_value > 1
+  std::vector<int32_t> zero_len;     // (class, start, weight) triples, see collect_zero_length
+  int64_t n_lines = 0;               // lines consumed (regions seen), including dropped ones
+};
+
+// Packs blocks of lines from `src` until about `target_reads` reads are in `out` or the input ends.
+// Returns false when the input is exhausted (out may still hold reads).  The first error in file
+// order, if any, is left in *err and packing stops there.
+class BedPacker {
+ public:
+  BedPacker(LineSource *src /* may be NULL: primed text only */, const PackOptions &opt);
+  // text to be packed before anything is read from the source: one line without its '\n' (a
+  // region the caller had already pulled from the stream), or a block of '\n'-terminated lines
+  void Prime(const std::string &line, long line_no);
+  void PrimeBlock(const std::string &lines, long first_line);
+  bool NextBatch(PackedBatch *out, size_t target_reads, PackError *err);
+ private:
+  bool PackBlock(std::vector<char> &block, size_t got, long first_line, PackedBatch *out, PackError *err);
+  std::vector<char> primed_; long primed_first_line_ = 0; bool primed_set_ = false;
+  LineSource *src_; PackOptions opt_;
+  // order check across blocks
+  bool have_prev_ = false; std::string prev_chrom_; char prev_strand_ = '+'; long prev_start_ = 0;
+};
+
+}  // namespace gtxhost

@@ -51,6 +51,9 @@ struct gtx_ctx {
   hipEvent_t evRing[kProfSlots][4] = {};
   hipEvent_t *ev = evRing[0];
 
+  // streaming count (begin/add/end)
+  bool streamOpen = false; int64_t streamSeen = 0; gtx::DevInfo streamTotal; int32_t streamLast[2] = {0, 0};
+
   int chunksPerWave = 0;                // 0 = choose per call from the number of reads
   int prefetch = 4;                     // reads per lane per step (R) of the streaming kernel
 };
@@ -115,7 +118,9 @@ int64_t gtx_n_refs(const gtx_ctx *c) { return c ? c->nRefs : -1; }
 // ---------------------------------------------------------------------------------------------
 // reference side
 // ---------------------------------------------------------------------------------------------
-int gtx_set_refs(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses)
+int gtx_set_refs(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses) { return gtx_set_refs_ex(c, tri, m, nClasses, 0); }
+
+int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses, uint32_t flags)
 {
   if (!c || m < 0 || (m > 0 && !tri)) return c ? fail(c, GTX_E_ARG, "gtx_set_refs: bad argument") : GTX_E_ARG;
   if (m >= (int64_t)INT32_MAX - 4096) return fail(c, GTX_E_ARG, "gtx_set_refs: too many reference regions");
@@ -135,7 +140,12 @@ int gtx_set_refs(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses)
   std::vector<u64> keyE, keyS;                   // (class, biased coordinate, ordinal) packed for one sort each
   std::vector<int32_t> ord;
   ord.reserve(m);
-  for (int64_t k = 0; k < m; k++) { int32_t s = tri[3 * k + 1], e = tri[3 * k + 2]; if (!(s > e || e <= 0)) ord.push_back((int32_t)k); }
+  const bool keepZero = (flags & GTX_REFS_KEEP_ZERO_LENGTH) != 0;
+  for (int64_t k = 0; k < m; k++) {
+    int32_t s = tri[3 * k + 1], e = tri[3 * k + 2];
+    const bool take = keepZero ? (int64_t)s <= (int64_t)e + 1 : !(s > e || e <= 0);
+    if (take) ord.push_back((int32_t)k);
+  }
   const int64_t nv = (int64_t)ord.size();
   struct Item { int32_t cls; int32_t val; int32_t k; };
   std::vector<Item> itE(nv), itS(nv);
@@ -200,6 +210,7 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
   const int r = std::max(1, std::min(4, c->prefetch));
   a.chunksPerWave = (cpw + r - 1) / r * r;
   a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0; a.prefetch = c->prefetch;
+  a.zeroLenOk = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   return a;
 }
 
@@ -273,46 +284,74 @@ static int ensure_out(gtx_ctx *c, size_t n)
 // Host buffers: the reads are streamed through the device in batches (the histograms simply keep
 // accumulating across batches), so N is bounded by host memory only -- the analogue of the
 // reference never holding the query set in memory (genomic_intervals.cpp:3855-3861).
-int gtx_count(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, uint32_t flags, uint64_t *hits, gtx_count_info *info)
+int gtx_count_begin(gtx_ctx *c)
 {
   if (!c) return GTX_E_ARG;
-  if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_count: gtx_set_refs has not been called");
-  if (n < 0 || (n > 0 && !reads) || (c->nRefs > 0 && !hits)) return fail(c, GTX_E_ARG, "gtx_count: bad argument");
+  if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_count_begin: gtx_set_refs has not been called");
   HIPCHK(c, hipSetDevice(c->device));
-  const int64_t batch = 64ll << 20;              // 64 Mi reads = 768 MiB of triples per batch
+  int rc = count_begin(c); if (rc) return rc;
+  c->streamTotal = c->h_info[1]; c->streamSeen = 0; c->streamOpen = true; c->streamLast[0] = c->streamLast[1] = INT32_MIN;
+  return GTX_OK;
+}
+
+int gtx_count_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, uint32_t flags)
+{
+  if (!c) return GTX_E_ARG;
+  if (!c->streamOpen) return fail(c, GTX_E_STATE, "gtx_count_add: gtx_count_begin has not been called");
+  if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_count_add: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t batch = 64ll << 20;              // 64 Mi reads = 768 MiB of triples per device batch
   int rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
-  rc = ensure_out(c, (size_t)c->nRefs); if (rc) return rc;
-  rc = count_begin(c); if (rc) return rc;
-  gtx::DevInfo total = c->h_info[1];
   for (int64_t off = 0; off < n; off += batch) {
     const int64_t cnt = std::min(batch, n - off);
     HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
     if (weights) HIPCHK(c, hipMemcpyAsync(c->d_weights, weights + off, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, gtx::launch_count(c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags, cnt), (flags & GTX_READS_SORTED) != 0, c->stream));
-    if (n > batch) {
-      // fold this batch's info (indices are batch-relative) and reset for the next one
-      HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      const gtx::DevInfo &d = c->h_info[0];
-      if (d.first_unsorted != INT64_MAX && total.first_unsorted == INT64_MAX) total.first_unsorted = d.first_unsorted + off;
-      if (d.first_degenerate != INT64_MAX && total.first_degenerate == INT64_MAX) total.first_degenerate = d.first_degenerate + off;
-      total.n_no_class += d.n_no_class; total.n_degenerate += d.n_degenerate;
-      if ((flags & GTX_CHECK_SORTED) && off > 0 && total.first_unsorted == INT64_MAX) {
-        const int32_t *p = reads + 3 * (off - 1), *q = reads + 3 * off;
-        if (q[0] < p[0] || (q[0] == p[0] && q[1] < p[1])) total.first_unsorted = off;
-      }
-      HIPCHK(c, hipMemcpyAsync(c->d_info, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
+    // fold this batch's info (indices are batch-relative) and reset the device block for the next one
+    HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_info, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is reused by the next batch
+    const gtx::DevInfo &d = c->h_info[0];
+    gtx::DevInfo &t = c->streamTotal;
+    const int64_t pos = c->streamSeen + off;
+    if (d.first_unsorted != INT64_MAX && t.first_unsorted == INT64_MAX) t.first_unsorted = d.first_unsorted + pos;
+    if (d.first_degenerate != INT64_MAX && t.first_degenerate == INT64_MAX) t.first_degenerate = d.first_degenerate + pos;
+    t.n_no_class += d.n_no_class; t.n_degenerate += d.n_degenerate;
+    if ((flags & GTX_CHECK_SORTED) && pos > 0 && cnt > 0) {
+      // order across the batch seam
+      const int32_t *q = reads + 3 * off;
+      if ((q[0] < c->streamLast[0] || (q[0] == c->streamLast[0] && q[1] < c->streamLast[1])) && (t.first_unsorted == INT64_MAX || t.first_unsorted > pos))
+        t.first_unsorted = pos;
     }
+    if (cnt > 0) { c->streamLast[0] = reads[3 * (off + cnt - 1)]; c->streamLast[1] = reads[3 * (off + cnt - 1) + 1]; }
   }
+  c->streamSeen += n;
+  return GTX_OK;
+}
+
+int gtx_count_end(gtx_ctx *c, uint64_t *hits, gtx_count_info *info)
+{
+  if (!c) return GTX_E_ARG;
+  if (!c->streamOpen) return fail(c, GTX_E_STATE, "gtx_count_end: gtx_count_begin has not been called");
+  if (c->nRefs > 0 && !hits) return fail(c, GTX_E_ARG, "gtx_count_end: null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->streamOpen = false;
+  int rc = ensure_out(c, (size_t)c->nRefs); if (rc) return rc;
   rc = count_end(c, c->d_out); if (rc) return rc;
   if (c->nRefs > 0) HIPCHK(c, hipMemcpyAsync(hits, c->d_out, sizeof(u64) * c->nRefs, hipMemcpyDeviceToHost, c->stream));
-  if (n <= batch) {
-    HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    total = c->h_info[0];
-  } else HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (info) info_out(total, info, 0);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (info) info_out(c->streamTotal, info, 0);
   return GTX_OK;
+}
+
+int gtx_count(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, uint32_t flags, uint64_t *hits, gtx_count_info *info)
+{
+  if (!c) return GTX_E_ARG;
+  if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_count: gtx_set_refs has not been called");
+  if (n < 0 || (n > 0 && !reads) || (c->nRefs > 0 && !hits)) return fail(c, GTX_E_ARG, "gtx_count: bad argument");
+  int rc = gtx_count_begin(c); if (rc) return rc;
+  rc = gtx_count_add(c, reads, weights, n, flags); if (rc) { c->streamOpen = false; return rc; }
+  return gtx_count_end(c, hits, info);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,14 +397,13 @@ static int scan_prepare(gtx_ctx *c, const int32_t *classLen, int nClasses, int s
 int gtx_scan_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, const int32_t *classLen, int32_t nClasses,
                     int32_t step, int32_t size, char prep, uint32_t flags, void *d_out, const int64_t *classOff)
 {
-  (void)flags;
   if (!c) return GTX_E_ARG;
   if (n < 0 || (n > 0 && !d_reads)) return fail(c, GTX_E_ARG, "gtx_scan_device: bad argument");
   if (prep != '1' && prep != 'c') return fail(c, GTX_E_ARG, "gtx_scan_device: preprocess operator must be '1' or 'c'");
   HIPCHK(c, hipSetDevice(c->device));
   gtx::ScanArgs a;
   int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
-  a.center = prep == 'c';
+  a.center = prep == 'c'; a.sortedRule = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   if (c->scanTotalWindows > 0 && !d_out) return fail(c, GTX_E_ARG, "gtx_scan_device: null output");
   if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[0], c->stream)); }
   if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * sizeof(u64), c->stream));
@@ -386,7 +424,7 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
   HIPCHK(c, hipSetDevice(c->device));
   gtx::ScanArgs a;
   int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
-  a.center = prep == 'c';
+  a.center = prep == 'c'; a.sortedRule = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   // output layout in the caller's buffer is given by class_offsets: find its extent
   int64_t extent = 0;
   for (int i = 0; i < nClasses; i++) extent = std::max<int64_t>(extent, classOff[i] + gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size));

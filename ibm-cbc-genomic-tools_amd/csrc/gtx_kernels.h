@@ -24,7 +24,8 @@ struct CountArgs {
   int chunksPerWave;             // 64-read chunks one wave streams
   int checkSorted;               // verify (class >> sortClassShift, start) order
   int sortClassShift;
-  int prefetch;                  // chunks kept in flight per wave (1..4)
+  int prefetch;                  // reads per lane per step of the streaming kernel (1..4)
+  int zeroLenOk;                 // start == end+1 is a countable read (sorted-merge semantics)
 };
 
 struct ScanArgs {
@@ -37,6 +38,7 @@ struct ScanArgs {
   int winStep;
   int comb;                      // win_size / win_step
   int center;                    // preprocess 'c'
+  int sortedRule;                // sorted scanner: no validity test, pos < 1 lands in the first micro-window
 };
 
 int scan_tiles(long long len);

@@ -233,7 +233,7 @@ __device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountA
     st.validA = st.validB = false;
     st.sg.start = rfl(a.segStart[c0]); st.sg.end = rfl(a.segStart[c0 + 1]); st.sg.cls = c0;
   }
-  const u64 degen = __ballot(t.s > t.e) & active;
+  const u64 degen = __ballot(t.s > t.e + a.zeroLenOk) & active;
   const u64 noclass = __ballot((unsigned)t.c >= (unsigned)a.nClasses) & active;
   const u64 mine = __ballot(t.c == st.sg.cls) & active & ~degen & ~noclass;
   const u64 other = active & ~mine & ~degen & ~noclass;      // valid reads of another class
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__
       // every read of the step: current class and start <= end ?
       int odd = 0, dg = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) { odd |= t[r].c ^ st.sg.cls; dg += t[r].s > t[r].e ? 1 : 0; }
+      for (int r = 0; r < R; ++r) { odd |= t[r].c ^ st.sg.cls; dg += t[r].s > t[r].e + a.zeroLenOk ? 1 : 0; }
       if (__ballot((odd | dg) != 0) == 0) {
         int ks[R], ke[R];
 #pragma unroll
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void count_search_kernel(const Tri *__restrict
     Tri t = reads[i];
     i64 w = WEIGHTED ? (i64)weights[i] : 1;
     if ((unsigned)t.c >= (unsigned)a.nClasses) { nNoClass++; continue; }
-    if (t.s > t.e) { nDegen++; if (i < firstDegen) firstDegen = i; continue; }
+    if (t.s > t.e + a.zeroLenOk) { nDegen++; if (i < firstDegen) firstDegen = i; continue; }
     int s0 = a.segStart[t.c], s1 = a.segStart[t.c + 1];
     if (s0 == s1) continue;
     int lo = s0, hi = s1;
@@ -538,9 +538,10 @@ __global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ 
     if (i < n) {
       Tri t = reads[i];
       if (WEIGHTED) w = weights[i];
-      if ((unsigned)t.c < (unsigned)a.nClasses && t.s <= t.e && t.e > 0) {
+      if ((unsigned)t.c < (unsigned)a.nClasses && (a.sortedRule || (t.s <= t.e && t.e > 0))) {
         i64 pos = a.center ? (i64)t.s + ((i64)t.e - t.s) / 2 : (i64)t.s;
         i64 mw = (pos - 1) / a.winStep;             // 0-based micro-window (C division: pos>=1 checked next)
+        if (a.sortedRule && pos < 1) { pos = 1; mw = 0; }    // the sorted scanner takes START <= stop of the first window
         if (pos >= 1 && mw < a.nMicro[t.c]) slot = a.microOff[t.c] + mw;
       }
     }

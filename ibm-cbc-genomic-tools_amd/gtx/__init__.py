@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgtx.so")
 
 READS_SORTED = 1
 CHECK_SORTED = 2
+ZERO_LENGTH_OK = 4
+REFS_KEEP_ZERO_LENGTH = 1
 
 _lib = None
 
@@ -39,7 +41,11 @@ ABI = {
     "gtx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "gtx_set_refs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]),
+    "gtx_set_refs_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32]),
     "gtx_n_refs": (ctypes.c_int64, [ctypes.c_void_p]),
+    "gtx_count_begin": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_count_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]),
+    "gtx_count_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32,
                                  ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_count_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32,
@@ -135,10 +141,22 @@ class Engine:
     def sync(self):
         self._chk(self.lib.gtx_sync(self.ctx))
 
-    def set_refs(self, refs, n_classes=0):
+    def set_refs(self, refs, n_classes=0, flags=0):
         refs = _triples(refs)
-        self._chk(self.lib.gtx_set_refs(self.ctx, _ptr(refs), refs.shape[0], int(n_classes)))
+        self._chk(self.lib.gtx_set_refs_ex(self.ctx, _ptr(refs), refs.shape[0], int(n_classes), int(flags)))
         self.n_refs = refs.shape[0]
+
+    def count_stream(self, batches, flags=READS_SORTED):
+        """gtx_count_begin / _add per (reads, weights) batch / _end."""
+        self._chk(self.lib.gtx_count_begin(self.ctx))
+        for reads, w in batches:
+            reads = _triples(reads)
+            w = None if w is None else np.ascontiguousarray(w, dtype=np.int32)
+            self._chk(self.lib.gtx_count_add(self.ctx, _ptr(reads), _ptr(w), reads.shape[0], int(flags)))
+        hits = np.zeros(max(self.n_refs, 1), dtype=np.uint64)
+        info = CountInfo()
+        self._chk(self.lib.gtx_count_end(self.ctx, _ptr(hits), ctypes.byref(info)))
+        return hits[:self.n_refs], info.as_dict()
 
     def count(self, reads, weights=None, flags=READS_SORTED):
         reads = _triples(reads)

@@ -53,6 +53,12 @@ typedef struct gtx_ctx gtx_ctx;
                                    wave-ballot kernel is used; it is exact for ANY order, only
                                    slower on unsorted input.  Without the hint the per-read
                                    binary-search kernel runs.                                  */
+#define GTX_ZERO_LENGTH_OK   4u  /* sorted-merge semantics for degenerate reads: a zero-length read
+                                   (start == end+1, BED start == end) IS counted, as
+                                   SortedGenomicRegionSetOverlaps does (genomic_intervals.cpp:5903-5918
+                                   has no start<=stop check); only start > end+1 is reported as
+                                   degenerate.  Scans: GTX_ZERO_LENGTH_OK selects the sorted scanner's
+                                   rule (no validity test, genomic_intervals.cpp:4933-4947).       */
 #define GTX_CHECK_SORTED    2u  /* also verify the order the sorted merge requires
                                    (SortedGenomicRegionSetOverlaps::NextQuery,
                                    genomic_intervals.cpp:5889-5898) and report the first
@@ -91,6 +97,11 @@ int         gtx_sync(gtx_ctx *ctx);
  * Regions with start > end or end <= 0 stay in the numbering but never match, as at :5659.
  * n_classes <= 0 means "max class id + 1". */
 int gtx_set_refs(gtx_ctx *ctx, const int32_t *ref_triples, int64_t n_refs, int32_t n_classes);
+/* flags for gtx_set_refs_ex */
+#define GTX_REFS_KEEP_ZERO_LENGTH 1u   /* sorted-merge semantics: the merge never validates index
+                                          regions, so zero-length ones (start == end+1) and ones with
+                                          end <= 0 take part; start > end+1 still never matches here */
+int gtx_set_refs_ex(gtx_ctx *ctx, const int32_t *ref_triples, int64_t n_refs, int32_t n_classes, uint32_t flags);
 int64_t gtx_n_refs(const gtx_ctx *ctx);
 
 /* ---- genomic_overlaps count ------------------------------------------------------------- */
@@ -104,6 +115,14 @@ int64_t gtx_n_refs(const gtx_ctx *ctx);
  * Host buffers in, host buffer out; copies + kernels + sync inside. */
 int gtx_count(gtx_ctx *ctx, const int32_t *read_triples, const int32_t *weights, int64_t n_reads,
               uint32_t flags, uint64_t *hits_out /* n_refs */, gtx_count_info *info /* may be NULL */);
+
+/* Streaming form of gtx_count for a query set that is never held in memory (the reference's
+ * load_in_memory=false mode, genomic_intervals.cpp:3855-3861): begin, any number of add calls with
+ * consecutive batches of the stream, end.  gtx_count(...) == begin + add + end.  Indices in `info`
+ * are positions in the whole stream. */
+int gtx_count_begin(gtx_ctx *ctx);
+int gtx_count_add(gtx_ctx *ctx, const int32_t *read_triples, const int32_t *weights, int64_t n_reads, uint32_t flags);
+int gtx_count_end(gtx_ctx *ctx, uint64_t *hits_out /* n_refs */, gtx_count_info *info /* may be NULL */);
 
 /* Same with reads (and weights) already resident in this device's HBM and the count vector
  * left in HBM (d_hits_out: uint64[n_refs], overwritten).  Asynchronous on the context's stream.
