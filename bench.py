@@ -33,7 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import gtx  # noqa: E402
-from gtx import synth  # noqa: E402
+from gtx import shard, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 READ_LEN = 50
@@ -84,7 +84,7 @@ def main():
 
     # ---- workload -------------------------------------------------------------------------------
     refs = synth.genome_intervals(args.refs, 43, 50, 2000)                 # 1M refs, all chromosomes, every rank
-    shards = synth.lpt_shards(synth.CHROM_LEN, world)                      # chromosomes -> ranks
+    shards = shard.rank_chroms(synth.CHROM_LEN, world)                     # chromosomes -> ranks (LPT)
     my_chroms = np.asarray(shards[rank], dtype=np.int64)
     reads = make_reads_on_device(args.reads, my_chroms, 1000 + rank, device)
     n = reads.shape[0]
@@ -99,7 +99,7 @@ def main():
     def step():
         eng.count_device(reads.data_ptr(), n, hits.data_ptr(), None, flags)
         if world > 1:
-            dist.all_reduce(hits, op=dist.ReduceOp.SUM)                    # RCCL over xGMI: the per-region count vector
+            shard.reduce_counts(hits, dist, device_tensor=True)            # RCCL all-reduce over xGMI of the count vector
 
     def fence():
         torch.cuda.synchronize()
