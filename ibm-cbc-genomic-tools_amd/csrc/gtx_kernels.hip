@@ -25,6 +25,7 @@
 // the speed depends on the order.  No MFMA: this is integer indexing, not a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "gtx_kernels.h"
 
@@ -77,6 +78,7 @@ struct Win {
   int W, Wn;            // window and the prefetched next window
   acc_t acc;            // per-lane accumulator (lane L <-> slot L-1)
 
+  static constexpr bool kStrict = STRICT;
   static __device__ __forceinline__ bool below(int x, int w) { return STRICT ? x < w : x <= w; }
   // boundary v sorts before key x  (v counts towards x's rank)
   static __device__ __forceinline__ bool before(int v, int x) { return STRICT ? v <= x : v < x; }
@@ -270,22 +272,95 @@ __device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountA
 
 // Fast path for R x 64 reads of the current class, all valid, unweighted, window placed and no key
 // behind the current slot (the caller has checked all that).  k[r] are the keys.
+// The boundary-crossing loop inside one register window, hand-scheduled (gfx950 ISA): hipcc turns
+// the C++ form of this multi-exit loop into a state machine of ~50 instructions per boundary; this
+// is 27.  Per boundary: 4 compares against the wave-uniform boundary + 4 scalar popcounts give the
+// number of keys at or below it; the difference to the previous boundary is the slot's count, which
+// is handed to the lane that owns the slot; then the next boundary is fetched with v_readlane.
+// Leaves with status 0 when every key is accounted for, 1 when the window is exhausted (j == 63).
+// CMP is "v_cmp_ge_i32" (key <= W) for the ends array, "v_cmp_gt_i32" (key < W) for the starts array.
+#define GTX_CROSS_LOOP4(CMP)                                                                        \
+  asm volatile(                                                                                     \
+      "1:\n\t"                                                                                      \
+      CMP " vcc, %[cw], %[k0]\n\t"                                                                  \
+      "s_bcnt1_i32_b64 %[c], vcc\n\t"                                                               \
+      CMP " vcc, %[cw], %[k1]\n\t"                                                                  \
+      "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                               \
+      "s_add_i32 %[c], %[c], %[t]\n\t"                                                              \
+      CMP " vcc, %[cw], %[k2]\n\t"                                                                  \
+      "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                               \
+      "s_add_i32 %[c], %[c], %[t]\n\t"                                                              \
+      CMP " vcc, %[cw], %[k3]\n\t"                                                                  \
+      "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                               \
+      "s_add_i32 %[c], %[c], %[t]\n\t"                                                              \
+      "s_sub_i32 %[t], %[c], %[cp]\n\t"                                                             \
+      "s_add_i32 %[pend], %[pend], %[t]\n\t"                                                        \
+      "s_mov_b32 %[cp], %[c]\n\t"                                                                   \
+      "s_mov_b32 %[st], 0\n\t"                                                                      \
+      "s_cmpk_eq_i32 %[c], 0x100\n\t"                                                               \
+      "s_cbranch_scc1 2f\n\t"                                                                       \
+      "s_add_i32 %[j], %[j], 1\n\t"                /* lane j+1 owns the slot that is now complete */ \
+      "s_add_i32 %[t], %[j], 1\n\t"                /* lane of the next upper boundary             */ \
+      "v_cmp_eq_u32 vcc, %[j], %[lane]\n\t"                                                         \
+      "v_mov_b32 %[tv], %[pend]\n\t"                                                                \
+      "v_cndmask_b32 %[tv], 0, %[tv], vcc\n\t"                                                      \
+      "v_add_u32 %[acc], %[acc], %[tv]\n\t"                                                         \
+      "s_mov_b32 %[pend], 0\n\t"                                                                    \
+      "s_mov_b32 %[st], 1\n\t"                                                                      \
+      "s_cmpk_eq_i32 %[j], 63\n\t"                                                                  \
+      "s_cbranch_scc1 2f\n\t"                                                                       \
+      "v_readlane_b32 %[cw], %[w], %[t]\n\t"       /* >= 4 instructions after the s_add of t      */ \
+      "s_branch 1b\n\t"                                                                             \
+      "2:\n\t"                                                                                      \
+      : [c] "=&s"(c), [t] "=&s"(t), [st] "=&s"(status), [tv] "=&v"(tv), [cw] "+s"(curW), [j] "+s"(j),  \
+        [pend] "+s"(pend), [cp] "+s"(cprev), [acc] "+v"(X.acc)                                      \
+      : [k0] "v"(k[0]), [k1] "v"(k[1]), [k2] "v"(k[2]), [k3] "v"(k[3]), [w] "v"(X.W), [lane] "v"(lane) \
+      : "vcc", "scc")
+
+// Fast path for R x 64 reads of the current class, all valid, unweighted, window placed and no key
+// behind the current slot (the caller has checked all that).  k[r] are the keys.
 template <int R, class WIN>
 __device__ __forceinline__ void walk_fast(WIN &X, const Seg &sg, const int (&k)[R], int kmax, int lane, bool &valid)
 {
   if (__ballot(WIN::below(kmax, X.curW)) == ~0ull) { X.pend += 64u * R; return; }   // no boundary crossed
-  unsigned cprev = 0; int adv = 0;
+  // (readfirstlane: these are wave-uniform, and the asm below needs them in SGPRs)
+  int j = rfl(X.j), curW = rfl(X.curW);
+  unsigned pend = (unsigned)rfl((int)X.pend), cprev = 0;
+  int adv = 0;
   for (;;) {
-    unsigned c = 0;
+    int status;
+    if constexpr (R == 4 && sizeof(X.acc) == 4) {
+      unsigned c, t, tv;
+      if (WIN::kStrict) GTX_CROSS_LOOP4("v_cmp_gt_i32"); else GTX_CROSS_LOOP4("v_cmp_ge_i32");
+      // asm results count as divergent for the compiler; they are SGPRs: tell it so
+      status = rfl(status); j = rfl(j); curW = rfl(curW); pend = (unsigned)rfl((int)pend); cprev = (unsigned)rfl((int)cprev);
+    } else {
+      status = 1;
+      for (;;) {                                             // inside one register window
+        unsigned c = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) c += (unsigned)__popcll(__ballot(WIN::below(k[r], X.curW)));
-    X.pend += c - cprev; cprev = c;
-    if (c == 64u * R) return;
-    if (X.fwd(sg, lane) && ++adv > 2) {
+        for (int r = 0; r < R; ++r) c += (unsigned)__popcll(__ballot(WIN::below(k[r], curW)));
+        pend += c - cprev; cprev = c;
+        if (c == 64u * R) { status = 0; break; }
+        ++j;
+        X.acc += (lane == j) ? pend : 0u; pend = 0;         // the slot is complete: hand its count to the lane that owns it
+        if (j == kSlots) break;
+        curW = rdlane(X.W, j + 1);
+      }
+    }
+    if (status == 0) { X.j = j; X.prevW = rdlane(X.W, j); X.curW = curW; X.pend = pend; return; }
+    // window exhausted (once per 63 boundaries): publish it and slide
+    if (X.acc != 0) atomicAdd(&X.hist[(i64)X.base - 1 + lane + sg.cls], (u64)X.acc);
+    X.acc = 0; X.base += kSlots; j = 0;
+    X.W = X.Wn; X.Wn = X.load_window(sg, X.base + kSlots, lane);
+    curW = rdlane(X.W, 1);
+    if (++adv > 2) {
       // keys spread over many windows: every key above the boundary just passed adds itself
+      const int passed = rdlane(X.W, 0);
 #pragma unroll
-      for (int r = 0; r < R; ++r) if (!WIN::below(k[r], X.prevW)) X.lane_add(sg, k[r], 1);
-      X.flush(sg, lane); valid = false;
+      for (int r = 0; r < R; ++r) if (!WIN::below(k[r], passed)) X.lane_add(sg, k[r], 1);
+      X.j = 0; X.prevW = passed; X.curW = curW; X.pend = 0;
+      valid = false;                                         // acc is 0 and nothing is pending: nothing to flush
       return;
     }
   }
@@ -343,6 +418,8 @@ __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__
     Tri t[R];
     bool have = false;                                         // t holds step s (loaded by the fast loop)
     // ---------------- fast loop ----------------
+    // No software prefetch: a second register buffer costs 48 VGPRs (8 -> 4 waves per SIMD) and
+    // measured no gain; the 7-8 resident waves per SIMD overlap each other's load latency instead.
     if (fastOk && st.validA && st.validB) {
       while (s < nFull) {
         const char *p = base + (size_t)s * (768 * R) + loff;
@@ -352,11 +429,13 @@ __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__
         int odd = 0, dg = 0, ks[R], ke[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { odd |= t[r].c ^ st.sg.cls; dg |= (t[r].e + zl) - t[r].s; ks[r] = t[r].s; ke[r] = t[r].e; }
-        // dg < 0 in some lane <=> some read has start > end (+zl); coordinates are < 2^31-2 in magnitude, the general path re-tests exactly
+        // dg < 0 in some lane <=> some read has start > end (+zl); the general path re-tests exactly
         const int kmin = min_of<R>(ks), emin = min_of<R>(ke);
         if (__ballot((odd != 0) | (dg < 0) | (kmin <= st.A.prevW) | (emin < st.B.prevW))) break;
-        walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
-        walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
+        if constexpr (!WEIGHTED) {
+          walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
+          walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
+        }
         ++s; have = false;
         if (!(st.validA && st.validB)) break;
       }
@@ -594,13 +673,15 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
   if (sortedHint) {
     const i64 nChunks = (n + 63) >> 6;
     const i64 waves = (nChunks + a.chunksPerWave - 1) / a.chunksPerWave;
-    const unsigned grid = (unsigned)((waves + 3) / 4);
+    static const int wpb = getenv("GTX_WAVES_PER_BLOCK") ? atoi(getenv("GTX_WAVES_PER_BLOCK")) : 4;
+    const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+    const unsigned bs = 64u * wpb;
     // a.prefetch = reads per lane per step (R)
-    if (weights) count_walk_kernel<true, 2><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-    else if (a.prefetch <= 1) count_walk_kernel<false, 1><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-    else if (a.prefetch == 2) count_walk_kernel<false, 2><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-    else if (a.prefetch == 3) count_walk_kernel<false, 3><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-    else count_walk_kernel<false, 4><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    if (weights) count_walk_kernel<true, 2><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (a.prefetch <= 1) count_walk_kernel<false, 1><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (a.prefetch == 2) count_walk_kernel<false, 2><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (a.prefetch == 3) count_walk_kernel<false, 3><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else count_walk_kernel<false, 4><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   } else {
     i64 blocks = (n + 255) / 256; if (blocks > 256 * 32) blocks = 256 * 32;
     if (weights) count_search_kernel<true><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
