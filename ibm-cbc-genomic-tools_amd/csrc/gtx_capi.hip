@@ -29,7 +29,9 @@ struct gtx_ctx {
   int nClasses = 0;
   int *d_sortedE = nullptr, *d_sortedS = nullptr, *d_segStart = nullptr;
   int *d_posE = nullptr, *d_posS = nullptr, *d_classBase = nullptr;
-  u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr;
+  u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr, *d_prefA = nullptr, *d_prefB = nullptr;
+  bool histDirty = false;              // a call was abandoned between begin and end
+  bool tileSumsValid = true;           // every kernel since the last finalize maintained the tile sums
   int64_t histLen = 0;
 
   gtx::DevInfo *d_info = nullptr;
@@ -100,7 +102,7 @@ void gtx_destroy(gtx_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
-  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_info);
+  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   dfree(c->d_reads); dfree(c->d_weights); dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
   if (c->h_info) (void)hipHostFree(c->h_info);
   for (auto &slot : c->evRing) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
@@ -168,7 +170,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   }
 
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
-  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB);
+  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB);
   c->nRefs = -1;
   const int64_t histLen = nv + nClasses;
   const int nTiles = gtx::scan_tiles(histLen);
@@ -180,8 +182,16 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   HIPCHK(c, hipMalloc(&c->d_classBase, sizeof(int32_t) * (m + 1)));
   HIPCHK(c, hipMalloc(&c->d_histA, sizeof(u64) * histLen));
   HIPCHK(c, hipMalloc(&c->d_histB, sizeof(u64) * histLen));
-  HIPCHK(c, hipMalloc(&c->d_partA, sizeof(u64) * (nTiles + 1)));
-  HIPCHK(c, hipMalloc(&c->d_partB, sizeof(u64) * (nTiles + 1)));
+  HIPCHK(c, hipMalloc(&c->d_partA, sizeof(u64) * (nTiles + 2)));
+  HIPCHK(c, hipMalloc(&c->d_partB, sizeof(u64) * (nTiles + 2)));
+  HIPCHK(c, hipMalloc(&c->d_prefA, sizeof(u64) * histLen));
+  HIPCHK(c, hipMalloc(&c->d_prefB, sizeof(u64) * histLen));
+  // invariant between calls: histograms and tile sums are all zero (the finalize kernels leave them so)
+  HIPCHK(c, hipMemset(c->d_histA, 0, sizeof(u64) * histLen));
+  HIPCHK(c, hipMemset(c->d_histB, 0, sizeof(u64) * histLen));
+  HIPCHK(c, hipMemset(c->d_partA, 0, sizeof(u64) * (nTiles + 2)));
+  HIPCHK(c, hipMemset(c->d_partB, 0, sizeof(u64) * (nTiles + 2)));
+  c->histDirty = false; c->tileSumsValid = true;
   HIPCHK(c, hipMemcpy(c->d_sortedE, sortedE.data(), sizeof(int32_t) * nv, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_sortedS, sortedS.data(), sizeof(int32_t) * nv, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_segStart, seg.data(), sizeof(int32_t) * (nClasses + 1), hipMemcpyHostToDevice));
@@ -201,7 +211,7 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
 {
   gtx::CountArgs a;
   a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart;
-  a.histA = c->d_histA; a.histB = c->d_histB; a.info = c->d_info;
+  a.histA = c->d_histA; a.histB = c->d_histB; a.partA = c->d_partA; a.partB = c->d_partB; a.info = c->d_info;
   a.nClasses = c->nClasses;
   // span of one wave: long enough to amortise the two window seeks at its start, short enough that
   // the grid has >= ~2 rounds of the 8192 wave slots of the chip (256 CUs x 32 waves)
@@ -217,16 +227,23 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
 // begin: zero histograms + info; accumulate: one kernel per resident batch; end: prefix + gather
 static int count_begin(gtx_ctx *c)
 {
-  HIPCHK(c, hipMemsetAsync(c->d_histA, 0, sizeof(u64) * c->histLen, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_histB, 0, sizeof(u64) * c->histLen, c->stream));
+  if (c->histDirty) {                             // only after an abandoned call
+    const int nTiles = gtx::scan_tiles(c->histLen);
+    HIPCHK(c, hipMemsetAsync(c->d_histA, 0, sizeof(u64) * c->histLen, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_histB, 0, sizeof(u64) * c->histLen, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_partA, 0, sizeof(u64) * (nTiles + 2), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_partB, 0, sizeof(u64) * (nTiles + 2), c->stream));
+  }
+  c->histDirty = true; c->tileSumsValid = true;
   HIPCHK(c, hipMemcpyAsync(c->d_info, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
   return GTX_OK;
 }
 
 static int count_end(gtx_ctx *c, void *d_hits)
 {
-  HIPCHK(c, gtx::launch_finalize(c->d_histA, c->d_histB, c->histLen, c->d_partA, c->d_partB, c->d_posE, c->d_posS, c->d_classBase,
-                                 c->nRefs, (u64 *)d_hits, c->stream));
+  HIPCHK(c, gtx::launch_finalize(c->d_histA, c->d_histB, c->histLen, c->d_partA, c->d_partB, c->tileSumsValid, c->d_prefA, c->d_prefB,
+                                 c->d_posE, c->d_posS, c->d_classBase, c->nRefs, (u64 *)d_hits, c->stream));
+  c->histDirty = false;
   return GTX_OK;
 }
 
@@ -239,6 +256,7 @@ int gtx_count_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int
   if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[0], c->stream)); }
   int rc = count_begin(c); if (rc) return rc;
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (!(flags & GTX_READS_SORTED)) c->tileSumsValid = false;
   HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), (flags & GTX_READS_SORTED) != 0, c->stream));
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   rc = count_end(c, d_hits); if (rc) return rc;
@@ -306,6 +324,7 @@ int gtx_count_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int6
     const int64_t cnt = std::min(batch, n - off);
     HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
     if (weights) HIPCHK(c, hipMemcpyAsync(c->d_weights, weights + off, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
+    if (!(flags & GTX_READS_SORTED)) c->tileSumsValid = false;
     HIPCHK(c, gtx::launch_count(c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags, cnt), (flags & GTX_READS_SORTED) != 0, c->stream));
     // fold this batch's info (indices are batch-relative) and reset the device block for the next one
     HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));

@@ -19,6 +19,8 @@ struct CountArgs {
   const int *segStart;           // [nClasses+1] class segments in both arrays
   unsigned long long *histA;     // [nValid + nClasses] rank histogram over sortedE
   unsigned long long *histB;     // same over sortedS
+  unsigned long long *partA;     // per-tile sums of histA / histB (1024 slots per tile)
+  unsigned long long *partB;
   DevInfo *info;
   int nClasses;
   int chunksPerWave;             // 64-read chunks one wave streams
@@ -44,8 +46,11 @@ struct ScanArgs {
 int scan_tiles(long long len);
 
 hipError_t launch_count(const void *reads, const void *weights, long long n, const CountArgs &a, bool sortedHint, hipStream_t st);
+// tileSumsValid: the streaming kernel kept tileA/tileB up to date (the search kernel does not).
+// Leaves histA/histB and the tile sums zeroed for the next call.
 hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB, long long histLen,
-                           unsigned long long *partA, unsigned long long *partB,
+                           unsigned long long *tileA, unsigned long long *tileB, bool tileSumsValid,
+                           unsigned long long *prefA, unsigned long long *prefB,
                            const int *posE, const int *posS, const int *classBase, long long m,
                            unsigned long long *hits, hipStream_t st);
 hipError_t launch_scan_hist(const void *reads, const void *weights, long long n, const ScanArgs &a, hipStream_t st);

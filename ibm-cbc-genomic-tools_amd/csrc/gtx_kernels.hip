@@ -37,6 +37,8 @@ typedef long long i64;
 static constexpr int kHi = 0x7fffffff;          // +inf sentinel (coordinates are < 2^31-1)
 static constexpr int kLo = (int)0x80000000;     // -inf sentinel
 static constexpr int kSlots = 63;               // slots per register window (lane 0 holds the boundary below slot 0)
+static constexpr int kTileShift = 10;           // finalize scan tile = 1024 histogram slots
+static constexpr int kTile = 1 << kTileShift;
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -71,6 +73,7 @@ struct Win {
   typedef typename std::conditional<WEIGHTED, i64, unsigned>::type acc_t;
   const int *arr;       // sorted boundaries of all classes
   u64 *hist;            // rank histogram, index = rank + class id
+  u64 *part;            // per-tile (kTile slots) sums of hist, kept up to date for the finalize scan
   int base;             // global rank of slot 0
   int j;                // current slot 0..62
   int prevW, curW;      // arr[base+j-1], arr[base+j]
@@ -96,11 +99,23 @@ struct Win {
     if (pend != 0) { if (lane == j + 1) acc += pend; pend = 0; }
   }
 
+  // publish the window's accumulators: one contiguous 64-lane atomic add into the histogram, and
+  // the same amounts into the (at most two) tile sums the window touches
+  __device__ __forceinline__ void flush_acc(const Seg &sg, int lane)
+  {
+    const i64 idx = (i64)base - 1 + lane + sg.cls;
+    if (acc != 0) atomicAdd(&hist[idx], (u64)(i64)acc);
+    const int tile = (int)(idx >> kTileShift);
+    const int t0 = rdlane(tile, 1);                        // lane 0 never holds a count
+    const i64 s0 = wave_sum(tile == t0 ? (i64)acc : 0), s1 = wave_sum(tile != t0 ? (i64)acc : 0);
+    if (lane == 0) { if (s0 != 0) atomicAdd(&part[t0], (u64)s0); if (s1 != 0) atomicAdd(&part[t0 + 1], (u64)s1); }
+    acc = 0;
+  }
+
   __device__ __forceinline__ void flush(const Seg &sg, int lane)
   {
     deposit(lane);
-    if (acc != 0) atomicAdd(&hist[(i64)base - 1 + lane + sg.cls], (u64)(i64)acc);
-    acc = 0;
+    if (__ballot(acc != 0)) flush_acc(sg, lane);
   }
 
   // position slot 0 at rank p (the caller has flushed)
@@ -165,7 +180,9 @@ struct Win {
   {
     int lo = sg.start, hi = sg.end;
     while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (before(arr[mid], key)) lo = mid + 1; else hi = mid; }
-    atomicAdd(&hist[(i64)lo + sg.cls], (u64)w);
+    const i64 idx = (i64)lo + sg.cls;
+    atomicAdd(&hist[idx], (u64)w);
+    atomicAdd(&part[idx >> kTileShift], (u64)w);
   }
 
   // Add the lanes of m (keys `key`, weights `w`) to the histogram; returns the lanes it left
@@ -350,8 +367,8 @@ __device__ __forceinline__ void walk_fast(WIN &X, const Seg &sg, const int (&k)[
     }
     if (status == 0) { X.j = j; X.prevW = rdlane(X.W, j); X.curW = curW; X.pend = pend; return; }
     // window exhausted (once per 63 boundaries): publish it and slide
-    if (X.acc != 0) atomicAdd(&X.hist[(i64)X.base - 1 + lane + sg.cls], (u64)X.acc);
-    X.acc = 0; X.base += kSlots; j = 0;
+    if (__ballot(X.acc != 0)) X.flush_acc(sg, lane);
+    X.base += kSlots; j = 0;
     X.W = X.Wn; X.Wn = X.load_window(sg, X.base + kSlots, lane);
     curW = rdlane(X.W, 1);
     if (++adv > 2) {
@@ -398,7 +415,7 @@ __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__
   const int nFull = nMine / (64 * R);                          // steps with all R x 64 reads present
 
   WaveState<WEIGHTED> st;
-  st.A.arr = a.sortedE; st.A.hist = a.histA; st.B.arr = a.sortedS; st.B.hist = a.histB;
+  st.A.arr = a.sortedE; st.A.hist = a.histA; st.A.part = a.partA; st.B.arr = a.sortedS; st.B.hist = a.histB; st.B.part = a.partB;
   st.A.acc = st.B.acc = 0; st.A.pend = st.B.pend = 0; st.A.j = st.B.j = 0; st.A.base = st.B.base = 0;
   st.A.W = st.A.Wn = st.B.W = st.B.Wn = kHi; st.A.prevW = st.B.prevW = kLo; st.A.curW = st.B.curW = kHi;
   st.validA = st.validB = false;
@@ -503,103 +520,82 @@ __global__ __launch_bounds__(256) void count_search_kernel(const Tri *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// Finalize: inclusive prefix sums of both histograms (3-phase block scan), then the gather
-//   hits[k] = (PA[posE[k]] - PA[classBase[k]]) - (PB[posS[k]] - PB[classBase[k]])
+// Finalize (2 launches):
+//   finalize_scan_kernel   one block per tile of kTile histogram slots: tile offset = sum of the
+//                          tile sums below it (kept up to date by the streaming kernel), local scan,
+//                          writes the inclusive prefixes PA/PB and ZEROES the histograms for the next call
+//   gather_hits_kernel     hits[k] = (PA[posE[k]] - PA[classBase[k]]) - (PB[posS[k]] - PB[classBase[k]])
+//                          and zeroes the tile sums
+// (tile_sums_kernel rebuilds the tile sums for the search kernel, which does not maintain them.)
 // ---------------------------------------------------------------------------------------------
-static constexpr int kScanThreads = 256;
-static constexpr int kScanItems = 16;                       // per thread
-static constexpr int kScanTile = kScanThreads * kScanItems; // 4096 per block
-
 __device__ __forceinline__ u64 block_sum(u64 v, u64 *lds)
 {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
   if (lane == 0) lds[wv] = v;
   __syncthreads();
   u64 s = 0;
   for (int k = 0; k < (int)(blockDim.x >> 6); k++) s += lds[k];
-  __syncthreads();
   return s;
 }
 
-__global__ __launch_bounds__(kScanThreads) void scan_partials_kernel(const u64 *__restrict__ ha, const u64 *__restrict__ hb, i64 len,
-                                                                     u64 *__restrict__ pa, u64 *__restrict__ pb)
+__global__ __launch_bounds__(256) void tile_sums_kernel(const u64 *__restrict__ ha, const u64 *__restrict__ hb, i64 len,
+                                                        u64 *__restrict__ pa, u64 *__restrict__ pb)
 {
-  __shared__ u64 lds[8];
-  i64 b0 = (i64)blockIdx.x * kScanTile;
+  __shared__ u64 lds[4];
+  const i64 b0 = (i64)blockIdx.x * kTile;
   u64 sa = 0, sb = 0;
-  for (int k = 0; k < kScanItems; k++) {
-    i64 i = b0 + (i64)k * kScanThreads + threadIdx.x;
+  for (int k = 0; k < kTile / 256; k++) {
+    i64 i = b0 + (i64)k * 256 + threadIdx.x;
     if (i < len) { sa += ha[i]; sb += hb[i]; }
   }
   sa = block_sum(sa, lds); sb = block_sum(sb, lds);
   if (threadIdx.x == 0) { pa[blockIdx.x] = sa; pb[blockIdx.x] = sb; }
 }
 
-// single block: exclusive scan of the per-tile partial sums (nb <= a few thousand)
-__global__ __launch_bounds__(1024) void scan_top_kernel(u64 *__restrict__ pa, u64 *__restrict__ pb, int nb)
+__global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha, u64 *__restrict__ hb, i64 len,
+                                                            const u64 *__restrict__ ta, const u64 *__restrict__ tb,
+                                                            u64 *__restrict__ pa, u64 *__restrict__ pb)
 {
-  __shared__ u64 la[1024], lb[1024];
-  __shared__ u64 carry[2];
-  if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
-  __syncthreads();
-  for (int b0 = 0; b0 < nb; b0 += 1024) {
-    int i = b0 + threadIdx.x;
-    u64 va = i < nb ? pa[i] : 0, vb = i < nb ? pb[i] : 0;
-    la[threadIdx.x] = va; lb[threadIdx.x] = vb;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      u64 xa = threadIdx.x >= o ? la[threadIdx.x - o] : 0, xb = threadIdx.x >= o ? lb[threadIdx.x - o] : 0;
-      __syncthreads();
-      la[threadIdx.x] += xa; lb[threadIdx.x] += xb;
-      __syncthreads();
-    }
-    if (i < nb) { pa[i] = carry[0] + la[threadIdx.x] - va; pb[i] = carry[1] + lb[threadIdx.x] - vb; }
-    __syncthreads();
-    if (threadIdx.x == 1023) { carry[0] += la[1023]; carry[1] += lb[1023]; }
-    __syncthreads();
-  }
-}
-
-// in place: histogram -> inclusive prefix.  Thread t owns kScanItems consecutive elements.
-__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(u64 *__restrict__ ha, u64 *__restrict__ hb, i64 len,
-                                                                  const u64 *__restrict__ pa, const u64 *__restrict__ pb)
-{
+  __shared__ u64 lds[4];
   __shared__ u64 wsum[2][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  i64 b0 = (i64)blockIdx.x * kScanTile + (i64)threadIdx.x * kScanItems;
-  u64 va[kScanItems], vb[kScanItems];
-  u64 sa = 0, sb = 0;
+  const int tile = blockIdx.x;
+  // offset of this tile: sum of the tile sums below it
+  u64 oa = 0, ob = 0;
+  for (int t = threadIdx.x; t < tile; t += 256) { oa += ta[t]; ob += tb[t]; }
+  oa = block_sum(oa, lds); ob = block_sum(ob, lds);
+  // thread t owns 4 consecutive slots (two 16-byte loads per array)
+  const i64 i0 = (i64)tile * kTile + (i64)threadIdx.x * 4;
+  u64 va[4], vb[4];
 #pragma unroll
-  for (int k = 0; k < kScanItems; k++) {
-    i64 i = b0 + k;
-    va[k] = i < len ? ha[i] : 0; vb[k] = i < len ? hb[i] : 0;
-    sa += va[k]; va[k] = sa; sb += vb[k]; vb[k] = sb;
-  }
-  // exclusive scan of the per-thread totals across the block
-  u64 xa = sa, xb = sb;
+  for (int k = 0; k < 4; k++) { va[k] = i0 + k < len ? ha[i0 + k] : 0; vb[k] = i0 + k < len ? hb[i0 + k] : 0; }
+  va[1] += va[0]; va[2] += va[1]; va[3] += va[2];
+  vb[1] += vb[0]; vb[2] += vb[1]; vb[3] += vb[2];
+  u64 xa = va[3], xb = vb[3];                      // inclusive scan of the thread totals across the wave
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    u64 ta = __shfl_up(xa, o), tb = __shfl_up(xb, o);
-    if (lane >= o) { xa += ta; xb += tb; }
+    u64 ya = __shfl_up(xa, o), yb = __shfl_up(xb, o);
+    if (lane >= o) { xa += ya; xb += yb; }
   }
   if (lane == 63) { wsum[0][wv] = xa; wsum[1][wv] = xb; }
   __syncthreads();
-  u64 oa = pa[blockIdx.x] + xa - sa, ob = pb[blockIdx.x] + xb - sb;
+  oa += xa - va[3]; ob += xb - vb[3];
   for (int k = 0; k < wv; k++) { oa += wsum[0][k]; ob += wsum[1][k]; }
 #pragma unroll
-  for (int k = 0; k < kScanItems; k++) {
-    i64 i = b0 + k;
-    if (i < len) { ha[i] = va[k] + oa; hb[i] = vb[k] + ob; }
-  }
+  for (int k = 0; k < 4; k++)
+    if (i0 + k < len) { pa[i0 + k] = va[k] + oa; pb[i0 + k] = vb[k] + ob; ha[i0 + k] = 0; hb[i0 + k] = 0; }
 }
 
 __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict__ pa, const u64 *__restrict__ pb,
                                                           const int *__restrict__ posE, const int *__restrict__ posS,
-                                                          const int *__restrict__ classBase, i64 m, u64 *__restrict__ hits)
+                                                          const int *__restrict__ classBase, i64 m, u64 *__restrict__ hits,
+                                                          u64 *__restrict__ ta, u64 *__restrict__ tb, int nTiles)
 {
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nTiles) { ta[k] = 0; tb[k] = 0; }         // the tile sums have been consumed: clean for the next call
   if (k >= m) return;
   int pe = posE[k];
   u64 h = 0;
@@ -665,7 +661,7 @@ __global__ __launch_bounds__(256) void scan_window_kernel(const u64 *__restrict_
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
-int scan_tiles(i64 len) { return (int)((len + kScanTile - 1) / kScanTile); }
+int scan_tiles(i64 len) { return (int)((len + kTile - 1) / kTile); }
 
 hipError_t launch_count(const void *reads, const void *weights, i64 n, const CountArgs &a, bool sortedHint, hipStream_t st)
 {
@@ -690,16 +686,16 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
   return hipGetLastError();
 }
 
-hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *partA, u64 *partB,
+hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, bool tileSumsValid, u64 *prefA, u64 *prefB,
                            const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, hipStream_t st)
 {
   const int nb = scan_tiles(histLen);
   if (nb > 0) {
-    scan_partials_kernel<<<nb, kScanThreads, 0, st>>>(histA, histB, histLen, partA, partB);
-    scan_top_kernel<<<1, 1024, 0, st>>>(partA, partB, nb);
-    scan_apply_kernel<<<nb, kScanThreads, 0, st>>>(histA, histB, histLen, partA, partB);
+    if (!tileSumsValid) tile_sums_kernel<<<nb, 256, 0, st>>>(histA, histB, histLen, tileA, tileB);
+    finalize_scan_kernel<<<nb, 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB);
   }
-  if (m > 0) gather_hits_kernel<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(histA, histB, posE, posS, classBase, m, hits);
+  const i64 work = m > nb ? m : nb;
+  if (work > 0) gather_hits_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(prefA, prefB, posE, posS, classBase, m, hits, tileA, tileB, nb);
   return hipGetLastError();
 }
 
