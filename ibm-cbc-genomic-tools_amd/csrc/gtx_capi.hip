@@ -34,7 +34,8 @@ struct gtx_ctx {
   bool tileSumsValid = true;           // every kernel since the last finalize maintained the tile sums
   int64_t histLen = 0;
 
-  gtx::DevInfo *d_info = nullptr;
+  gtx::DevInfo *d_info = nullptr;       // 2 blocks: the finalize of one call resets the block of the next
+  int infoCur = 0;
   gtx::DevInfo *h_info = nullptr;       // pinned: [0] = readback, [1] = init pattern
 
   // staging for the host-buffer entry points
@@ -84,11 +85,15 @@ gtx_ctx *gtx_create(int device_id)
   if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
   gtx_ctx *c = new gtx_ctx();
   c->device = device_id;
-  if (hipMalloc(&c->d_info, sizeof(gtx::DevInfo)) != hipSuccess || hipHostMalloc(&c->h_info, 2 * sizeof(gtx::DevInfo)) != hipSuccess) {
+  if (hipMalloc(&c->d_info, 2 * sizeof(gtx::DevInfo)) != hipSuccess || hipHostMalloc(&c->h_info, 2 * sizeof(gtx::DevInfo)) != hipSuccess) {
     g_create_error = "gtx_create: allocation failed"; delete c; return nullptr;
   }
   c->h_info[1].first_unsorted = INT64_MAX; c->h_info[1].n_no_class = 0; c->h_info[1].n_degenerate = 0; c->h_info[1].first_degenerate = INT64_MAX;
   c->h_info[0] = c->h_info[1];
+  if (hipMemcpy(c->d_info, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->d_info + 1, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice) != hipSuccess) {
+    g_create_error = "gtx_create: hipMemcpy failed"; delete c; return nullptr;
+  }
   for (auto &slot : c->evRing) for (auto &ev : slot) if (hipEventCreate(&ev) != hipSuccess) { g_create_error = "gtx_create: hipEventCreate failed"; delete c; return nullptr; }
   const char *cpw = getenv("GTX_CHUNKS_PER_WAVE");
   if (cpw && atoi(cpw) > 0) c->chunksPerWave = atoi(cpw);
@@ -211,7 +216,7 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
 {
   gtx::CountArgs a;
   a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart;
-  a.histA = c->d_histA; a.histB = c->d_histB; a.partA = c->d_partA; a.partB = c->d_partB; a.info = c->d_info;
+  a.histA = c->d_histA; a.histB = c->d_histB; a.partA = c->d_partA; a.partB = c->d_partB; a.info = c->d_info + c->infoCur;
   a.nClasses = c->nClasses;
   // span of one wave: long enough to amortise the two window seeks at its start, short enough that
   // the grid has >= ~2 rounds of the 8192 wave slots of the chip (256 CUs x 32 waves)
@@ -234,16 +239,17 @@ static int count_begin(gtx_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_partA, 0, sizeof(u64) * (nTiles + 2), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_partB, 0, sizeof(u64) * (nTiles + 2), c->stream));
   }
+  if (c->histDirty) HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
   c->histDirty = true; c->tileSumsValid = true;
-  HIPCHK(c, hipMemcpyAsync(c->d_info, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
   return GTX_OK;
 }
 
 static int count_end(gtx_ctx *c, void *d_hits)
 {
   HIPCHK(c, gtx::launch_finalize(c->d_histA, c->d_histB, c->histLen, c->d_partA, c->d_partB, c->tileSumsValid, c->d_prefA, c->d_prefB,
-                                 c->d_posE, c->d_posS, c->d_classBase, c->nRefs, (u64 *)d_hits, c->stream));
+                                 c->d_posE, c->d_posS, c->d_classBase, c->nRefs, (u64 *)d_hits, c->d_info + (c->infoCur ^ 1), c->stream));
   c->histDirty = false;
+  c->infoCur ^= 1;                                // the block just used stays readable until the call after next
   return GTX_OK;
 }
 
@@ -253,9 +259,8 @@ int gtx_count_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int
   if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_count_device: gtx_set_refs has not been called");
   if (n < 0 || (n > 0 && !d_reads) || (c->nRefs > 0 && !d_hits)) return fail(c, GTX_E_ARG, "gtx_count_device: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
-  if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[0], c->stream)); }
   int rc = count_begin(c); if (rc) return rc;
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
   if (!(flags & GTX_READS_SORTED)) c->tileSumsValid = false;
   HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), (flags & GTX_READS_SORTED) != 0, c->stream));
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -275,7 +280,7 @@ int gtx_last_info(gtx_ctx *c, gtx_count_info *info)
 {
   if (!c || !info) return GTX_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + (c->infoCur ^ 1), sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   info_out(c->h_info[0], info, 0);
   return GTX_OK;
@@ -327,8 +332,8 @@ int gtx_count_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int6
     if (!(flags & GTX_READS_SORTED)) c->tileSumsValid = false;
     HIPCHK(c, gtx::launch_count(c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags, cnt), (flags & GTX_READS_SORTED) != 0, c->stream));
     // fold this batch's info (indices are batch-relative) and reset the device block for the next one
-    HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_info, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + c->infoCur, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is reused by the next batch
     const gtx::DevInfo &d = c->h_info[0];
     gtx::DevInfo &t = c->streamTotal;
@@ -424,9 +429,8 @@ int gtx_scan_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int6
   int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
   a.center = prep == 'c'; a.sortedRule = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   if (c->scanTotalWindows > 0 && !d_out) return fail(c, GTX_E_ARG, "gtx_scan_device: null output");
-  if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[0], c->stream)); }
   if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * sizeof(u64), c->stream));
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
   HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream));
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, gtx::launch_scan_windows(c->d_micro, a, c->scanTotalWindows, (u64 *)d_out, c->stream));
@@ -480,7 +484,7 @@ int gtx_profile_read(gtx_ctx *c, int back, float *msKernel, float *msTotal)
   HIPCHK(c, hipEventSynchronize(ev[3]));
   float a = 0, b = 0;
   HIPCHK(c, hipEventElapsedTime(&a, ev[1], ev[2]));
-  HIPCHK(c, hipEventElapsedTime(&b, ev[0], ev[3]));
+  HIPCHK(c, hipEventElapsedTime(&b, ev[1], ev[3]));
   if (msKernel) *msKernel = a;
   if (msTotal) *msTotal = b;
   return GTX_OK;

@@ -52,7 +52,7 @@ hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB,
                            unsigned long long *tileA, unsigned long long *tileB, bool tileSumsValid,
                            unsigned long long *prefA, unsigned long long *prefB,
                            const int *posE, const int *posS, const int *classBase, long long m,
-                           unsigned long long *hits, hipStream_t st);
+                           unsigned long long *hits, DevInfo *nextInfo, hipStream_t st);
 hipError_t launch_scan_hist(const void *reads, const void *weights, long long n, const ScanArgs &a, hipStream_t st);
 hipError_t launch_scan_windows(const unsigned long long *micro, const ScanArgs &a, long long totalWindows,
                                unsigned long long *out, hipStream_t st);

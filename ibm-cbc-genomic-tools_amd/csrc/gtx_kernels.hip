@@ -563,15 +563,15 @@ __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha
   __shared__ u64 wsum[2][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int tile = blockIdx.x;
-  // offset of this tile: sum of the tile sums below it
-  u64 oa = 0, ob = 0;
-  for (int t = threadIdx.x; t < tile; t += 256) { oa += ta[t]; ob += tb[t]; }
-  oa = block_sum(oa, lds); ob = block_sum(ob, lds);
-  // thread t owns 4 consecutive slots (two 16-byte loads per array)
+  // thread t owns 4 consecutive slots (two 16-byte loads per array); issued first, used last
   const i64 i0 = (i64)tile * kTile + (i64)threadIdx.x * 4;
   u64 va[4], vb[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) { va[k] = i0 + k < len ? ha[i0 + k] : 0; vb[k] = i0 + k < len ? hb[i0 + k] : 0; }
+  // offset of this tile: sum of the tile sums below it
+  u64 oa = 0, ob = 0;
+  for (int t = threadIdx.x; t < tile; t += 256) { oa += ta[t]; ob += tb[t]; }
+  oa = block_sum(oa, lds); ob = block_sum(ob, lds);
   va[1] += va[0]; va[2] += va[1]; va[3] += va[2];
   vb[1] += vb[0]; vb[2] += vb[1]; vb[3] += vb[2];
   u64 xa = va[3], xb = vb[3];                      // inclusive scan of the thread totals across the wave
@@ -592,10 +592,11 @@ __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha
 __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict__ pa, const u64 *__restrict__ pb,
                                                           const int *__restrict__ posE, const int *__restrict__ posS,
                                                           const int *__restrict__ classBase, i64 m, u64 *__restrict__ hits,
-                                                          u64 *__restrict__ ta, u64 *__restrict__ tb, int nTiles)
+                                                          u64 *__restrict__ ta, u64 *__restrict__ tb, int nTiles, DevInfo *nextInfo)
 {
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < nTiles) { ta[k] = 0; tb[k] = 0; }         // the tile sums have been consumed: clean for the next call
+  if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; }
   if (k >= m) return;
   int pe = posE[k];
   u64 h = 0;
@@ -687,15 +688,15 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
 }
 
 hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, bool tileSumsValid, u64 *prefA, u64 *prefB,
-                           const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, hipStream_t st)
+                           const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, DevInfo *nextInfo, hipStream_t st)
 {
   const int nb = scan_tiles(histLen);
   if (nb > 0) {
     if (!tileSumsValid) tile_sums_kernel<<<nb, 256, 0, st>>>(histA, histB, histLen, tileA, tileB);
     finalize_scan_kernel<<<nb, 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB);
   }
-  const i64 work = m > nb ? m : nb;
-  if (work > 0) gather_hits_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(prefA, prefB, posE, posS, classBase, m, hits, tileA, tileB, nb);
+  const i64 work = (m > nb ? m : nb) > 0 ? (m > nb ? m : nb) : 1;
+  gather_hits_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(prefA, prefB, posE, posS, classBase, m, hits, tileA, tileB, nb, nextInfo);
   return hipGetLastError();
 }
 
