@@ -46,7 +46,7 @@ struct gtx_ctx {
   u64 *d_micro = nullptr; size_t capMicro = 0;
   long long *d_scanTab = nullptr; size_t capScanTab = 0;
   std::vector<long long> scanKey;       // geometry the tables on the device were built for
-  int64_t scanTotalWindows = 0, scanTotalMicro = 0;
+  int64_t scanTotalWindows = 0, scanTotalMicro = 0, scanTotalTiles = 0;
 
   // measurement
   static constexpr int kProfSlots = 64;   // ring: the last 64 profiled calls can be read back
@@ -395,17 +395,21 @@ static int scan_prepare(gtx_ctx *c, const int32_t *classLen, int nClasses, int s
   std::vector<long long> key;
   key.push_back(nClasses); key.push_back(step); key.push_back(size);
   for (int i = 0; i < nClasses; i++) { key.push_back(classLen[i]); key.push_back(classOff[i]); }
-  const size_t tabLen = (size_t)4 * nClasses + 1;
+  const size_t tabLen = (size_t)5 * nClasses + 2;
   if (key != c->scanKey) {
     std::vector<long long> tab(tabLen);
-    long long *microOff = tab.data(), *nMicro = microOff + nClasses, *winOff = nMicro + nClasses, *outOff = winOff + nClasses + 1;
-    long long mo = 0, wo = 0;
+    long long *microOff = tab.data(), *nMicro = microOff + nClasses, *winOff = nMicro + nClasses, *outOff = winOff + nClasses + 1,
+              *tileOff = outOff + nClasses;
+    long long mo = 0, wo = 0, to = 0;
+    const long long tile = gtx::scan_window_tile();
     for (int i = 0; i < nClasses; i++) {
       long long nm = classLen[i] < 0 ? 0 : classLen[i] / step;
-      microOff[i] = mo; nMicro[i] = nm; winOff[i] = wo; outOff[i] = classOff[i];
-      mo += nm; wo += gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size);
+      long long nw = gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size);
+      microOff[i] = mo; nMicro[i] = nm; winOff[i] = wo; outOff[i] = classOff[i]; tileOff[i] = to;
+      mo += nm; wo += nw; to += (nw + tile - 1) / tile;
     }
-    winOff[nClasses] = wo;
+    winOff[nClasses] = wo; tileOff[nClasses] = to;
+    c->scanTotalTiles = to;
     if (tabLen > c->capScanTab) { dfree(c->d_scanTab); c->capScanTab = 0; HIPCHK(c, hipMalloc(&c->d_scanTab, tabLen * sizeof(long long))); c->capScanTab = tabLen; }
     if ((size_t)mo + 1 > c->capMicro) { dfree(c->d_micro); c->capMicro = 0; HIPCHK(c, hipMalloc(&c->d_micro, ((size_t)mo + 1) * sizeof(u64))); c->capMicro = (size_t)mo + 1; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -413,8 +417,9 @@ static int scan_prepare(gtx_ctx *c, const int32_t *classLen, int nClasses, int s
     c->scanKey = key; c->scanTotalMicro = mo; c->scanTotalWindows = wo;
   }
   out->micro = c->d_micro; out->microOff = c->d_scanTab; out->nMicro = c->d_scanTab + nClasses;
-  out->winOff = c->d_scanTab + 2 * nClasses; out->outOff = c->d_scanTab + 3 * nClasses + 1;
+  out->winOff = c->d_scanTab + 2 * nClasses; out->outOff = c->d_scanTab + 3 * nClasses + 1; out->tileOff = c->d_scanTab + 4 * nClasses + 1;
   out->nClasses = nClasses; out->winStep = step; out->comb = size / step;
+  out->winStepInv = step > 1 ? (unsigned)((1ull << 32) / (unsigned)step) : 0;
   return GTX_OK;
 }
 
@@ -433,7 +438,7 @@ int gtx_scan_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int6
   if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
   HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream));
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, a, c->scanTotalWindows, (u64 *)d_out, c->stream));
+  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, a, c->scanTotalTiles, (u64 *)d_out, c->stream));
   if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   return GTX_OK;
 }
@@ -464,7 +469,7 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
     if (n > batch) HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   if (extent > 0) HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)extent * sizeof(u64), c->stream));
-  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, a, c->scanTotalWindows, c->d_out, c->stream));
+  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, a, c->scanTotalTiles, c->d_out, c->stream));
   if (extent > 0) HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)extent * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTX_OK;

@@ -36,8 +36,10 @@ struct ScanArgs {
   const long long *nMicro;       // [nClasses] micro-windows of class c (len / step)
   const long long *winOff;       // [nClasses+1] prefix of window counts (launch order)
   const long long *outOff;       // [nClasses] caller's class_offsets
+  const long long *tileOff;      // [nClasses+1] prefix of window tiles (scan_window_tile() windows each)
   int nClasses;
   int winStep;
+  unsigned winStepInv;           // floor(2^32 / winStep) (unused for winStep == 1)
   int comb;                      // win_size / win_step
   int center;                    // preprocess 'c'
   int sortedRule;                // sorted scanner: no validity test, pos < 1 lands in the first micro-window
@@ -54,7 +56,8 @@ hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB,
                            const int *posE, const int *posS, const int *classBase, long long m,
                            unsigned long long *hits, DevInfo *nextInfo, hipStream_t st);
 hipError_t launch_scan_hist(const void *reads, const void *weights, long long n, const ScanArgs &a, hipStream_t st);
-hipError_t launch_scan_windows(const unsigned long long *micro, const ScanArgs &a, long long totalWindows,
+int scan_window_tile();
+hipError_t launch_scan_windows(const unsigned long long *micro, const ScanArgs &a, long long totalTiles,
                                unsigned long long *out, hipStream_t st);
 
 } // namespace gtx

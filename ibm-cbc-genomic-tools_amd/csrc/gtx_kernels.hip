@@ -613,50 +613,113 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict_
 // genomic_intervals.cpp:5036-5055) and sliding sums (:5058-5075).
 // Sorted reads put runs of equal micro-window index in neighbouring lanes: one atomic per run.
 // ---------------------------------------------------------------------------------------------
+// previous lane's value (lane 0 keeps its own): DPP wave_shr:1, no LDS traffic
+__device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+
+// one register of 64 reads -> micro-window slots -> one atomic per run of equal slots
 template <bool WEIGHTED>
-__global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, ScanArgs a)
+__device__ __forceinline__ void scan_add64(const Tri &t, int w, bool in_range, const ScanArgs &a, int lane)
 {
-  const int lane = threadIdx.x & 63;
-  for (i64 i0 = ((i64)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n; i0 += (i64)gridDim.x * blockDim.x) {
-    i64 i = i0 + lane;
-    i64 slot = -1; i64 w = 1;
-    if (i < n) {
-      Tri t = reads[i];
-      if (WEIGHTED) w = weights[i];
-      if ((unsigned)t.c < (unsigned)a.nClasses && (a.sortedRule || (t.s <= t.e && t.e > 0))) {
-        i64 pos = a.center ? (i64)t.s + ((i64)t.e - t.s) / 2 : (i64)t.s;
-        i64 mw = (pos - 1) / a.winStep;             // 0-based micro-window (C division: pos>=1 checked next)
-        if (a.sortedRule && pos < 1) { pos = 1; mw = 0; }    // the sorted scanner takes START <= stop of the first window
-        if (pos >= 1 && mw < a.nMicro[t.c]) slot = a.microOff[t.c] + mw;
-      }
+  int cls = -1, mw = -1;
+  if (in_range && (unsigned)t.c < (unsigned)a.nClasses && (a.sortedRule || (t.s <= t.e && t.e > 0))) {
+    i64 pos = a.center ? (i64)t.s + ((i64)t.e - t.s) / 2 : (i64)t.s;
+    if (a.sortedRule && pos < 1) pos = 1;           // the sorted scanner takes START <= stop of the first window
+    if (pos >= 1) {
+      // (pos-1) / winStep without a 64-bit divide: 32-bit reciprocal estimate (never too high, at most 1 low) + fix-up
+      const unsigned x = (unsigned)(pos - 1), d = (unsigned)a.winStep;
+      unsigned q = d == 1 ? x : __umulhi(x, a.winStepInv);
+      unsigned r = x - q * d;
+      if (r >= d) { q++; r -= d; }
+      if (r >= d) q++;
+      if ((i64)q < a.nMicro[t.c]) { cls = t.c; mw = (int)q; }
     }
-    // run-length aggregation across the wave
-    i64 up = __shfl_up(slot, 1);
-    bool head = lane == 0 || up != slot;
-    u64 heads = __ballot(head);
-    if (!WEIGHTED) {
-      if (head && slot >= 0) {
-        u64 later = lane == 63 ? 0 : (heads >> (lane + 1));
-        int run = later ? __ffsll((unsigned long long)later) : 64 - lane;
-        atomicAdd(&a.micro[slot], (u64)run);
-      }
-    } else if (slot >= 0) atomicAdd(&a.micro[slot], (u64)w);   // weighted: one atomic per read
+  }
+  if (__ballot(mw >= 0) == 0) return;
+  if (WEIGHTED) {                                  // weighted: one atomic per read
+    if (mw >= 0) atomicAdd(&a.micro[a.microOff[cls] + mw], (u64)(i64)w);
+    return;
+  }
+  // sorted reads put equal slots in neighbouring lanes: the first lane of a run adds the run length
+  const int pm = lane_prev(mw), pc = lane_prev(cls);      // (all lanes active here: DPP must not run under a partial exec mask)
+  const bool head = lane == 0 || pm != mw || pc != cls;
+  const u64 heads = __ballot(head);
+  if (head && mw >= 0) {
+    const u64 later = lane == 63 ? 0 : (heads >> (lane + 1));
+    const int run = later ? __ffsll((unsigned long long)later) : 64 - lane;
+    atomicAdd(&a.micro[a.microOff[cls] + mw], (u64)run);
   }
 }
 
-// out[off_out[c] + k] = sum_{j<comb} micro[off_in[c] + k + j]; one thread per output window.
-__global__ __launch_bounds__(256) void scan_window_kernel(const u64 *__restrict__ micro, ScanArgs a, i64 totalWindows, u64 *__restrict__ out)
+// genomic_scans counts, histogram pass: like the count kernel a wave takes 4 x 64 reads per step
+// (four coalesced non-temporal 768-byte requests in flight), spans are dealt to waves contiguously.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, ScanArgs a)
 {
-  i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= totalWindows) return;
-  // find class by scanning the (small) class table
+  constexpr int R = 4;
+  const int lane = threadIdx.x & 63;
+  const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + rfl(threadIdx.x >> 6);
+  const i64 nWaves = (i64)gridDim.x * (blockDim.x >> 6);
+  const i64 nSteps = (n + 64 * R - 1) / (64 * R);
+  const i64 per = (nSteps + nWaves - 1) / nWaves;
+  i64 s0 = wave * per, s1 = s0 + per; if (s1 > nSteps) s1 = nSteps;
+  for (i64 s = s0; s < s1; ++s) {
+    const i64 at = s * 64 * R;
+    Tri t[R]; int w[R];
+    if (at + 64 * R <= n) {
+      const char *p = (const char *)(reads + at) + (unsigned)lane * 12u;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { t[r] = load_tri(p + 768 * r); w[r] = WEIGHTED ? weights[at + 64 * r + lane] : 1; }
+#pragma unroll
+      for (int r = 0; r < R; ++r) scan_add64<WEIGHTED>(t[r], w[r], true, a, lane);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const i64 i = at + 64 * r + lane;
+        t[r].c = -1; t[r].s = 0; t[r].e = 0; w[r] = 1;
+        if (i < n) { t[r] = reads[i]; if (WEIGHTED) w[r] = weights[i]; }
+        scan_add64<WEIGHTED>(t[r], w[r], i < n, a, lane);
+      }
+    }
+  }
+}
+
+// Window sums: out[k] = sum_{j<comb} micro[k+j].  A block owns a tile of kWinTile consecutive windows
+// of one class: the tile's kWinTile+comb-1 micro-windows go through LDS once (coalesced), every thread
+// then slides over kWinPer consecutive windows (first sum, then +new -old).
+static constexpr int kWinPer = 8;
+static constexpr int kWinTile = 256 * kWinPer;
+static constexpr int kWinMaxComb = 2048;           // LDS: (kWinTile + kWinMaxComb) * 8 B = 32 KB
+
+__global__ __launch_bounds__(256) void scan_window_kernel(const u64 *__restrict__ micro, ScanArgs a, u64 *__restrict__ out)
+{
+  __shared__ u64 lds[kWinTile + kWinMaxComb];
+  // class of this tile (tileOff is a prefix over classes; few dozen entries)
   int c = 0;
-  while (c + 1 < a.nClasses && g >= a.winOff[c + 1]) c++;
-  i64 k = g - a.winOff[c];
-  const u64 *src = micro + a.microOff[c] + k;
-  u64 s = 0;
-  for (int j = 0; j < a.comb; j++) s += src[j];
-  out[a.outOff[c] + k] = s;
+  while (c + 1 < a.nClasses && (i64)blockIdx.x >= a.tileOff[c + 1]) c++;
+  const i64 nWin = a.winOff[c + 1] - a.winOff[c];
+  const i64 k0 = ((i64)blockIdx.x - a.tileOff[c]) * kWinTile;
+  if (k0 >= nWin) return;
+  const i64 cntWin = nWin - k0 < kWinTile ? nWin - k0 : kWinTile;
+  const u64 *src = micro + a.microOff[c] + k0;
+  u64 *dst = out + a.outOff[c] + k0;
+  if (a.comb == 1) {                               // windows == micro-windows: plain copy
+    for (i64 i = threadIdx.x; i < cntWin; i += 256) dst[i] = src[i];
+    return;
+  }
+  if (a.comb > kWinMaxComb) {                      // very long windows: direct sums
+    for (i64 i = threadIdx.x; i < cntWin; i += 256) { u64 s = 0; for (int j = 0; j < a.comb; j++) s += src[i + j]; dst[i] = s; }
+    return;
+  }
+  const i64 need = cntWin + a.comb - 1;
+  for (i64 i = threadIdx.x; i < need; i += 256) lds[i] = src[i];
+  __syncthreads();
+  const i64 w0 = (i64)threadIdx.x * kWinPer;
+  if (w0 < cntWin) {
+    u64 s = 0;
+    for (int j = 0; j < a.comb; j++) s += lds[w0 + j];
+    dst[w0] = s;
+    for (int q = 1; q < kWinPer && w0 + q < cntWin; q++) { s += lds[w0 + q + a.comb - 1] - lds[w0 + q - 1]; dst[w0 + q] = s; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -703,16 +766,18 @@ hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 
 hipError_t launch_scan_hist(const void *reads, const void *weights, i64 n, const ScanArgs &a, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
-  i64 blocks = (n + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16;
+  i64 blocks = (n + 4095) / 4096; if (blocks > 256 * 16) blocks = 256 * 16;      // >= 4 steps per wave, <= 16 blocks per CU
   if (weights) scan_hist_kernel<true><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   else scan_hist_kernel<false><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   return hipGetLastError();
 }
 
-hipError_t launch_scan_windows(const u64 *micro, const ScanArgs &a, i64 totalWindows, u64 *out, hipStream_t st)
+int scan_window_tile() { return kWinTile; }
+
+hipError_t launch_scan_windows(const u64 *micro, const ScanArgs &a, i64 totalTiles, u64 *out, hipStream_t st)
 {
-  if (totalWindows <= 0) return hipSuccess;
-  scan_window_kernel<<<(unsigned)((totalWindows + 255) / 256), 256, 0, st>>>(micro, a, totalWindows, out);
+  if (totalTiles <= 0) return hipSuccess;
+  scan_window_kernel<<<(unsigned)totalTiles, 256, 0, st>>>(micro, a, out);
   return hipGetLastError();
 }
 
