@@ -76,11 +76,19 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    # GTX_BENCH_REHEARSE=1: all ranks share GPU 0 and reduce through gloo -- only to exercise the N>1 code
+    # path on a one-GPU box (RCCL refuses two ranks on one device); never a reported configuration
+    rehearse = os.environ.get("GTX_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     # ---- workload -------------------------------------------------------------------------------
     refs = synth.genome_intervals(args.refs, 43, 50, 2000)                 # 1M refs, all chromosomes, every rank
@@ -89,6 +97,11 @@ def main():
     reads = make_reads_on_device(args.reads, my_chroms, 1000 + rank, device)
     n = reads.shape[0]
     hits = torch.zeros(len(refs), dtype=torch.int64, device=device)        # uint64 bit pattern; int64 for RCCL sum
+    # two count vectors in ping-pong: the all-reduce of step i (RCCL's own stream) overlaps the kernels of step i+1
+    hits_pp = [hits, torch.zeros_like(hits)]
+    pending = [None, None]
+    pipelined = world > 1 and os.environ.get("GTX_BENCH_SYNC_REDUCE") != "1"
+    step_no = [0]
 
     eng = gtx.Engine(local)
     eng.set_refs(refs, synth.n_classes())
@@ -97,11 +110,28 @@ def main():
     flags = gtx.READS_SORTED
 
     def step():
+        if pipelined and not rehearse:
+            b = step_no[0] & 1
+            step_no[0] += 1
+            if pending[b] is not None:
+                pending[b].wait()                                          # stream-side wait: buffer b is free again
+            eng.count_device(reads.data_ptr(), n, hits_pp[b].data_ptr(), None, flags)
+            pending[b] = dist.all_reduce(hits_pp[b], op=dist.ReduceOp.SUM, async_op=True)
+            return
         eng.count_device(reads.data_ptr(), n, hits.data_ptr(), None, flags)
         if world > 1:
-            shard.reduce_counts(hits, dist, device_tensor=True)            # RCCL all-reduce over xGMI of the count vector
+            if rehearse:
+                h = hits.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                hits.copy_(h)
+            else:
+                shard.reduce_counts(hits, dist, device_tensor=True)        # RCCL all-reduce over xGMI of the count vector
 
     def fence():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -119,9 +149,30 @@ def main():
     k_ms = [eng.profile_last(b)[0] for b in range(min(args.steps, 64))]
     eng.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # multi-rank parity: the reduced vector must be the single-process count of all ranks' reads
+        if os.environ.get("GTX_BENCH_VERIFY") == "1":
+            from oracle import orc
+            mine = orc.count(refs, reads.cpu().numpy(), algo=orc.SORTED_MERGE).view(np.int64)
+            tot = torch.from_numpy(mine.copy()) if rehearse else torch.from_numpy(mine.copy()).to(device)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            pipelined = False
+            step()
+            torch.cuda.synchronize()
+            if not torch.equal(hits.cpu(), tot.cpu()):
+                sys.exit("PARITY FAILURE: reduced multi-rank counts differ from the oracle's")
+
+    # HBM traffic of the dominant kernel: bench.py cannot collect PMC counters itself; the figure is the
+    # committed rocprofv3 --pmc pass of this same command (scripts/pmc.sh -> profiles/rNN_pmc_count_walk.json),
+    # FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes for gfx950, valid for the default workload only
+    traffic = None
+    if n == 100_000_000 and args.refs == 1_000_000:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_count_walk.json")))
+        if cand:
+            traffic = json.load(open(cand[-1])).get("traffic_bytes_per_launch")
 
     kernel_ms = float(np.mean(k_ms))
     alg_bytes = 12.0 * n                                                    # the triples the kernel must read once
@@ -155,9 +206,10 @@ def main():
             "config": {"workload": "BASELINE config 3: %d 50bp reads/GPU sorted by (chrom,start) x %d ref intervals over 24 hg38 "
                                    "chromosomes, strand ignored (genomic_overlaps count -S -i); reads resident in HBM" % (n, len(refs)),
                        "reads_per_gpu": n, "refs": len(refs),
-                       "parallelism": "chromosome shards (LPT) x%d, all-reduce(sum) of the uint64 count vector" % world},
+                       "parallelism": "chromosome shards (LPT) x%d, all-reduce(sum) of the uint64 count vector%s"
+                                      % (world, " overlapped with the next step" if pipelined else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "count_walk_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
             "cpu_baseline": cpu,
         }
