@@ -142,3 +142,97 @@ def test_scans_cli_equals_oracle_cli(beds, args):
         assert got[1] == want[1]
     else:
         assert got[2].strip() == want[2].strip()
+
+
+# ---- G1: the reference's own example data, examples/genes.bed.gz (4785 overlapping,
+# strand-mixed chr1 genes, space-separated BED6; copied as a data fixture) x 200k seeded 50 bp reads,
+# in the five modes that must agree pairwise ------------------------------------------------------------
+@pytest.fixture(scope="module")
+def g1(tmp_path_factory):
+    d = tmp_path_factory.mktemp("g1")
+    rng = np.random.default_rng(101)
+    n = 200_000
+    s = np.sort(rng.integers(3_000_000, 197_000_000, size=n))
+    strand = rng.choice(["+", "-"], size=n)
+    tri = np.stack([np.zeros(n, dtype=np.int64), s + 1, s + 50], axis=1)
+    write_bed(d / "reads_pos.bed", tri, ["chr1"], None, strand)
+    o = np.lexsort((s, strand == "-"))
+    write_bed(d / "reads_strand.bed", tri[o], ["chr1"], None, strand[o])
+    # genes sorted the two ways -S needs (the shipped file is sorted by start)
+    genes = gzip.open(os.path.join(GOLD, "genes.bed.gz"), "rt").read().splitlines()
+    rows = [g.split() for g in genes]
+    with open(d / "genes_pos.bed", "w") as f:
+        f.write("\n".join(" ".join(r) for r in sorted(rows, key=lambda r: int(r[1]))) + "\n")
+    with open(d / "genes_strand.bed", "w") as f:
+        f.write("\n".join(" ".join(r) for r in sorted(rows, key=lambda r: (r[5] == "-", int(r[1])))) + "\n")
+    return d
+
+
+def test_g1_five_modes(g1):
+    gz = os.path.join(GOLD, "genes.bed.gz")
+    runs = {
+        "unsorted": ["count", gz, "reads_pos.bed"],
+        "unsorted_i": ["count", "-i", gz, "reads_pos.bed"],
+        "S_i": ["count", "-S", "-i", "genes_pos.bed", "reads_pos.bed"],
+        "S_s": ["count", "-S", "-s", "genes_strand.bed", "reads_strand.bed"],
+        "S": ["count", "-S", "genes_pos.bed", "reads_pos.bed"],
+    }
+    out = {}
+    for name, args in runs.items():
+        want = oracle(args, cwd=g1)
+        got = product("overlaps", args, cwd=g1)
+        assert want[0] == 0 and got[0] == 0, (name, want[2], got[2])
+        assert got[1] == want[1], name
+        out[name] = dict(line.split("\t") for line in got[1].splitlines())
+    # pairwise agreement inside each strand mode (two distinct results in all, as the survey observed)
+    assert out["unsorted_i"] == out["S_i"]
+    assert out["unsorted"] == out["S"] == out["S_s"]
+    assert out["unsorted"] != out["unsorted_i"]
+
+
+def test_g8_medium_single_chromosome(tmp_path):
+    """1M reads x 200k refs on one chromosome as BED text through both CLIs."""
+    refs = synth.refs_single_chrom(200_000, seed=42)
+    reads = synth.reads_single_chrom(1_000_000, seed=42)
+    write_bed(tmp_path / "refs.bed", refs, ["chr1"], ["e%d" % i for i in range(len(refs))])
+    np.savetxt(tmp_path / "reads.bed", np.stack([reads[:, 1] - 1, reads[:, 2]], axis=1), fmt="chr1\t%d\t%d")
+    for args in (["count", "-i", "refs.bed", "reads.bed"], ["count", "-S", "-i", "-min", "3", "refs.bed", "reads.bed"]):
+        want = oracle(args, cwd=tmp_path)
+        got = product("overlaps", args, cwd=tmp_path)
+        assert got[:2] == want[:2]
+
+
+# ---- sorted-merge corner cases: zero-length reads / regions, errors the packer must reproduce -----------
+def test_sorted_mode_zero_length_regions(tmp_path):
+    (tmp_path / "refs.bed").write_text("chr1\t100\t100\tZ\t0\t+\nchr1\t100\t200\tA\t0\t+\nchr1\t150\t150\tY\t0\t+\n")
+    (tmp_path / "reads.bed").write_text("chr1\t50\t120\tr1\t0\t+\nchr1\t100\t100\tr2\t0\t+\nchr1\t100\t101\tr3\t0\t+\nchr1\t149\t151\tr5\t0\t+\nchr1\t150\t150\tr4\t0\t+\n")
+    args = ["count", "-S", "-i", "refs.bed", "reads.bed"]
+    want = oracle(args, cwd=tmp_path)
+    got = product("overlaps", args, cwd=tmp_path)
+    assert want[0] == 0
+    assert got[:2] == want[:2]
+
+
+@pytest.mark.parametrize("reads,frag", [
+    ("chr1\t10\t20\tr\t0\t+\nchr1\t5\n", "number of tokens should be at least 3"),
+    ("chr1\t10\t20\tr\t0\t+\nchr1\t30\t40\tr\t0\t*\n", "invalid strand '*'"),
+    ("chr1\t10\t20\tr\t0\t+\nchr1\t-30\t-20\tr\t0\t+\n", "stop position must be positive"),
+])
+def test_ingest_errors_match_reference_text(tmp_path, reads, frag):
+    (tmp_path / "refs.bed").write_text("chr1\t0\t1000\tA\t0\t+\n")
+    (tmp_path / "reads.bed").write_text(reads)
+    args = ["count", "-i", "refs.bed", "reads.bed"]
+    want = oracle(args, cwd=tmp_path)
+    got = product("overlaps", args, cwd=tmp_path)
+    assert want[0] == 1 and got[0] == 1
+    assert frag in want[2] and got[2].strip() == want[2].strip()
+
+
+def test_no_gpu_free_paths_fail_loudly(tmp_path):
+    (tmp_path / "refs.bed").write_text("chr1\t0\t1000\tA\t0\t+\n")
+    rc, out, err = product("overlaps", ["coverage", "refs.bed"], cwd=tmp_path)
+    assert rc == 1 and "outside the MI355X" in err
+    rc, out, err = product("overlaps", ["frobnicate", "refs.bed"], cwd=tmp_path)
+    assert rc == 1 and "Unknown operation" in err
+    rc, out, err = product("overlaps", ["count", "-Q", "refs.bed"], cwd=tmp_path)
+    assert rc == 1 and "unknown option '-Q'" in err
