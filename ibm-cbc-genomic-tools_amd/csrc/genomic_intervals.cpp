@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <future>
 #include <iostream>
 
 #include "gtx.h"
@@ -20,6 +21,15 @@ using gtxhost::PackError;
 using gtxhost::PackOptions;
 
 bool _MESSAGES_ = false;
+
+// GTX_TIMING=1: wall-clock marks on stderr (where the end-to-end time of a CLI run goes)
+#include <chrono>
+static void Mark(const char *what)
+{
+  static const bool on = getenv("GTX_TIMING") != NULL;
+  static const auto t0 = std::chrono::steady_clock::now();
+  if (on) fprintf(stderr, "[gtx %8.3f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what);
+}
 
 static char *CopyString(const char *s) { size_t n = strlen(s) + 1; char *p = new char[n]; memcpy(p, s, n); return p; }
 
@@ -147,8 +157,12 @@ void GenomicRegionSet::DetectFormat(const char *line)
   format = "BED";
 }
 
+void GtxWarmUp();
+
 void GenomicRegionSet::Init()
 {
+  if (getenv("GTX_NO_WARMUP") == NULL) GtxWarmUp();
+  Mark(load_in_memory ? "GenomicRegionSet (in memory): open" : "GenomicRegionSet (stream): open");
   std::string err;
   src = LineSource::Open(file, &err);
   if (!src) { fprintf(stderr, "%s\n", err.c_str()); exit(1); }
@@ -222,13 +236,31 @@ LineSource *GenomicRegionSet::DetachStream(std::string *current_line, long int *
 // ---------------------------------------------------------------------------------------------------
 // GPU context shared by the classes of this file
 // ---------------------------------------------------------------------------------------------------
+// HIP start-up takes ~0.2 s: it runs on its own thread from the first region set on, next to the
+// parsing of the reference file (GtxWarmUp), and is joined when the context is first needed.
+static std::future<gtx_ctx *> g_ctx_future;
+static std::string g_ctx_error;
+
+static gtx_ctx *CreateContext()
+{
+  const char *d = getenv("GTX_DEVICE");
+  gtx_ctx *c = gtx_create(d ? atoi(d) : 0);
+  if (!c) g_ctx_error = gtx_last_error(NULL);      // thread-local in the library: copy it out on this thread
+  return c;
+}
+
+void GtxWarmUp()
+{
+  if (!g_ctx_future.valid()) g_ctx_future = std::async(std::launch::async, CreateContext);
+}
+
 static gtx_ctx *Device()
 {
   static gtx_ctx *ctx = NULL;
   if (!ctx) {
-    const char *d = getenv("GTX_DEVICE");
-    ctx = gtx_create(d ? atoi(d) : 0);
-    if (!ctx) { fflush(stdout); fprintf(stderr, "\nError: %s\n", gtx_last_error(NULL)); exit(1); }
+    GtxWarmUp();
+    ctx = g_ctx_future.get();
+    if (!ctx) { fflush(stdout); fprintf(stderr, "\nError: %s\n", g_ctx_error.c_str()); exit(1); }
   }
   return ctx;
 }
@@ -243,7 +275,7 @@ static void CheckGtx(gtx_ctx *c, int rc)
 template <class Sink>
 static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
 {
-  const size_t batch_reads = 32u << 20;
+  const size_t batch_reads = 24u << 20;
   PackedBatch batch; PackError err;
   if (!set->load_in_memory) {
     std::string first; long int first_no = 0;
@@ -278,7 +310,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
 }
 
 // quick order hint for the kernel choice (a wrong hint only costs speed): sample adjacent pairs
-static bool LooksSorted(const std::vector<int32_t> &tri)
+static bool LooksSorted(const gtxhost::RawVec &tri)
 {
   const size_t n = tri.size() / 3;
   if (n < 2) return true;
@@ -310,6 +342,7 @@ unsigned long int *GenomicRegionSetOverlaps::CountIndexOverlaps(bool match_gaps,
   const long int M = IndexSet->n_regions;
   const bool sorted = UsesSortedMerge(), by_strand = SortedByStrand();
   for (long int k = 0; k < M; k++) IndexSet->R[k]->n_line = k;                       // :5309
+  Mark("CountIndexOverlaps: start");
 
   // ---- index side ----
   ChromTable chroms;
@@ -339,9 +372,12 @@ unsigned long int *GenomicRegionSetOverlaps::CountIndexOverlaps(bool match_gaps,
     refs[3 * k] = id + ((strand_aware && i->STRAND == '-') ? n_chrom : 0);
     refs[3 * k + 1] = (int32_t)i->START; refs[3 * k + 2] = (int32_t)i->STOP;
   }
+  Mark("index packed");
   gtx_ctx *ctx = Device();
+  Mark("device ready");
   const int n_classes = std::max(1, n_chrom * (strand_aware ? 2 : 1));
   CheckGtx(ctx, gtx_set_refs_ex(ctx, refs.data(), M, n_classes, sorted ? GTX_REFS_KEEP_ZERO_LENGTH : 0));
+  Mark("gtx_set_refs done");
 
   // ---- query side: stream -> packed batches -> device ----
   PackOptions opt;
@@ -358,7 +394,9 @@ unsigned long int *GenomicRegionSetOverlaps::CountIndexOverlaps(bool match_gaps,
   });
   unsigned long int *hits = new unsigned long int[M > 0 ? M : 1];
   gtx_count_info info;
+  Mark("queries packed and enqueued");
   CheckGtx(ctx, gtx_count_end(ctx, (uint64_t *)hits, &info));
+  Mark("counts on the host");
   if (info.n_degenerate != 0) { fflush(stdout); fprintf(stderr, "\nError: internal: the packer let %ld degenerate reads through\n", (long)info.n_degenerate); exit(1); }
 
   // sorted merge only: a zero-length read never overlaps a zero-length region at the same spot

@@ -1,10 +1,14 @@
 // gtx_bed.cpp -- see gtx_bed.h
 #include "gtx_bed.h"
 
+#include <fcntl.h>
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
+#include <future>
 #include <thread>
 
 namespace gtxhost {
@@ -24,7 +28,12 @@ LineSource *LineSource::Open(const char *path, std::string *err)
   if (b1 == 0x1f && b2 == 0x8b) {                        // gzip magic
     s->gz_ = gzopen(path, "rb");
     if (s->gz_) gzbuffer(s->gz_, 1u << 20);
-  } else s->fp_ = fopen(path, "rb");
+  } else {
+    s->fp_ = fopen(path, "rb");
+    // a regular file can also be read in bulk with parallel pread()s (NextBlockView)
+    struct stat sb;
+    if (s->fp_ && fstat(fileno(s->fp_), &sb) == 0 && S_ISREG(sb.st_mode)) { s->fd_ = fileno(s->fp_); s->file_len_ = (size_t)sb.st_size; }
+  }
   if (!s->gz_ && !s->fp_) { *err = std::string("[CreateFileBuffer] Error: cannot open file '") + path + "'!"; delete s; return nullptr; }
   return s;
 }
@@ -60,6 +69,39 @@ char *LineSource::Next()
       return line;
     }
     if (Fill() == 0) return nullptr;                     // EOF: a last line without '\n' is dropped
+  }
+}
+
+size_t LineSource::NextBlockView(std::vector<char> &block, char **view, size_t target, long *first_line)
+{
+  if (fd_ < 0) { size_t n = NextBlock(block, target, first_line); *view = block.data(); return n; }
+  *first_line = line_no_ + 1;
+  if (!bulk_started_) {
+    // bytes the line-at-a-time reader has buffered but not handed out come first
+    bulk_started_ = true;
+    long at = ftell(fp_);
+    file_pos_ = at < 0 ? file_len_ : (size_t)at - (end_ - pos_);
+    pos_ = end_ = 0;
+  }
+  for (;;) {
+    const size_t left = file_len_ - file_pos_;
+    if (left == 0) return 0;
+    const size_t want = std::min(left, target);
+    block.resize(want);
+    // parallel pread: the kernel-to-user copy is the cost of reading a cached file, so split it
+    const int K = (int)std::min<size_t>(8, want / (4u << 20) + 1);
+    std::vector<std::thread> th;
+    auto rd = [&](int k) {
+      size_t b0 = want * (size_t)k / K, b1 = want * (size_t)(k + 1) / K;
+      while (b0 < b1) { ssize_t g = pread(fd_, block.data() + b0, b1 - b0, (off_t)(file_pos_ + b0)); if (g <= 0) break; b0 += (size_t)g; }
+    };
+    for (int k = 1; k < K; k++) th.emplace_back(rd, k);
+    rd(0);
+    for (auto &x : th) x.join();
+    char *nl = (char *)memrchr(block.data(), '\n', want);
+    if (nl) { const size_t n = (size_t)(nl - block.data()) + 1; file_pos_ += n; *view = block.data(); return n; }
+    if (want == left) return 0;                          // only an unterminated tail is left
+    target *= 2;                                         // a line longer than the block: take more
   }
 }
 
@@ -288,7 +330,7 @@ long CountLines(const char *b, const char *e)
 
 BedPacker::BedPacker(LineSource *src, const PackOptions &opt) : src_(src), opt_(opt)
 {
-  if (opt_.threads <= 0) { unsigned hc = std::thread::hardware_concurrency(); opt_.threads = hc ? (int)std::min(hc, 32u) : 4; }
+  if (opt_.threads <= 0) { unsigned hc = std::thread::hardware_concurrency(); opt_.threads = hc ? (int)std::min(hc, 64u) : 4; }
 }
 
 void BedPacker::Prime(const std::string &line, long line_no)
@@ -304,13 +346,13 @@ void BedPacker::PrimeBlock(const std::string &lines, long first_line)
 }
 
 // parse one block of complete lines with the thread pool and append the result to *out
-bool BedPacker::PackBlock(std::vector<char> &block, size_t got, long first_line, PackedBatch *out, PackError *err)
+bool BedPacker::PackBlock(char *block, size_t got, long first_line, PackedBatch *out, PackError *err)
 {
   const bool sorted_mode = opt_.mode == PACK_OVERLAPS_SORTED || opt_.mode == PACK_SCAN_SORTED;
   // cut the block into pieces at line ends
   int T = (int)std::min<size_t>((size_t)opt_.threads, got / (256u << 10) + 1);
   std::vector<Piece> pieces(T);
-  char *b = block.data(), *e = block.data() + got;
+  char *b = block, *e = block + got;
   for (int t = 0; t < T; t++) {
     char *pe = t == T - 1 ? e : b + (size_t)(e - b) / (size_t)(T - t);
     if (t != T - 1) { char *nl = (char *)memchr(pe, '\n', (size_t)(e - pe)); pe = nl ? nl + 1 : e; }
@@ -331,7 +373,7 @@ bool BedPacker::PackBlock(std::vector<char> &block, size_t got, long first_line,
     ParsePiece(&pieces[0], opt_);
     for (auto &x : th) x.join();
   }
-  // merge in file order; the first error in file order wins
+  // seams and errors in file order; the first error in file order wins
   for (int t = 0; t < T; t++) {
     Piece &p = pieces[t];
     if (sorted_mode && p.any && have_prev_ &&
@@ -340,10 +382,25 @@ bool BedPacker::PackBlock(std::vector<char> &block, size_t got, long first_line,
     }
     if (p.err.set) { *err = p.err; return false; }
     if (sorted_mode && p.any) { have_prev_ = true; prev_chrom_ = p.last_chrom; prev_strand_ = p.last_strand; prev_start_ = p.last_start; }
-    out->tri.insert(out->tri.end(), p.tri.begin(), p.tri.end());
-    out->w.insert(out->w.end(), p.w.begin(), p.w.end());
-    out->zero_len.insert(out->zero_len.end(), p.zero_len.begin(), p.zero_len.end());
-    out->n_lines += p.n_lines;
+  }
+  // concatenate the pieces (each thread copies its own piece to its final place)
+  std::vector<size_t> at_tri(T + 1), at_w(T + 1);
+  at_tri[0] = out->tri.size(); at_w[0] = out->w.size();
+  for (int t = 0; t < T; t++) { at_tri[t + 1] = at_tri[t] + pieces[t].tri.size(); at_w[t + 1] = at_w[t] + pieces[t].w.size(); }
+  out->tri.resize(at_tri[T]); out->w.resize(at_w[T]);
+  {
+    auto copy_piece = [&](int t) {
+      if (!pieces[t].tri.empty()) memcpy(out->tri.data() + at_tri[t], pieces[t].tri.data(), pieces[t].tri.size() * sizeof(int32_t));
+      if (!pieces[t].w.empty()) memcpy(out->w.data() + at_w[t], pieces[t].w.data(), pieces[t].w.size() * sizeof(int32_t));
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(copy_piece, t);
+    copy_piece(0);
+    for (auto &x : th) x.join();
+  }
+  for (int t = 0; t < T; t++) {
+    out->zero_len.insert(out->zero_len.end(), pieces[t].zero_len.begin(), pieces[t].zero_len.end());
+    out->n_lines += pieces[t].n_lines;
   }
   return true;
 }
@@ -351,21 +408,26 @@ bool BedPacker::PackBlock(std::vector<char> &block, size_t got, long first_line,
 bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
 {
   out->tri.clear(); out->w.clear(); out->zero_len.clear(); out->n_lines = 0;
+  out->tri.reserve(target_reads * 3 + (8u << 20));       // one allocation; its pages are first touched by the copy threads
+  if (opt_.max_label_value > 1) out->w.reserve(target_reads + (3u << 20));
   if (primed_set_) {
     primed_set_ = false;
-    if (!PackBlock(primed_, primed_.size(), primed_first_line_, out, err)) return false;
+    if (!PackBlock(primed_.data(), primed_.size(), primed_first_line_, out, err)) return false;
   }
-  if (!src_) return false;
-  std::vector<char> block;
-  const size_t block_bytes = 48u << 20;
+  if (!src_ || exhausted_) return false;
+  // the next block is read (and inflated, for .gz) while the current one is parsed
+  const size_t block_bytes = 64u << 20;
+  auto read_block = [this, block_bytes]() { Ahead a; long fl = 0; a.got = src_->NextBlockView(a.data, &a.view, block_bytes, &fl); return a; };
+  if (!ahead_.valid()) ahead_ = std::async(std::launch::async, read_block);
   while (out->tri.size() / 3 < target_reads) {
-    long first_line = 0;
-    size_t got = src_->NextBlock(block, block_bytes, &first_line);
-    if (got == 0) return false;
+    Ahead cur = ahead_.get();
+    if (cur.got == 0) { ahead_ = std::future<Ahead>(); exhausted_ = true; return false; }
+    const long first_line = src_->line_no() + 1;
+    ahead_ = std::async(std::launch::async, read_block);
     const int64_t before = out->n_lines;
-    bool ok = PackBlock(block, got, first_line, out, err);
+    bool ok = PackBlock(cur.view, cur.got, first_line, out, err);
     src_->AdvanceLines((long)(out->n_lines - before));
-    if (!ok) return false;
+    if (!ok) { ahead_.wait(); return false; }
   }
   return true;
 }

@@ -13,6 +13,8 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <future>
+#include <memory>
 #include <string>
 #include <vector>
 #include <zlib.h>
@@ -35,12 +37,17 @@ class LineSource {
   // `block` (0 at the end); *first_line receives the file line number of the block's first line.
   // The caller counts the lines of the block and reports them with AdvanceLines().
   size_t NextBlock(std::vector<char> &block, size_t target_bytes, long *first_line);
+  // Same, but a regular text file is read with several pread() calls in parallel straight into
+  // `block` (no intermediate buffer); *view = block.data().  .gz and stdin go through NextBlock.
+  size_t NextBlockView(std::vector<char> &block, char **view, size_t target_bytes, long *first_line);
   void AdvanceLines(long n) { line_no_ += n; }
 
  private:
   LineSource() {}
   size_t Fill();                     // read more raw bytes into buf_; 0 at EOF
   FILE *fp_ = nullptr; gzFile gz_ = nullptr; bool is_stdin_ = false;
+  int fd_ = -1; size_t file_len_ = 0, file_pos_ = 0;          // regular text file: bulk path uses pread on fd_
+  bool bulk_started_ = false;
   std::vector<char> buf_;            // raw bytes [pos_, end_) not yet handed out
   size_t pos_ = 0, end_ = 0;
   bool eof_ = false;
@@ -98,9 +105,18 @@ struct PackError {
   std::string msg;                   // what the reference prints after "Error: Line N: "
 };
 
+// std::vector that does not zero-fill on resize(): the packer threads overwrite every element
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+  template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<int32_t, NoInitAlloc<int32_t>> RawVec;
+
 struct PackedBatch {
-  std::vector<int32_t> tri;          // 3 per read
-  std::vector<int32_t> w;            // empty unless max_label_value > 1
+  RawVec tri;                        // 3 per read
+  RawVec w;                          // empty unless max_label_value > 1
   std::vector<int32_t> zero_len;     // (class, start, weight) triples, see collect_zero_length
   int64_t n_lines = 0;               // lines consumed (regions seen), including dropped ones
 };
@@ -117,8 +133,10 @@ class BedPacker {
   void PrimeBlock(const std::string &lines, long first_line);
   bool NextBatch(PackedBatch *out, size_t target_reads, PackError *err);
  private:
-  bool PackBlock(std::vector<char> &block, size_t got, long first_line, PackedBatch *out, PackError *err);
+  bool PackBlock(char *block, size_t got, long first_line, PackedBatch *out, PackError *err);
   std::vector<char> primed_; long primed_first_line_ = 0; bool primed_set_ = false;
+  struct Ahead { std::vector<char> data; char *view = nullptr; size_t got = 0; };   // block read ahead of the parsers
+  std::future<Ahead> ahead_; bool exhausted_ = false;
   LineSource *src_; PackOptions opt_;
   // order check across blocks
   bool have_prev_ = false; std::string prev_chrom_; char prev_strand_ = '+'; long prev_start_ = 0;

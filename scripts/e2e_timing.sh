@@ -1,0 +1,14 @@
+#!/bin/bash
+# where does the CLI's end-to-end time go? (GTX_TIMING marks)
+cd "$GRAFT_REPO_ROOT"
+python3 - <<PY
+import sys, os
+sys.path.insert(0, "ibm-cbc-genomic-tools_amd")
+import numpy as np, pandas as pd
+from gtx import synth
+names = np.array(synth.CHROM_NAMES)
+refs = synth.genome_intervals(1_000_000, 43, 50, 2000); reads = synth.genome_intervals(20_000_000, 44, 50, 51)
+pd.DataFrame({"c": names[refs[:,0]], "s": refs[:,1]-1, "e": refs[:,2], "l": ["g%d"%i for i in range(len(refs))]}).to_csv("/tmp/t_refs.bed", sep="\t", header=False, index=False)
+pd.DataFrame({"c": names[reads[:,0]], "s": reads[:,1]-1, "e": reads[:,2]}).to_csv("/tmp/t_reads.bed", sep="\t", header=False, index=False)
+PY
+GTX_TIMING=1 ./ibm-cbc-genomic-tools_amd/csrc/genomic_overlaps count -S -i /tmp/t_refs.bed /tmp/t_reads.bed 2>&1 >/dev/null | grep gtx
