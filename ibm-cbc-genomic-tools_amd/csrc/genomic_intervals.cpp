@@ -315,9 +315,10 @@ static bool LooksSorted(const gtxhost::RawVec &tri)
   const size_t n = tri.size() / 3;
   if (n < 2) return true;
   const size_t stride = n > 4096 ? n / 4096 : 1;
+  int descents = 0;                                     // a batch is a few sorted runs at most (e.g. the '+' then the '-' reads)
   for (size_t i = 0; i + 1 < n; i += stride) {
     const int32_t *a = &tri[3 * i], *b = a + 3;
-    if (b[0] < a[0] || (b[0] == a[0] && b[1] < a[1])) return false;
+    if ((b[0] < a[0] || (b[0] == a[0] && b[1] < a[1])) && ++descents > 2) return false;
   }
   return true;
 }

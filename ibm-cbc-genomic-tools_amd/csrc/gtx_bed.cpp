@@ -224,6 +224,7 @@ struct Piece {                       // one thread's share of a block
   char *begin = nullptr, *end = nullptr;
   long first_line = 0; long n_lines = 0;
   std::vector<int32_t> tri, w, zero_len;
+  std::vector<int32_t> tri_minus, w_minus;   // strand-aware runs: '-' reads are grouped behind the '+' reads of the batch
   PackError err;
   // order-check context of the regions in this piece
   bool any = false;
@@ -310,10 +311,12 @@ void ParsePiece(Piece *p, const PackOptions &o)
         break;
     }
     if (p->err.set) break;
-    const int32_t cls = (int32_t)(id + ((o.strand_aware && f.strand == '-') ? n_chrom : 0));
-    p->tri.push_back(cls); p->tri.push_back((int32_t)f.start); p->tri.push_back((int32_t)f.stop);
+    const bool minus = o.strand_aware && f.strand == '-';
+    const int32_t cls = (int32_t)(id + (minus ? n_chrom : 0));
+    std::vector<int32_t> &dst = minus ? p->tri_minus : p->tri;
+    dst.push_back(cls); dst.push_back((int32_t)f.start); dst.push_back((int32_t)f.stop);
     long wv = 1;
-    if (weighted) { long v = f.label ? FastAtol(f.label) : 0; wv = v < o.max_label_value ? v : o.max_label_value; p->w.push_back((int32_t)wv); }
+    if (weighted) { long v = f.label ? FastAtol(f.label) : 0; wv = v < o.max_label_value ? v : o.max_label_value; (minus ? p->w_minus : p->w).push_back((int32_t)wv); }
     if (zero_len && o.collect_zero_length) { p->zero_len.push_back(cls); p->zero_len.push_back((int32_t)f.start); p->zero_len.push_back((int32_t)wv); }
   }
   p->n_lines = line_no - (p->first_line - 1);
@@ -383,15 +386,20 @@ bool BedPacker::PackBlock(char *block, size_t got, long first_line, PackedBatch 
     if (p.err.set) { *err = p.err; return false; }
     if (sorted_mode && p.any) { have_prev_ = true; prev_chrom_ = p.last_chrom; prev_strand_ = p.last_strand; prev_start_ = p.last_start; }
   }
-  // concatenate the pieces (each thread copies its own piece to its final place)
-  std::vector<size_t> at_tri(T + 1), at_w(T + 1);
+  // concatenate the pieces (each thread copies its own piece to its final place): all '+' parts in
+  // file order, then all '-' parts in file order -- counting does not depend on the order of the
+  // reads, and a position-sorted strand-aware stream becomes two class-sorted runs for the kernel
+  std::vector<size_t> at_tri(2 * T + 1), at_w(2 * T + 1);
   at_tri[0] = out->tri.size(); at_w[0] = out->w.size();
   for (int t = 0; t < T; t++) { at_tri[t + 1] = at_tri[t] + pieces[t].tri.size(); at_w[t + 1] = at_w[t] + pieces[t].w.size(); }
-  out->tri.resize(at_tri[T]); out->w.resize(at_w[T]);
+  for (int t = 0; t < T; t++) { at_tri[T + t + 1] = at_tri[T + t] + pieces[t].tri_minus.size(); at_w[T + t + 1] = at_w[T + t] + pieces[t].w_minus.size(); }
+  out->tri.resize(at_tri[2 * T]); out->w.resize(at_w[2 * T]);
   {
     auto copy_piece = [&](int t) {
       if (!pieces[t].tri.empty()) memcpy(out->tri.data() + at_tri[t], pieces[t].tri.data(), pieces[t].tri.size() * sizeof(int32_t));
       if (!pieces[t].w.empty()) memcpy(out->w.data() + at_w[t], pieces[t].w.data(), pieces[t].w.size() * sizeof(int32_t));
+      if (!pieces[t].tri_minus.empty()) memcpy(out->tri.data() + at_tri[T + t], pieces[t].tri_minus.data(), pieces[t].tri_minus.size() * sizeof(int32_t));
+      if (!pieces[t].w_minus.empty()) memcpy(out->w.data() + at_w[T + t], pieces[t].w_minus.data(), pieces[t].w_minus.size() * sizeof(int32_t));
     };
     std::vector<std::thread> th;
     for (int t = 1; t < T; t++) th.emplace_back(copy_piece, t);
