@@ -434,11 +434,12 @@ int gtx_scan_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int6
   int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
   a.center = prep == 'c'; a.sortedRule = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   if (c->scanTotalWindows > 0 && !d_out) return fail(c, GTX_E_ARG, "gtx_scan_device: null output");
-  if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * sizeof(u64), c->stream));
+  const bool micro64 = d_weights != nullptr;
+  if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (micro64 ? 8 : 4), c->stream));
   if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
   HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream));
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, a, c->scanTotalTiles, (u64 *)d_out, c->stream));
+  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, (u64 *)d_out, c->stream));
   if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   return GTX_OK;
 }
@@ -460,7 +461,8 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
   rc = ensure_out(c, (size_t)extent); if (rc) return rc;
   const int64_t batch = 64ll << 20;
   rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
-  if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * sizeof(u64), c->stream));
+  const bool micro64 = weights != nullptr;
+  if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (micro64 ? 8 : 4), c->stream));
   for (int64_t off = 0; off < n; off += batch) {
     const int64_t cnt = std::min(batch, n - off);
     HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
@@ -469,7 +471,7 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
     if (n > batch) HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   if (extent > 0) HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)extent * sizeof(u64), c->stream));
-  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, a, c->scanTotalTiles, c->d_out, c->stream));
+  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, c->d_out, c->stream));
   if (extent > 0) HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)extent * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GTX_OK;

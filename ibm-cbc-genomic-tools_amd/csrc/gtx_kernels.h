@@ -31,7 +31,7 @@ struct CountArgs {
 };
 
 struct ScanArgs {
-  unsigned long long *micro;     // micro-window histogram, all classes
+  unsigned long long *micro;     // micro-window histogram, all classes: uint64 when weighted, uint32 (same buffer) otherwise
   const long long *microOff;     // [nClasses] offset of class c in micro
   const long long *nMicro;       // [nClasses] micro-windows of class c (len / step)
   const long long *winOff;       // [nClasses+1] prefix of window counts (launch order)
@@ -57,7 +57,7 @@ hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB,
                            unsigned long long *hits, DevInfo *nextInfo, hipStream_t st);
 hipError_t launch_scan_hist(const void *reads, const void *weights, long long n, const ScanArgs &a, hipStream_t st);
 int scan_window_tile();
-hipError_t launch_scan_windows(const unsigned long long *micro, const ScanArgs &a, long long totalTiles,
+hipError_t launch_scan_windows(const void *micro, bool micro64, const ScanArgs &a, long long totalTiles,
                                unsigned long long *out, hipStream_t st);
 
 } // namespace gtx

@@ -616,11 +616,10 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict_
 // previous lane's value (lane 0 keeps its own): DPP wave_shr:1, no LDS traffic
 __device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 
-// one register of 64 reads -> micro-window slots -> one atomic per run of equal slots
-template <bool WEIGHTED>
-__device__ __forceinline__ void scan_add64(const Tri &t, int w, bool in_range, const ScanArgs &a, int lane)
+// micro-window (class, index) of one read, or (-1,-1) when it does not count
+__device__ __forceinline__ void scan_slot(const Tri &t, bool in_range, const ScanArgs &a, int &cls, int &mw)
 {
-  int cls = -1, mw = -1;
+  cls = -1; mw = -1;
   if (in_range && (unsigned)t.c < (unsigned)a.nClasses && (a.sortedRule || (t.s <= t.e && t.e > 0))) {
     i64 pos = a.center ? (i64)t.s + ((i64)t.e - t.s) / 2 : (i64)t.s;
     if (a.sortedRule && pos < 1) pos = 1;           // the sorted scanner takes START <= stop of the first window
@@ -634,20 +633,60 @@ __device__ __forceinline__ void scan_add64(const Tri &t, int w, bool in_range, c
       if ((i64)q < a.nMicro[t.c]) { cls = t.c; mw = (int)q; }
     }
   }
-  if (__ballot(mw >= 0) == 0) return;
+}
+
+// Per-wave tile of micro-window counters in LDS.  Sorted reads stay inside a window of consecutive
+// micro-windows for a long time, so their increments are LDS atomics (pre-aggregated per run of equal
+// lanes) and reach HBM only when the tile is flushed: 64 contiguous 8-byte atomics per instruction,
+// i.e. whole 64-byte requests at the memory side instead of one request per read.
+static constexpr int kScanTile = 1024;
+
+struct ScanTile { unsigned *lds; int cls, base; bool used; };
+
+// (unweighted scans count in 32 bits -- at most n_reads < 2^32 per micro-window -- which halves the
+//  atomic, memset and window-sum traffic; weighted scans keep the reference's 64-bit counters)
+__device__ __forceinline__ void scan_tile_flush(ScanTile &T, const ScanArgs &a, int lane)
+{
+  if (!T.used) return;
+  unsigned *dst = (unsigned *)a.micro + a.microOff[T.cls] + T.base;
+  for (int k = 0; k < kScanTile; k += 64) {
+    unsigned v = T.lds[k + lane];
+    if (__ballot(v != 0) == 0) continue;
+    if (v != 0) { atomicAdd(&dst[k + lane], v); T.lds[k + lane] = 0; }
+  }
+  T.used = false;
+}
+
+template <bool WEIGHTED>
+__device__ __forceinline__ void scan_add64(const Tri &t, int w, bool in_range, const ScanArgs &a, ScanTile &T, int lane)
+{
+  int cls, mw;
+  scan_slot(t, in_range, a, cls, mw);
+  const u64 valid = __ballot(mw >= 0);
+  if (valid == 0) return;
   if (WEIGHTED) {                                  // weighted: one atomic per read
     if (mw >= 0) atomicAdd(&a.micro[a.microOff[cls] + mw], (u64)(i64)w);
     return;
   }
-  // sorted reads put equal slots in neighbouring lanes: the first lane of a run adds the run length
-  const int pm = lane_prev(mw), pc = lane_prev(cls);      // (all lanes active here: DPP must not run under a partial exec mask)
-  const bool head = lane == 0 || pm != mw || pc != cls;
+  // keep the tile where the reads are: if the first counting read of this register is outside, move the tile there
+  const int f = __ffsll((unsigned long long)valid) - 1;
+  const int fc = rdlane(cls, f), fm = rdlane(mw, f);
+  if (!T.used || fc != T.cls || (unsigned)(fm - T.base) >= (unsigned)kScanTile) {
+    scan_tile_flush(T, a, lane);
+    T.cls = fc; T.base = fm; T.used = true;
+  }
+  const bool inTile = mw >= 0 && cls == T.cls && (unsigned)(mw - T.base) < (unsigned)kScanTile;
+  // runs of equal slots in neighbouring lanes: the first lane of a run adds the run length
+  const int key = inTile ? mw : -1 - lane;         // lanes outside the tile never join a run
+  const int pk = lane_prev(key);                   // (all lanes active here: DPP must not run under a partial exec mask)
+  const bool head = lane == 0 || pk != key;
   const u64 heads = __ballot(head);
-  if (head && mw >= 0) {
+  if (inTile && head) {
     const u64 later = lane == 63 ? 0 : (heads >> (lane + 1));
     const int run = later ? __ffsll((unsigned long long)later) : 64 - lane;
-    atomicAdd(&a.micro[a.microOff[cls] + mw], (u64)run);
+    atomicAdd(&T.lds[mw - T.base], (unsigned)run);
   }
+  if (mw >= 0 && !inTile) atomicAdd((unsigned *)a.micro + a.microOff[cls] + mw, 1u);   // scattered read: straight to HBM
 }
 
 // genomic_scans counts, histogram pass: like the count kernel a wave takes 4 x 64 reads per step
@@ -656,12 +695,16 @@ template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, ScanArgs a)
 {
   constexpr int R = 4;
+  __shared__ unsigned tiles[4][kScanTile];
   const int lane = threadIdx.x & 63;
-  const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + rfl(threadIdx.x >> 6);
+  const int wv = rfl(threadIdx.x >> 6);
+  const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + wv;
   const i64 nWaves = (i64)gridDim.x * (blockDim.x >> 6);
   const i64 nSteps = (n + 64 * R - 1) / (64 * R);
   const i64 per = (nSteps + nWaves - 1) / nWaves;
   i64 s0 = wave * per, s1 = s0 + per; if (s1 > nSteps) s1 = nSteps;
+  ScanTile T; T.lds = tiles[wv]; T.cls = -1; T.base = 0; T.used = false;
+  if (!WEIGHTED) for (int k = lane; k < kScanTile; k += 64) T.lds[k] = 0;
   for (i64 s = s0; s < s1; ++s) {
     const i64 at = s * 64 * R;
     Tri t[R]; int w[R];
@@ -670,17 +713,18 @@ __global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ 
 #pragma unroll
       for (int r = 0; r < R; ++r) { t[r] = load_tri(p + 768 * r); w[r] = WEIGHTED ? weights[at + 64 * r + lane] : 1; }
 #pragma unroll
-      for (int r = 0; r < R; ++r) scan_add64<WEIGHTED>(t[r], w[r], true, a, lane);
+      for (int r = 0; r < R; ++r) scan_add64<WEIGHTED>(t[r], w[r], true, a, T, lane);
     } else {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const i64 i = at + 64 * r + lane;
         t[r].c = -1; t[r].s = 0; t[r].e = 0; w[r] = 1;
         if (i < n) { t[r] = reads[i]; if (WEIGHTED) w[r] = weights[i]; }
-        scan_add64<WEIGHTED>(t[r], w[r], i < n, a, lane);
+        scan_add64<WEIGHTED>(t[r], w[r], i < n, a, T, lane);
       }
     }
   }
+  scan_tile_flush(T, a, lane);
 }
 
 // Window sums: out[k] = sum_{j<comb} micro[k+j].  A block owns a tile of kWinTile consecutive windows
@@ -690,7 +734,8 @@ static constexpr int kWinPer = 8;
 static constexpr int kWinTile = 256 * kWinPer;
 static constexpr int kWinMaxComb = 2048;           // LDS: (kWinTile + kWinMaxComb) * 8 B = 32 KB
 
-__global__ __launch_bounds__(256) void scan_window_kernel(const u64 *__restrict__ micro, ScanArgs a, u64 *__restrict__ out)
+template <class MT>
+__global__ __launch_bounds__(256) void scan_window_kernel(const MT *__restrict__ micro, ScanArgs a, u64 *__restrict__ out)
 {
   __shared__ u64 lds[kWinTile + kWinMaxComb];
   // class of this tile (tileOff is a prefix over classes; few dozen entries)
@@ -700,7 +745,7 @@ __global__ __launch_bounds__(256) void scan_window_kernel(const u64 *__restrict_
   const i64 k0 = ((i64)blockIdx.x - a.tileOff[c]) * kWinTile;
   if (k0 >= nWin) return;
   const i64 cntWin = nWin - k0 < kWinTile ? nWin - k0 : kWinTile;
-  const u64 *src = micro + a.microOff[c] + k0;
+  const MT *src = micro + a.microOff[c] + k0;
   u64 *dst = out + a.outOff[c] + k0;
   if (a.comb == 1) {                               // windows == micro-windows: plain copy
     for (i64 i = threadIdx.x; i < cntWin; i += 256) dst[i] = src[i];
@@ -774,10 +819,11 @@ hipError_t launch_scan_hist(const void *reads, const void *weights, i64 n, const
 
 int scan_window_tile() { return kWinTile; }
 
-hipError_t launch_scan_windows(const u64 *micro, const ScanArgs &a, i64 totalTiles, u64 *out, hipStream_t st)
+hipError_t launch_scan_windows(const void *micro, bool micro64, const ScanArgs &a, i64 totalTiles, u64 *out, hipStream_t st)
 {
   if (totalTiles <= 0) return hipSuccess;
-  scan_window_kernel<<<(unsigned)totalTiles, 256, 0, st>>>(micro, a, out);
+  if (micro64) scan_window_kernel<u64><<<(unsigned)totalTiles, 256, 0, st>>>((const u64 *)micro, a, out);
+  else scan_window_kernel<unsigned><<<(unsigned)totalTiles, 256, 0, st>>>((const unsigned *)micro, a, out);
   return hipGetLastError();
 }
 
