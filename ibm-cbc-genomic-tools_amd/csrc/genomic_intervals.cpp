@@ -340,6 +340,21 @@ unsigned long int *GenomicRegionSetOverlaps::CountIndexOverlaps(bool match_gaps,
     fprintf(stderr, "[GenomicRegionSetOverlaps::CountIndexOverlaps]: index set must be loaded in memory for this operation!\n");
     exit(1);
   }
+  return Reduce(false, ignore_strand, max_label_value);
+}
+
+unsigned long int *GenomicRegionSetOverlaps::CalcIndexCoverage(bool match_gaps, bool ignore_strand, long int max_label_value)
+{
+  (void)match_gaps;   // single intervals: the envelope formula (:5278) and CalcOverlap (:1196-1202) coincide
+  if (IndexSet->load_in_memory == false) {
+    fprintf(stderr, "[GenomicRegionSetOverlaps::CalcIndexCoverage]: index set must be loaded in memory for this operation!\n");
+    exit(1);
+  }
+  return Reduce(true, ignore_strand, max_label_value);
+}
+
+unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool ignore_strand, long int max_label_value)
+{
   const long int M = IndexSet->n_regions;
   const bool sorted = UsesSortedMerge(), by_strand = SortedByStrand();
   for (long int k = 0; k < M; k++) IndexSet->R[k]->n_line = k;                       // :5309
@@ -384,8 +399,21 @@ unsigned long int *GenomicRegionSetOverlaps::CountIndexOverlaps(bool match_gaps,
   PackOptions opt;
   opt.mode = sorted ? gtxhost::PACK_OVERLAPS_SORTED : gtxhost::PACK_OVERLAPS_UNSORTED;
   opt.chroms = &chroms; opt.strand_aware = strand_aware; opt.sorted_by_strand = by_strand;
-  opt.max_label_value = max_label_value; opt.collect_zero_length = sorted && zero_length_refs;
+  opt.max_label_value = max_label_value; opt.collect_zero_length = !coverage && sorted && zero_length_refs;
   std::vector<int32_t> zero_len;
+  unsigned long int *hits = new unsigned long int[M > 0 ? M : 1];
+  gtx_count_info info;
+  if (coverage) {
+    // zero-length reads (sorted rules let them through) and zero-length regions contribute 0: the device leaves them out
+    CheckGtx(ctx, gtx_coverage_begin(ctx));
+    DrainSet(QuerySet, opt, [&](const PackedBatch &b) {
+      CheckGtx(ctx, gtx_coverage_add(ctx, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), 0));
+    });
+    Mark("queries packed and enqueued");
+    CheckGtx(ctx, gtx_coverage_end(ctx, (uint64_t *)hits, &info));
+    Mark("coverage on the host");
+    return hits;
+  }
   CheckGtx(ctx, gtx_count_begin(ctx));
   const uint32_t mode_flags = sorted ? GTX_ZERO_LENGTH_OK : 0;
   DrainSet(QuerySet, opt, [&](const PackedBatch &b) {
@@ -393,8 +421,6 @@ unsigned long int *GenomicRegionSetOverlaps::CountIndexOverlaps(bool match_gaps,
     CheckGtx(ctx, gtx_count_add(ctx, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), flags));
     zero_len.insert(zero_len.end(), b.zero_len.begin(), b.zero_len.end());
   });
-  unsigned long int *hits = new unsigned long int[M > 0 ? M : 1];
-  gtx_count_info info;
   Mark("queries packed and enqueued");
   CheckGtx(ctx, gtx_count_end(ctx, (uint64_t *)hits, &info));
   Mark("counts on the host");

@@ -119,12 +119,17 @@ class GenomicRegionSetOverlaps
   // a new[] array the caller releases (genomic_intervals.cpp:5304-5317).  Runs on the GPU.
   unsigned long int *CountIndexOverlaps(bool match_gaps, bool ignore_strand, long int max_label_value);
 
+  // coverage[k] = sum over query regions q overlapping index region k of w_q * overlap length
+  // (genomic_intervals.cpp:5269-5285); same ownership and device path as CountIndexOverlaps.
+  unsigned long int *CalcIndexCoverage(bool match_gaps, bool ignore_strand, long int max_label_value);
+
   GenomicRegionSet *QuerySet;
   GenomicRegionSet *IndexSet;
   GenomicRegion *current_qreg;
   GenomicRegion *current_ireg;
 
  protected:
+  unsigned long int *Reduce(bool coverage, bool ignore_strand, long int max_label_value);
   virtual bool UsesSortedMerge() const = 0;      // which reference algorithm's input rules apply
   virtual bool SortedByStrand() const { return false; }
 };

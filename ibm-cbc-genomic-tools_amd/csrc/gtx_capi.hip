@@ -31,6 +31,9 @@ struct gtx_ctx {
   int *d_posE = nullptr, *d_posS = nullptr, *d_classBase = nullptr;
   u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr, *d_prefA = nullptr, *d_prefB = nullptr;
   bool histDirty = false;              // a call was abandoned between begin and end
+  // coverage (allocated on first use): 8 histograms, 8 tile-sum arrays, 8 prefix arrays, region coordinates
+  u64 *d_cov[24] = {}; int *d_refS = nullptr, *d_refE = nullptr; bool covReady = false, covDirty = false, covOpen = false;
+  std::vector<int32_t> h_refS, h_refE;
   bool tileSumsValid = true;           // every kernel since the last finalize maintained the tile sums
   int64_t histLen = 0;
 
@@ -109,6 +112,8 @@ void gtx_destroy(gtx_ctx *c)
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   dfree(c->d_reads); dfree(c->d_weights); dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
+  for (auto &p : c->d_cov) dfree(p);
+  dfree(c->d_refS); dfree(c->d_refE);
   if (c->h_info) (void)hipHostFree(c->h_info);
   for (auto &slot : c->evRing) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
   delete c;
@@ -205,6 +210,10 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
     HIPCHK(c, hipMemcpy(c->d_posS, posS.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_classBase, classBase.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
   }
+  for (auto &p : c->d_cov) dfree(p);
+  dfree(c->d_refS); dfree(c->d_refE); c->covReady = false; c->covDirty = false;
+  c->h_refS.resize(m > 0 ? m : 1); c->h_refE.resize(m > 0 ? m : 1);
+  for (int64_t k = 0; k < m; k++) { c->h_refS[k] = tri[3 * k + 1]; c->h_refE[k] = tri[3 * k + 2]; }
   c->nRefs = m; c->nValid = nv; c->nClasses = nClasses; c->histLen = histLen;
   return GTX_OK;
 }
@@ -376,6 +385,143 @@ int gtx_count(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t 
   int rc = gtx_count_begin(c); if (rc) return rc;
   rc = gtx_count_add(c, reads, weights, n, flags); if (rc) { c->streamOpen = false; return rc; }
   return gtx_count_end(c, hits, info);
+}
+
+// ---------------------------------------------------------------------------------------------
+// coverage
+// ---------------------------------------------------------------------------------------------
+static int cover_prepare(gtx_ctx *c)
+{
+  if (c->covReady) return GTX_OK;
+  const int nTiles = gtx::scan_tiles(c->histLen);
+  for (int q = 0; q < 8; q++) {
+    HIPCHK(c, hipMalloc(&c->d_cov[q], sizeof(u64) * c->histLen));           // histograms
+    HIPCHK(c, hipMalloc(&c->d_cov[8 + q], sizeof(u64) * (nTiles + 2)));     // tile sums
+    HIPCHK(c, hipMalloc(&c->d_cov[16 + q], sizeof(u64) * c->histLen));      // prefixes
+    HIPCHK(c, hipMemset(c->d_cov[q], 0, sizeof(u64) * c->histLen));
+    HIPCHK(c, hipMemset(c->d_cov[8 + q], 0, sizeof(u64) * (nTiles + 2)));
+  }
+  HIPCHK(c, hipMalloc(&c->d_refS, sizeof(int32_t) * (c->nRefs + 1)));
+  HIPCHK(c, hipMalloc(&c->d_refE, sizeof(int32_t) * (c->nRefs + 1)));
+  if (c->nRefs > 0) {
+    HIPCHK(c, hipMemcpy(c->d_refS, c->h_refS.data(), sizeof(int32_t) * c->nRefs, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_refE, c->h_refE.data(), sizeof(int32_t) * c->nRefs, hipMemcpyHostToDevice));
+  }
+  c->covReady = true; c->covDirty = false;
+  return GTX_OK;
+}
+
+static gtx::CoverArgs cover_args(gtx_ctx *c, int64_t nReads)
+{
+  gtx::CoverArgs a;
+  a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart;
+  for (int q = 0; q < 8; q++) { a.hist[q] = c->d_cov[q]; a.part[q] = c->d_cov[8 + q]; }
+  a.info = c->d_info + c->infoCur; a.nClasses = c->nClasses;
+  int64_t nChunks = (nReads + 63) >> 6;
+  a.chunksPerWave = (int)std::min<int64_t>(128, std::max<int64_t>(8, nChunks / 16384));
+  return a;
+}
+
+static int cover_begin(gtx_ctx *c)
+{
+  int rc = cover_prepare(c); if (rc) return rc;
+  if (c->covDirty) {
+    const int nTiles = gtx::scan_tiles(c->histLen);
+    for (int q = 0; q < 8; q++) {
+      HIPCHK(c, hipMemsetAsync(c->d_cov[q], 0, sizeof(u64) * c->histLen, c->stream));
+      HIPCHK(c, hipMemsetAsync(c->d_cov[8 + q], 0, sizeof(u64) * (nTiles + 2), c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
+  }
+  c->covDirty = true;
+  return GTX_OK;
+}
+
+static int cover_end(gtx_ctx *c, void *d_cov_out)
+{
+  gtx::CoverGather g;
+  for (int q = 0; q < 8; q++) { g.pref[q] = c->d_cov[16 + q]; g.part[q] = c->d_cov[8 + q]; }
+  g.posE = c->d_posE; g.posS = c->d_posS; g.classBase = c->d_classBase; g.refS = c->d_refS; g.refE = c->d_refE;
+  HIPCHK(c, gtx::launch_coverage_finalize(cover_args(c, 0), c->histLen, g, c->nRefs, (u64 *)d_cov_out, c->d_info + (c->infoCur ^ 1), c->stream));
+  c->covDirty = false;
+  c->infoCur ^= 1;
+  return GTX_OK;
+}
+
+int gtx_coverage_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, void *d_cov)
+{
+  (void)flags;
+  if (!c) return GTX_E_ARG;
+  if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_coverage_device: gtx_set_refs has not been called");
+  if (n < 0 || (n > 0 && !d_reads) || (c->nRefs > 0 && !d_cov)) return fail(c, GTX_E_ARG, "gtx_coverage_device: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = cover_begin(c); if (rc) return rc;
+  if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
+  HIPCHK(c, gtx::launch_coverage(d_reads, d_weights, n, cover_args(c, n), c->stream));
+  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  rc = cover_end(c, d_cov); if (rc) return rc;
+  if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
+  return GTX_OK;
+}
+
+int gtx_coverage_begin(gtx_ctx *c)
+{
+  if (!c) return GTX_E_ARG;
+  if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_coverage_begin: gtx_set_refs has not been called");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = cover_begin(c); if (rc) return rc;
+  c->streamTotal = c->h_info[1]; c->streamSeen = 0; c->covOpen = true;
+  return GTX_OK;
+}
+
+int gtx_coverage_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, uint32_t flags)
+{
+  (void)flags;
+  if (!c) return GTX_E_ARG;
+  if (!c->covOpen) return fail(c, GTX_E_STATE, "gtx_coverage_add: gtx_coverage_begin has not been called");
+  if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_coverage_add: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t batch = 64ll << 20;
+  int rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
+  for (int64_t off = 0; off < n; off += batch) {
+    const int64_t cnt = std::min(batch, n - off);
+    HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
+    if (weights) HIPCHK(c, hipMemcpyAsync(c->d_weights, weights + off, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, gtx::launch_coverage(c->d_reads, weights ? c->d_weights : nullptr, cnt, cover_args(c, cnt), c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + c->infoCur, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const gtx::DevInfo &d = c->h_info[0];
+    gtx::DevInfo &t = c->streamTotal;
+    if (d.first_degenerate != INT64_MAX && t.first_degenerate == INT64_MAX) t.first_degenerate = d.first_degenerate + c->streamSeen + off;
+    t.n_no_class += d.n_no_class; t.n_degenerate += d.n_degenerate;
+  }
+  c->streamSeen += n;
+  return GTX_OK;
+}
+
+int gtx_coverage_end(gtx_ctx *c, uint64_t *cov, gtx_count_info *info)
+{
+  if (!c) return GTX_E_ARG;
+  if (!c->covOpen) return fail(c, GTX_E_STATE, "gtx_coverage_end: gtx_coverage_begin has not been called");
+  if (c->nRefs > 0 && !cov) return fail(c, GTX_E_ARG, "gtx_coverage_end: null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->covOpen = false;
+  int rc = ensure_out(c, (size_t)c->nRefs); if (rc) return rc;
+  rc = cover_end(c, c->d_out); if (rc) return rc;
+  if (c->nRefs > 0) HIPCHK(c, hipMemcpyAsync(cov, c->d_out, sizeof(u64) * c->nRefs, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (info) info_out(c->streamTotal, info, 0);
+  return GTX_OK;
+}
+
+int gtx_coverage(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, uint32_t flags, uint64_t *cov, gtx_count_info *info)
+{
+  if (!c) return GTX_E_ARG;
+  if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_coverage: bad argument");
+  int rc = gtx_coverage_begin(c); if (rc) return rc;
+  rc = gtx_coverage_add(c, reads, weights, n, flags); if (rc) { c->covOpen = false; return rc; }
+  return gtx_coverage_end(c, cov, info);
 }
 
 // ---------------------------------------------------------------------------------------------

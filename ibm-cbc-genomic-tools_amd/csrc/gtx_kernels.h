@@ -30,6 +30,22 @@ struct CountArgs {
   int zeroLenOk;                 // start == end+1 is a countable read (sorted-merge semantics)
 };
 
+// coverage: 8 histograms / tile-sum arrays in the order
+//   0 (E-array, key s, w)  1 (E-array, key s, w*s)  2 (E-array, key e, w)  3 (E-array, key e, w*e)
+//   4 (S-array, key s, w)  5 (S-array, key s, w*s)  6 (S-array, key e, w)  7 (S-array, key e, w*e)
+struct CoverArgs {
+  const int *sortedE, *sortedS, *segStart;
+  unsigned long long *hist[8], *part[8];
+  DevInfo *info;
+  int nClasses, chunksPerWave;
+};
+
+struct CoverGather {
+  unsigned long long *pref[8], *part[8];
+  const int *posE, *posS, *classBase;
+  const int *refS, *refE;        // region coordinates in FILE order
+};
+
 struct ScanArgs {
   unsigned long long *micro;     // micro-window histogram, all classes: uint64 when weighted, uint32 (same buffer) otherwise
   const long long *microOff;     // [nClasses] offset of class c in micro
@@ -55,6 +71,9 @@ hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB,
                            unsigned long long *prefA, unsigned long long *prefB,
                            const int *posE, const int *posS, const int *classBase, long long m,
                            unsigned long long *hits, DevInfo *nextInfo, hipStream_t st);
+hipError_t launch_coverage(const void *reads, const void *weights, long long n, const CoverArgs &a, hipStream_t st);
+hipError_t launch_coverage_finalize(const CoverArgs &a, long long histLen, const CoverGather &g, long long m,
+                                    unsigned long long *cov, DevInfo *nextInfo, hipStream_t st);
 hipError_t launch_scan_hist(const void *reads, const void *weights, long long n, const ScanArgs &a, hipStream_t st);
 int scan_window_tile();
 hipError_t launch_scan_windows(const void *micro, bool micro64, const ScanArgs &a, long long totalTiles,

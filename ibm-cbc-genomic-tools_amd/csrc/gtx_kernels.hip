@@ -68,12 +68,16 @@ __device__ __forceinline__ i64 wave_sum(i64 v)
 // ---------------------------------------------------------------------------------------------
 struct Seg { int start, end, cls; };            // class segment [start,end) of both boundary arrays
 
-template <bool WEIGHTED, bool STRICT>
+template <bool WEIGHTED, bool STRICT, bool SUMKEY = false>
 struct Win {
-  typedef typename std::conditional<WEIGHTED, i64, unsigned>::type acc_t;
+  // SUMKEY (coverage): besides the weight of the keys that fall into a slot, the sum of weight x key
+  // is kept in a second histogram (hist2 / part2 / acc2 / pend2)
+  typedef typename std::conditional<WEIGHTED || SUMKEY, i64, unsigned>::type acc_t;
   const int *arr;       // sorted boundaries of all classes
   u64 *hist;            // rank histogram, index = rank + class id
   u64 *part;            // per-tile (kTile slots) sums of hist, kept up to date for the finalize scan
+  u64 *hist2, *part2;   // SUMKEY only
+  i64 acc2, pend2;      // SUMKEY only
   int base;             // global rank of slot 0
   int j;                // current slot 0..62
   int prevW, curW;      // arr[base+j-1], arr[base+j]
@@ -97,6 +101,7 @@ struct Win {
   __device__ __forceinline__ void deposit(int lane)
   {
     if (pend != 0) { if (lane == j + 1) acc += pend; pend = 0; }
+    if (SUMKEY) { if (pend2 != 0) { if (lane == j + 1) acc2 += pend2; pend2 = 0; } }
   }
 
   // publish the window's accumulators: one contiguous 64-lane atomic add into the histogram, and
@@ -110,18 +115,24 @@ struct Win {
     const i64 s0 = wave_sum(tile == t0 ? (i64)acc : 0), s1 = wave_sum(tile != t0 ? (i64)acc : 0);
     if (lane == 0) { if (s0 != 0) atomicAdd(&part[t0], (u64)s0); if (s1 != 0) atomicAdd(&part[t0 + 1], (u64)s1); }
     acc = 0;
+    if (SUMKEY) {
+      if (acc2 != 0) atomicAdd(&hist2[idx], (u64)acc2);
+      const i64 q0 = wave_sum(tile == t0 ? acc2 : 0), q1 = wave_sum(tile != t0 ? acc2 : 0);
+      if (lane == 0) { if (q0 != 0) atomicAdd(&part2[t0], (u64)q0); if (q1 != 0) atomicAdd(&part2[t0 + 1], (u64)q1); }
+      acc2 = 0;
+    }
   }
 
   __device__ __forceinline__ void flush(const Seg &sg, int lane)
   {
     deposit(lane);
-    if (__ballot(acc != 0)) flush_acc(sg, lane);
+    if (__ballot(acc != 0 || (SUMKEY && acc2 != 0))) flush_acc(sg, lane);
   }
 
   // position slot 0 at rank p (the caller has flushed)
   __device__ __forceinline__ void place(const Seg &sg, int p, int lane)
   {
-    base = p; j = 0; pend = 0; acc = 0;
+    base = p; j = 0; pend = 0; acc = 0; acc2 = 0; pend2 = 0;
     W = load_window(sg, base, lane);
     Wn = load_window(sg, base + kSlots, lane);
     prevW = rdlane(W, 0); curW = rdlane(W, 1);
@@ -183,6 +194,7 @@ struct Win {
     const i64 idx = (i64)lo + sg.cls;
     atomicAdd(&hist[idx], (u64)w);
     atomicAdd(&part[idx >> kTileShift], (u64)w);
+    if (SUMKEY) { atomicAdd(&hist2[idx], (u64)(w * key)); atomicAdd(&part2[idx >> kTileShift], (u64)(w * key)); }
   }
 
   // Add the lanes of m (keys `key`, weights `w`) to the histogram; returns the lanes it left
@@ -204,6 +216,7 @@ struct Win {
       if (fresh) {
         if (WEIGHTED) pend += (acc_t)wave_sum(((fresh >> lane) & 1) ? (i64)w : 0);
         else pend += (acc_t)__popcll(fresh);
+        if (SUMKEY) pend2 += wave_sum(((fresh >> lane) & 1) ? (i64)w * key : 0);
       }
       done = le;
       if (le == m) return 0;
@@ -493,6 +506,96 @@ __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Coverage (GenomicRegionSetOverlaps::CalcIndexCoverage, genomic_intervals.cpp:5269-5285):
+//   cov[k] = sum over reads q overlapping k of w_q * (min(e_q,E_k) - max(s_q,S_k) + 1)
+// With Ws(x) = sum w[s<=x], We(x) = sum w[e<=x], Fs(x) = sum w*s[s<=x], Fe(x) = sum w*e[e<=x] (valid reads,
+// s <= e) the overlapping reads split by where their ends lie, and
+//   cov[k] = Fe(E) - Fe(S-1) + E*(Ws(E) - We(E))  -  Fs(E) + Fs(S-1) - S*(Ws(S-1) - We(S-1))  +  Ws(E) - We(S-1)
+// (all in wrap-around 64-bit arithmetic, like the reference's unsigned long).  So the same streaming pass
+// walks four windows -- (ends array, key s), (ends array, key e), (starts array, key s), (starts array,
+// key e) -- each with a weight histogram and a weight x key histogram.  Zero-length reads and regions
+// always contribute 0 and are left out.  This kernel is the general per-chunk form (no hand-tuned fast
+// path yet): correctness first for this "next" row.
+// ---------------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CoverArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + rfl(threadIdx.x >> 6);
+  const i64 first = wave * (i64)a.chunksPerWave * 64;
+  if (first >= n) return;
+  i64 cnt = n - first; if (cnt > (i64)a.chunksPerWave * 64) cnt = (i64)a.chunksPerWave * 64;
+  const int nMine = (int)cnt;
+
+  Win<WEIGHTED, false, true> As, Ae;          // ends array:   #{E_j <  key}
+  Win<WEIGHTED, true, true> Bs, Be;           // starts array: #{S_j <= key}
+  As.arr = Ae.arr = a.sortedE; Bs.arr = Be.arr = a.sortedS;
+  As.hist = a.hist[0]; As.hist2 = a.hist[1]; As.part = a.part[0]; As.part2 = a.part[1];
+  Ae.hist = a.hist[2]; Ae.hist2 = a.hist[3]; Ae.part = a.part[2]; Ae.part2 = a.part[3];
+  Bs.hist = a.hist[4]; Bs.hist2 = a.hist[5]; Bs.part = a.part[4]; Bs.part2 = a.part[5];
+  Be.hist = a.hist[6]; Be.hist2 = a.hist[7]; Be.part = a.part[6]; Be.part2 = a.part[7];
+  As.acc = Ae.acc = Bs.acc = Be.acc = 0; As.acc2 = Ae.acc2 = Bs.acc2 = Be.acc2 = 0;
+  As.pend = Ae.pend = Bs.pend = Be.pend = 0; As.pend2 = Ae.pend2 = Bs.pend2 = Be.pend2 = 0;
+  As.j = Ae.j = Bs.j = Be.j = 0; As.base = Ae.base = Bs.base = Be.base = 0;
+  As.W = As.Wn = Ae.W = Ae.Wn = Bs.W = Bs.Wn = Be.W = Be.Wn = kHi;
+  As.prevW = Ae.prevW = Bs.prevW = Be.prevW = kLo; As.curW = Ae.curW = Bs.curW = Be.curW = kHi;
+  bool vAs = false, vAe = false, vBs = false, vBe = false;
+  Seg sg; sg.start = 0; sg.end = 0; sg.cls = -1;
+  int nNoClass = 0, nDegen = 0; i64 firstDegen = INT64_MAX;
+
+  for (int at = 0; at < nMine; at += 64) {
+    const int left = nMine - at;
+    const u64 active = left >= 64 ? ~0ull : ((1ull << left) - 1);
+    Tri t; t.c = -1; t.s = 0; t.e = 0; int w = 1;
+    if (lane < left) { t = reads[first + at + lane]; if (WEIGHTED) w = weights[first + at + lane]; }
+    const int c0 = rdlane(t.c, 0);
+    if (c0 != sg.cls && (unsigned)c0 < (unsigned)a.nClasses) {
+      if (vAs) As.flush(sg, lane);
+      if (vAe) Ae.flush(sg, lane);
+      if (vBs) Bs.flush(sg, lane);
+      if (vBe) Be.flush(sg, lane);
+      vAs = vAe = vBs = vBe = false;
+      sg.start = rfl(a.segStart[c0]); sg.end = rfl(a.segStart[c0 + 1]); sg.cls = c0;
+    }
+    const u64 noclass = __ballot((unsigned)t.c >= (unsigned)a.nClasses) & active;
+    const u64 degen = __ballot(t.s > t.e) & active & ~noclass;        // zero-length or inverted: contributes nothing
+    const u64 mine = __ballot(t.c == sg.cls) & active & ~degen & ~noclass;
+    const u64 other = active & ~mine & ~degen & ~noclass;
+    if (degen | noclass) {
+      nNoClass += __popcll(noclass);
+      const u64 inv = __ballot(t.s > t.e + 1) & degen;                // only these are reported (the packer's business)
+      if (inv) { nDegen += __popcll(inv); i64 p = first + at + (__ffsll((unsigned long long)inv) - 1); if (p < firstDegen) firstDegen = p; }
+    }
+    if (mine && sg.start != sg.end) {
+      u64 r0 = As.walk(sg, t.s, w, mine, lane, vAs);
+      u64 r1 = Ae.walk(sg, t.e, w, mine, lane, vAe);
+      u64 r2 = Bs.walk(sg, t.s, w, mine, lane, vBs);
+      u64 r3 = Be.walk(sg, t.e, w, mine, lane, vBe);
+      if (r0 | r1 | r2 | r3) {
+        if ((r0 >> lane) & 1) As.lane_add(sg, t.s, w);
+        if ((r1 >> lane) & 1) Ae.lane_add(sg, t.e, w);
+        if ((r2 >> lane) & 1) Bs.lane_add(sg, t.s, w);
+        if ((r3 >> lane) & 1) Be.lane_add(sg, t.e, w);
+      }
+    }
+    if (other) {
+      if ((other >> lane) & 1) {
+        Seg so; so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c;
+        if (so.start != so.end) { As.lane_add(so, t.s, w); Ae.lane_add(so, t.e, w); Bs.lane_add(so, t.s, w); Be.lane_add(so, t.e, w); }
+      }
+    }
+  }
+  if (vAs) As.flush(sg, lane);
+  if (vAe) Ae.flush(sg, lane);
+  if (vBs) Bs.flush(sg, lane);
+  if (vBe) Be.flush(sg, lane);
+  if (lane == 0) {
+    if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
+    if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Order-agnostic count kernel ("search"): every read does two binary searches in the (L2 /
 // Infinity-Cache resident) boundary arrays.  Used when the caller does not claim sorted reads.
 // ---------------------------------------------------------------------------------------------
@@ -606,6 +709,29 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict_
     h = (pa[pe] - ba) - (pb[posS[k]] - bb);
   }
   hits[k] = h;
+}
+
+__global__ __launch_bounds__(256) void gather_coverage_kernel(CoverGather g, i64 m, u64 *__restrict__ cov, int nTiles, DevInfo *nextInfo)
+{
+  i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nTiles) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) g.part[q][k] = 0;
+  }
+  if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; }
+  if (k >= m) return;
+  const int pe = g.posE[k];
+  u64 c = 0;
+  if (pe >= 0 && g.refE[k] >= g.refS[k]) {          // zero-length regions: coverage 0
+    const int ps = g.posS[k], cb = g.classBase[k];
+    u64 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const u64 *p = g.pref[q]; v[q] = p[q < 4 ? pe : ps] - (cb >= 0 ? p[cb] : 0); }
+    // v: 0 Ws(E) 1 Fs(E) 2 We(E) 3 Fe(E) 4 Ws(S-1) 5 Fs(S-1) 6 We(S-1) 7 Fe(S-1)
+    const u64 E = (u64)(i64)g.refE[k], S = (u64)(i64)g.refS[k];
+    c = v[3] - v[7] + E * (v[0] - v[2]) - v[1] + v[5] - S * (v[4] - v[6]) + v[0] - v[6];
+  }
+  cov[k] = c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -805,6 +931,27 @@ hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 
   }
   const i64 work = (m > nb ? m : nb) > 0 ? (m > nb ? m : nb) : 1;
   gather_hits_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(prefA, prefB, posE, posS, classBase, m, hits, tileA, tileB, nb, nextInfo);
+  return hipGetLastError();
+}
+
+hipError_t launch_coverage(const void *reads, const void *weights, i64 n, const CoverArgs &a, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  const i64 nChunks = (n + 63) >> 6;
+  const i64 waves = (nChunks + a.chunksPerWave - 1) / a.chunksPerWave;
+  const unsigned grid = (unsigned)((waves + 3) / 4);
+  if (weights) coverage_walk_kernel<true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  else coverage_walk_kernel<false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_coverage_finalize(const CoverArgs &a, i64 histLen, const CoverGather &g, i64 m, u64 *cov, DevInfo *nextInfo, hipStream_t st)
+{
+  const int nb = scan_tiles(histLen);
+  for (int q = 0; q < 8 && nb > 0; q += 2)
+    finalize_scan_kernel<<<nb, 256, 0, st>>>(a.hist[q], a.hist[q + 1], histLen, a.part[q], a.part[q + 1], g.pref[q], g.pref[q + 1]);
+  const i64 work = (m > nb ? m : nb) > 0 ? (m > nb ? m : nb) : 1;
+  gather_coverage_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(g, m, cov, nb, nextInfo);
   return hipGetLastError();
 }
 

@@ -51,6 +51,13 @@ ABI = {
     "gtx_count_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32,
                                         ctypes.c_void_p]),
     "gtx_last_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_coverage_begin": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_coverage_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]),
+    "gtx_coverage_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_coverage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32,
+                                    ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_coverage_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32,
+                                           ctypes.c_void_p]),
     "gtx_scan_n_windows": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
     "gtx_scan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32,
@@ -169,6 +176,17 @@ class Engine:
     def count_device(self, d_reads, n_reads, d_hits, d_weights=None, flags=READS_SORTED):
         """reads/weights/hits are raw device addresses (e.g. torch tensor .data_ptr()); asynchronous."""
         self._chk(self.lib.gtx_count_device(self.ctx, _ptr(d_reads), _ptr(d_weights), int(n_reads), int(flags), _ptr(d_hits)))
+
+    def coverage(self, reads, weights=None, flags=READS_SORTED):
+        reads = _triples(reads)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.int32)
+        cov = np.zeros(max(self.n_refs, 1), dtype=np.uint64)
+        info = CountInfo()
+        self._chk(self.lib.gtx_coverage(self.ctx, _ptr(reads), _ptr(w), reads.shape[0], int(flags), _ptr(cov), ctypes.byref(info)))
+        return cov[:self.n_refs], info.as_dict()
+
+    def coverage_device(self, d_reads, n_reads, d_cov, d_weights=None, flags=READS_SORTED):
+        self._chk(self.lib.gtx_coverage_device(self.ctx, _ptr(d_reads), _ptr(d_weights), int(n_reads), int(flags), _ptr(d_cov)))
 
     def last_info(self):
         info = CountInfo()

@@ -132,6 +132,22 @@ int gtx_count_device(gtx_ctx *ctx, const void *d_read_triples, const void *d_wei
 /* Result of the most recent *_device call (synchronises the stream). */
 int gtx_last_info(gtx_ctx *ctx, gtx_count_info *info);
 
+/* ---- genomic_overlaps coverage / density ------------------------------------------------- */
+
+/* Replaces GenomicRegionSetOverlaps::CalcIndexCoverage (genomic_intervals.cpp:5269-5285, decl
+ * genomic_intervals.h:2455) for single-interval regions:
+ *     cov[k] = sum over reads q overlapping reference k of w_q * (min(e_q,E_k) - max(s_q,S_k) + 1)
+ * in FILE order, 64-bit wrap-around arithmetic.  Same calling pattern as the count entry points; the
+ * reference set is the one given to gtx_set_refs[_ex].  Reads and regions of zero length contribute 0
+ * (both CalcOverlap and the -gaps formula yield 0 for them). */
+int gtx_coverage_begin(gtx_ctx *ctx);
+int gtx_coverage_add(gtx_ctx *ctx, const int32_t *read_triples, const int32_t *weights, int64_t n_reads, uint32_t flags);
+int gtx_coverage_end(gtx_ctx *ctx, uint64_t *cov_out /* n_refs */, gtx_count_info *info /* may be NULL */);
+int gtx_coverage(gtx_ctx *ctx, const int32_t *read_triples, const int32_t *weights, int64_t n_reads,
+                 uint32_t flags, uint64_t *cov_out /* n_refs */, gtx_count_info *info /* may be NULL */);
+int gtx_coverage_device(gtx_ctx *ctx, const void *d_read_triples, const void *d_weights, int64_t n_reads,
+                        uint32_t flags, void *d_cov_out);
+
 /* ---- genomic_scans counts --------------------------------------------------------------- */
 
 /* Number of sliding windows the scanners report for a chromosome of length `len`

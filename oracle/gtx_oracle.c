@@ -275,6 +275,36 @@ static int region_is_before(const orc_chroms *c, const orc_region *a, const orc_
   return front_start(a) < front_start(b);
 }
 
+/* genomic_intervals.cpp:427-432 + 1196-1202: sum over interval pairs of max(0, min(stops)-max(starts)+1),
+ * 0 for a pair on different chromosomes / (unless ignored) strands */
+static long region_calc_overlap(const orc_chroms *c, const orc_region *a, const orc_region *b, int ignore_strand)
+{
+  if (chrom_cmp(c, a->chrom, b->chrom)) return 0;
+  if (!ignore_strand && a->strand != b->strand) return 0;
+  const long *x = RIV(a), *y = RIV(b);
+  long tot = 0;
+  for (int i = 0; i < a->n_iv; i++)
+    for (int j = 0; j < b->n_iv; j++) {
+      long lo = x[2 * i] > y[2 * j] ? x[2 * i] : y[2 * j], hi = x[2 * i + 1] < y[2 * j + 1] ? x[2 * i + 1] : y[2 * j + 1];
+      if (hi - lo + 1 > 0) tot += hi - lo + 1;
+    }
+  return tot;
+}
+
+/* what one overlapping (query, index) pair adds: its label value for `count` (genomic_intervals.cpp:5312),
+ * overlap length x label value for `coverage` (:5278-5280) */
+static uint64_t pair_value(const orc_chroms *c, const orc_region *q, const orc_region *r, int coverage, int match_gaps, int ignore_strand, long w)
+{
+  if (!coverage) return (uint64_t)w;
+  long cc;
+  if (match_gaps) {
+    long lo = front_start(q) > front_start(r) ? front_start(q) : front_start(r), hi = back_stop(q) < back_stop(r) ? back_stop(q) : back_stop(r);
+    cc = hi - lo + 1;
+  } else cc = region_calc_overlap(c, r, q, ignore_strand);
+  cc *= w;
+  return (uint64_t)cc;
+}
+
 /* genomic_intervals.cpp:5224-5248: filter applied to every candidate */
 static int accept_overlap(const orc_chroms *c, const orc_region *q, const orc_region *r, int match_gaps, int ignore_strand)
 {
@@ -426,7 +456,7 @@ static int binindex_build(const orc_chroms *chroms, const orc_set *set, const ch
 /* CountIndexOverlaps over the bin index: genomic_intervals.cpp:5304-5317 driving
  * GetQuery/NextQuery (:5693-5711), GetMatch/NextMatch (:5717-5764), GetOverlap (:5224-5248) */
 static int count_with_binindex(orc_chroms *chroms, const orc_set *set, const orc_binindex *bx, orc_source *src,
-                               int match_gaps, int ignore_strand, long max_label_value, uint64_t *hits)
+                               int match_gaps, int ignore_strand, long max_label_value, uint64_t *hits, int coverage)
 {
   for (long k = 0; k < set->n; k++) hits[k] = 0;
   orc_region q;
@@ -452,7 +482,7 @@ static int count_with_binindex(orc_chroms *chroms, const orc_set *set, const orc
               for (long z = bx->head[q.chrom][l][b]; z != -1; z = bx->next[z]) {
                 const orc_region *r = &set->R[z];
                 if (s <= back_stop(r) && e >= front_start(r) && accept_overlap(chroms, &q, r, match_gaps, ignore_strand))
-                  hits[z] += (uint64_t)w;                                         /* :5312 */
+                  hits[z] += pair_value(chroms, &q, r, coverage, match_gaps, ignore_strand, w);   /* :5312 / :5280 */
               }
           }
         }
@@ -468,7 +498,7 @@ static int count_with_binindex(orc_chroms *chroms, const orc_set *set, const orc
 /* sorted merge -- SortedGenomicRegionSetOverlaps, genomic_intervals.cpp:5807-5937             */
 /* ------------------------------------------------------------------------------------------ */
 static int count_with_merge(orc_chroms *chroms, const orc_set *set, orc_source *src, int by_strand,
-                            int match_gaps, int ignore_strand, long max_label_value, uint64_t *hits)
+                            int match_gaps, int ignore_strand, long max_label_value, uint64_t *hits, int coverage)
 {
   for (long k = 0; k < set->n; k++) hits[k] = 0;
   long *buf = xmalloc(sizeof(long) * (set->n + 1)); long nbuf = 0;               /* IRegBuffer, as index numbers */
@@ -508,7 +538,7 @@ static int count_with_merge(orc_chroms *chroms, const orc_set *set, orc_source *
       int d = region_direction(chroms, &q, r->chrom, r->strand, front_start(r), back_stop(r), by_strand);
       if (d > 0) { memmove(buf + j, buf + j + 1, sizeof(long) * (nbuf - j - 1)); nbuf--; continue; }   /* erase, stay */
       if (d < 0) break;
-      if (accept_overlap(chroms, &q, r, match_gaps, ignore_strand)) hits[buf[j]] += (uint64_t)w;
+      if (accept_overlap(chroms, &q, r, match_gaps, ignore_strand)) hits[buf[j]] += pair_value(chroms, &q, r, coverage, match_gaps, ignore_strand, w);
       j++;
     }
     if (have_prev) region_free(&prev);
@@ -657,8 +687,25 @@ static void set_from_packed(const int32_t *tri, int64_t m, orc_set *set)
 /* algo: 0 = bin index (genomic_overlaps count, default), 1 = sorted merge (-S).
  * weights may be NULL (every read counts 1); otherwise w_q = min(max_label_value, weights[q])
  * unless max_label_value <= 1 (then 1), as GetLabelValue does. */
+static int reduce_packed(const int32_t *refs, int64_t m, const int32_t *reads, const int32_t *weights, int64_t n,
+                         int algo, long max_label_value, uint64_t *hits, int coverage);
+
 int orc_count_packed(const int32_t *refs, int64_t m, const int32_t *reads, const int32_t *weights, int64_t n,
                      int algo, long max_label_value, uint64_t *hits)
+{
+  return reduce_packed(refs, m, reads, weights, n, algo, max_label_value, hits, 0);
+}
+
+/* CalcIndexCoverage (genomic_intervals.cpp:5269-5285) on packed triples: sum over overlapping reads of
+ * overlap length x label value */
+int orc_coverage_packed(const int32_t *refs, int64_t m, const int32_t *reads, const int32_t *weights, int64_t n,
+                        int algo, long max_label_value, uint64_t *cov)
+{
+  return reduce_packed(refs, m, reads, weights, n, algo, max_label_value, cov, 1);
+}
+
+static int reduce_packed(const int32_t *refs, int64_t m, const int32_t *reads, const int32_t *weights, int64_t n,
+                         int algo, long max_label_value, uint64_t *hits, int coverage)
 {
   g_failed = 0; g_err[0] = 0;
   orc_chroms ch; memset(&ch, 0, sizeof ch); ch.packed = 1;
@@ -669,9 +716,9 @@ int orc_count_packed(const int32_t *refs, int64_t m, const int32_t *reads, const
   if (algo == 0) {
     orc_binindex bx;
     rc = binindex_build(&ch, &set, NULL, &bx);
-    if (!rc) rc = count_with_binindex(&ch, &set, &bx, &src, 0, 1, mlv, hits);
+    if (!rc) rc = count_with_binindex(&ch, &set, &bx, &src, 0, 1, mlv, hits, coverage);
     binindex_free(&bx);
-  } else rc = count_with_merge(&ch, &set, &src, 0, 0, 1, mlv, hits);
+  } else rc = count_with_merge(&ch, &set, &src, 0, 0, 1, mlv, hits, coverage);
   free(set.R);
   return rc;
 }
@@ -722,8 +769,9 @@ int orc_scan_packed(const int32_t *reads, const int32_t *weights, int64_t n, con
 
 /* ------------------------------------------------------------------------------------------ */
 /* CLI: same operations, options and output format as the reference drivers                   */
-/*   gtx_oracle count|rpkm [-S] [-s] [-i] [-gaps] [-B bits] [--max-label-value V] [-min m] REF [READS]   */
-/*        genomic_overlaps.cpp:185-249 (options), :408-431 (count), :746-775 (rpkm)            */
+/*   gtx_oracle count|rpkm|coverage|density [-S] [-s] [-i] [-gaps] [-B bits] [--max-label-value V] [-min m] REF [READS] */
+/*        genomic_overlaps.cpp:185-249 (options), :408-431 (count), :438-459 (coverage), :466-490 (density),     */
+/*        :746-775 (rpkm)                                                                      */
 /*   gtx_oracle counts -g GENOME [-S] [-i] [-op 1|c] [-w W] [-d D] [-min m] [--max-label-value V] [READS] */
 /*        genomic_scans.cpp:108-121 (options), :399-436 (RunCounts)                            */
 /* ------------------------------------------------------------------------------------------ */
@@ -744,7 +792,9 @@ int main(int argc, char **argv)
   int sorted = 0, by_strand = 0, ign = 0, gaps = 0; long mlv = 1; const char *bits = "17,20,23,26";
   unsigned long min_count = 0; long min_reads = 10, win = 500, dist = 25; char prep = '1'; const char *genome = "";
   int is_scan = !strcmp(op, "counts");
-  if (strcmp(op, "count") && strcmp(op, "rpkm") && !is_scan) { fprintf(stderr, "Unknown operation '%s'!\n", op); return 1; }
+  int is_cov = !strcmp(op, "coverage") || !strcmp(op, "density");
+  double min_density = 0.0;
+  if (strcmp(op, "count") && strcmp(op, "rpkm") && !is_cov && !is_scan) { fprintf(stderr, "Unknown operation '%s'!\n", op); return 1; }
   int a = 2;
   for (; a < argc && argv[a][0] == '-'; a++) {                                     /* core.cpp:2420-2436 */
     const char *o = argv[a];
@@ -756,7 +806,7 @@ int main(int argc, char **argv)
     else if (!is_scan && !strcmp(o, "-gaps")) gaps = 1;
     else if (!is_scan && !strcmp(o, "-B")) { NEEDVAL(); bits = argv[++a]; }
     else if (!strcmp(o, "--max-label-value")) { NEEDVAL(); mlv = atol(argv[++a]); }
-    else if (!strcmp(o, "-min")) { NEEDVAL(); ++a; if (is_scan) min_reads = atol(argv[a]); else if (!strcmp(op, "count")) min_count = strtoul(argv[a], NULL, 10); }
+    else if (!strcmp(o, "-min")) { NEEDVAL(); ++a; if (is_scan) min_reads = atol(argv[a]); else if (!strcmp(op, "count") || !strcmp(op, "coverage")) min_count = strtoul(argv[a], NULL, 10); else if (!strcmp(op, "density")) min_density = atof(argv[a]); }
     else if (is_scan && !strcmp(o, "-g")) { NEEDVAL(); genome = argv[++a]; }
     else if (is_scan && !strcmp(o, "-w")) { NEEDVAL(); win = atol(argv[++a]); }
     else if (is_scan && !strcmp(o, "-d")) { NEEDVAL(); dist = atol(argv[++a]); }
@@ -775,10 +825,19 @@ int main(int argc, char **argv)
     orc_source src; memset(&src, 0, sizeof src); src.chroms = &ch; src.rd = &rd;
     uint64_t *hits = xmalloc(sizeof(uint64_t) * (ref.n + 1));
     int rc;
-    if (sorted) rc = count_with_merge(&ch, &ref, &src, by_strand, gaps, ign, mlv, hits);
-    else { orc_binindex bx; rc = binindex_build(&ch, &ref, bits, &bx); if (!rc) rc = count_with_binindex(&ch, &ref, &bx, &src, gaps, ign, mlv, hits); }
+    if (sorted) rc = count_with_merge(&ch, &ref, &src, by_strand, gaps, ign, mlv, hits, is_cov);
+    else { orc_binindex bx; rc = binindex_build(&ch, &ref, bits, &bx); if (!rc) rc = count_with_binindex(&ch, &ref, &bx, &src, gaps, ign, mlv, hits, is_cov); }
     if (rc) die();
-    if (!strcmp(op, "count")) {
+    if (!strcmp(op, "density")) {                                                  /* genomic_overlaps.cpp:477-486 */
+      for (long k = 0; k < ref.n; k++) {
+        const orc_region *r = &ref.R[k];
+        long size;
+        if (!gaps) { size = 0; const long *iv = RIV(r); for (int i = 0; i < r->n_iv; i++) size += iv[2 * i + 1] - iv[2 * i] + 1; }
+        else size = back_stop(r) - front_start(r) + 1;
+        volatile double den = (double)hits[k] / size;
+        if (den >= min_density) printf("%s\t%.4e\n", r->label, den);
+      }
+    } else if (!strcmp(op, "count") || !strcmp(op, "coverage")) {
       for (long k = 0; k < ref.n; k++) if (hits[k] >= min_count) printf("%s\t%lu\n", ref.R[k].label, (unsigned long)hits[k]);
     } else {                                                                       /* rpkm :757-772; its -min is parsed but never applied */
       unsigned long total = 0; for (long k = 0; k < ref.n; k++) total += hits[k];

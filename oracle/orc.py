@@ -31,6 +31,8 @@ def lib():
         L.orc_count_packed.restype = ctypes.c_int
         L.orc_count_packed.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                        ctypes.c_int, ctypes.c_long, ctypes.c_void_p]
+        L.orc_coverage_packed.restype = ctypes.c_int
+        L.orc_coverage_packed.argtypes = L.orc_count_packed.argtypes
         L.orc_scan_packed.restype = ctypes.c_int
         L.orc_scan_packed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_int, ctypes.c_long,
@@ -58,6 +60,17 @@ def count(refs, reads, weights=None, algo=BIN_INDEX, max_label_value=1 << 40):
     if rc:
         raise OracleError(lib().orc_last_error().decode())
     return hits[:len(refs)]
+
+
+def coverage(refs, reads, weights=None, algo=BIN_INDEX, max_label_value=1 << 40):
+    refs = np.ascontiguousarray(refs, dtype=np.int32)
+    reads = np.ascontiguousarray(reads, dtype=np.int32)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.int32)
+    cov = np.zeros(max(len(refs), 1), dtype=np.uint64)
+    rc = lib().orc_coverage_packed(_p(refs), len(refs), _p(reads), _p(w), len(reads), algo, max_label_value, _p(cov))
+    if rc:
+        raise OracleError(lib().orc_last_error().decode())
+    return cov[:len(refs)]
 
 
 def scan(reads, class_len, win_step, win_size, preprocess="1", weights=None, algo=0, max_label_value=1 << 40):

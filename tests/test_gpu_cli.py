@@ -102,6 +102,14 @@ OVERLAP_RUNS = [
     (["rpkm", "-i", "refs.bed", "reads_pos.bed"]),
     (["rpkm", "-S", "refs.bed", "reads_pos.bed"]),
     (["count", "-S", "-i", "refs.bed", "reads_shuffled.bed.gz"]),       # not sorted -> the reference's error
+    (["coverage", "-i", "refs.bed", "reads_pos.bed"]),
+    (["coverage", "refs.bed", "reads_pos.bed"]),
+    (["coverage", "-S", "-i", "-min", "200", "refs.bed", "reads_pos.bed"]),
+    (["coverage", "-S", "-s", "refs_strand.bed", "reads_strand.bed"]),
+    (["coverage", "-i", "--max-label-value", "4", "refs.bed", "reads_shuffled.bed.gz"]),
+    (["coverage", "-i", "-gaps", "refs.bed", "reads_pos.bed"]),
+    (["density", "-i", "refs.bed", "reads_pos.bed"]),
+    (["density", "-S", "-min", "0.05", "refs.bed", "reads_pos.bed"]),
 ]
 
 
@@ -230,7 +238,7 @@ def test_ingest_errors_match_reference_text(tmp_path, reads, frag):
 
 def test_no_gpu_free_paths_fail_loudly(tmp_path):
     (tmp_path / "refs.bed").write_text("chr1\t0\t1000\tA\t0\t+\n")
-    rc, out, err = product("overlaps", ["coverage", "refs.bed"], cwd=tmp_path)
+    rc, out, err = product("overlaps", ["subset", "refs.bed"], cwd=tmp_path)
     assert rc == 1 and "outside the MI355X" in err
     rc, out, err = product("overlaps", ["frobnicate", "refs.bed"], cwd=tmp_path)
     assert rc == 1 and "Unknown operation" in err
