@@ -60,6 +60,7 @@ struct gtx_ctx {
   // streaming count (begin/add/end)
   bool streamOpen = false; int64_t streamSeen = 0; gtx::DevInfo streamTotal; int32_t streamLast[2] = {0, 0};
 
+  int64_t batchReads = 64ll << 20;      // reads per device batch of the host-buffer entry points (768 MiB of triples)
   int chunksPerWave = 0;                // 0 = choose per call from the number of reads
   int prefetch = 4;                     // reads per lane per step (R) of the streaming kernel
 };
@@ -100,6 +101,8 @@ gtx_ctx *gtx_create(int device_id)
   for (auto &slot : c->evRing) for (auto &ev : slot) if (hipEventCreate(&ev) != hipSuccess) { g_create_error = "gtx_create: hipEventCreate failed"; delete c; return nullptr; }
   const char *cpw = getenv("GTX_CHUNKS_PER_WAVE");
   if (cpw && atoi(cpw) > 0) c->chunksPerWave = atoi(cpw);
+  const char *br = getenv("GTX_BATCH_READS");
+  if (br && atoll(br) > 0) c->batchReads = atoll(br);
   const char *pf = getenv("GTX_PREFETCH");
   if (pf && atoi(pf) > 0) c->prefetch = atoi(pf);
   return c;
@@ -332,7 +335,7 @@ int gtx_count_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int6
   if (!c->streamOpen) return fail(c, GTX_E_STATE, "gtx_count_add: gtx_count_begin has not been called");
   if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_count_add: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
-  const int64_t batch = 64ll << 20;              // 64 Mi reads = 768 MiB of triples per device batch
+  const int64_t batch = c->batchReads;
   int rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
   for (int64_t off = 0; off < n; off += batch) {
     const int64_t cnt = std::min(batch, n - off);
@@ -481,7 +484,7 @@ int gtx_coverage_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, i
   if (!c->covOpen) return fail(c, GTX_E_STATE, "gtx_coverage_add: gtx_coverage_begin has not been called");
   if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_coverage_add: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
-  const int64_t batch = 64ll << 20;
+  const int64_t batch = c->batchReads;
   int rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
   for (int64_t off = 0; off < n; off += batch) {
     const int64_t cnt = std::min(batch, n - off);
@@ -575,6 +578,7 @@ int gtx_scan_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int6
   if (!c) return GTX_E_ARG;
   if (n < 0 || (n > 0 && !d_reads)) return fail(c, GTX_E_ARG, "gtx_scan_device: bad argument");
   if (prep != '1' && prep != 'c') return fail(c, GTX_E_ARG, "gtx_scan_device: preprocess operator must be '1' or 'c'");
+  if (!d_weights && n >= (1ll << 32)) return fail(c, GTX_E_ARG, "gtx_scan_device: unweighted scans count in 32 bits per micro-window: at most 2^32-1 reads per call");
   HIPCHK(c, hipSetDevice(c->device));
   gtx::ScanArgs a;
   int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
@@ -596,6 +600,7 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
   if (!c) return GTX_E_ARG;
   if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_scan: bad argument");
   if (prep != '1' && prep != 'c') return fail(c, GTX_E_ARG, "gtx_scan: preprocess operator must be '1' or 'c'");
+  if (!weights && n >= (1ll << 32)) return fail(c, GTX_E_ARG, "gtx_scan: unweighted scans count in 32 bits per micro-window: at most 2^32-1 reads per call");
   HIPCHK(c, hipSetDevice(c->device));
   gtx::ScanArgs a;
   int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
@@ -605,7 +610,7 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
   for (int i = 0; i < nClasses; i++) extent = std::max<int64_t>(extent, classOff[i] + gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size));
   if (extent > 0 && !out) return fail(c, GTX_E_ARG, "gtx_scan: null output");
   rc = ensure_out(c, (size_t)extent); if (rc) return rc;
-  const int64_t batch = 64ll << 20;
+  const int64_t batch = c->batchReads;
   rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
   const bool micro64 = weights != nullptr;
   if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (micro64 ? 8 : 4), c->stream));

@@ -194,3 +194,48 @@ def test_config2_10m_reads_200k_refs(engine):
     want = orc.count(refs, reads, algo=orc.SORTED_MERGE)
     np.testing.assert_array_equal(hits, want)
     assert info["n_degenerate"] == 0 and info["n_no_class"] == 0
+
+
+def test_streaming_begin_add_end(engine):
+    """gtx_count_begin / _add / _end over several batches == one gtx_count; the order check works across seams."""
+    refs = synth.genome_intervals(20000, 61, 50, 2000)
+    reads = synth.genome_intervals(300000, 62, 50, 51)
+    engine.set_refs(refs, synth.n_classes())
+    want, _ = engine.count(reads)
+    cuts = [0, 1, 64, 70000, 70001, 199999, len(reads)]
+    batches = [(reads[a:b], None) for a, b in zip(cuts[:-1], cuts[1:])]
+    got, info = engine.count_stream(batches, gtx.READS_SORTED | gtx.CHECK_SORTED)
+    np.testing.assert_array_equal(got, want)
+    assert info["first_unsorted"] == -1
+    # a violation exactly at a seam: the first read of a batch sorts before the last read of the previous one
+    bad = reads.copy()
+    bad[70000], bad[69999] = reads[69999].copy(), reads[70000].copy()
+    if bad[70000, 1] == bad[69999, 1]:
+        bad[70000, 1] -= 1
+    batches = [(bad[a:b], None) for a, b in zip(cuts[:-1], cuts[1:])]
+    _, info = engine.count_stream(batches, gtx.READS_SORTED | gtx.CHECK_SORTED)
+    assert info["first_unsorted"] == 70000
+
+
+def test_device_batching_inside_one_call():
+    """GTX_BATCH_READS forces gtx_count / gtx_scan / gtx_coverage to split one call into many device batches."""
+    import os
+    os.environ["GTX_BATCH_READS"] = "50000"
+    try:
+        e = gtx.Engine(0)
+    finally:
+        del os.environ["GTX_BATCH_READS"]
+    rng = np.random.default_rng(63)
+    refs = synth.genome_intervals(8000, 63, 50, 3000)
+    reads = synth.genome_intervals(260001, 64, 30, 400)
+    w = rng.integers(0, 4, size=len(reads)).astype(np.int32)
+    e.set_refs(refs, synth.n_classes())
+    hits, info = e.count(reads, w, gtx.READS_SORTED | gtx.CHECK_SORTED)
+    np.testing.assert_array_equal(hits, orc.count(refs, reads, w))
+    assert info["first_unsorted"] == -1
+    cov, _ = e.coverage(reads, w)
+    np.testing.assert_array_equal(cov, orc.coverage(refs, reads, w))
+    win, _ = e.scan(reads, synth.CHROM_LEN, 1000, 3000)
+    want, _ = orc.scan(reads, synth.CHROM_LEN, 1000, 3000)
+    np.testing.assert_array_equal(win, want)
+    e.close()
