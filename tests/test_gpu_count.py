@@ -239,3 +239,39 @@ def test_device_batching_inside_one_call():
     want, _ = orc.scan(reads, synth.CHROM_LEN, 1000, 3000)
     np.testing.assert_array_equal(win, want)
     e.close()
+
+
+def test_linearity_at_large_scale(engine):
+    """Size-independent property at a size the CPU oracle is not run at: counts are additive over any split
+    of the read stream, and the grand total equals the number of (read, region) overlaps summed per part.
+    250M reads (3 GB) resident in HBM, 1M regions."""
+    torch = pytest.importorskip("torch")
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 250_000_000
+    dev = torch.device("cuda", 0)
+    reads = bench.make_reads_on_device(n, np.arange(24), 77, dev)
+    refs = synth.genome_intervals(1_000_000, 43, 50, 2000)
+    engine.set_refs(refs, 24)
+    engine.set_stream(torch.cuda.current_stream().cuda_stream)
+    whole = torch.zeros(len(refs), dtype=torch.int64, device=dev)
+    part = torch.zeros_like(whole)
+    acc = torch.zeros_like(whole)
+    engine.count_device(reads.data_ptr(), n, whole.data_ptr())
+    cuts = [0, 1, 99_999_937, 100_000_000, 250_000_000]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        engine.count_device(reads[a:b].data_ptr(), b - a, part.data_ptr())
+        acc += part
+    engine.sync()
+    engine.set_stream(0)
+    assert torch.equal(whole, acc)
+    assert engine.last_info()["n_degenerate"] == 0
+    # spot-check one chromosome's regions against the oracle on that chromosome's reads
+    c = 20                                            # chr7 in strcmp order -> a mid-sized class
+    sel = reads[:, 0] == c
+    sub = reads[sel].cpu().numpy()
+    rsel = np.nonzero(refs[:, 0] == c)[0]
+    want = orc.count(refs[rsel], sub, algo=orc.SORTED_MERGE)
+    np.testing.assert_array_equal(whole.cpu().numpy().view(np.uint64)[rsel], want)
