@@ -458,8 +458,11 @@ __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__
         have = true;
         int odd = 0, dg = 0, ks[R], ke[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { odd |= t[r].c ^ st.sg.cls; dg |= (t[r].e + zl) - t[r].s; ks[r] = t[r].s; ke[r] = t[r].e; }
-        // dg < 0 in some lane <=> some read has start > end (+zl); the general path re-tests exactly
+        for (int r = 0; r < R; ++r) {
+          odd |= t[r].c ^ st.sg.cls; ks[r] = t[r].s; ke[r] = t[r].e;
+          dg |= __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(t[r].e, zl), t[r].s);   // saturating: the sign is exact for any int32
+        }
+        // dg < 0 in some lane <=> some read has start > end (+zl)
         const int kmin = min_of<R>(ks), emin = min_of<R>(ke);
         if (__ballot((odd != 0) | (dg < 0) | (kmin <= st.A.prevW) | (emin < st.B.prevW))) break;
         if constexpr (!WEIGHTED) {
