@@ -1,0 +1,68 @@
+// gtx_packtool -- host-only view of the BED ingest (gtx_bed.*): packs a BED stream with the rules of one
+// of the four consumers and prints the packed triples as text.  No GPU, no libgtx: this is how the
+// CPU test suite checks the packer (line handling, tokenising, order checks, error text and line numbers,
+// thread-count independence) on machines without an MI355X.
+//
+//   gtx_packtool MODE [-t THREADS] [-s] [-a] [-l MAXLABEL] [-c CHROM,CHROM,...] [FILE]
+//     MODE   ou = overlaps/unsorted   os = overlaps/sorted   su = scan/unsorted   ss = scan/sorted
+//     -s sorted by strand   -a strand-aware classes   -c known chromosomes (default: all seen in FILE order? no:
+//        the list is required for reproducible class ids)
+//   output: one line per packed read "class start end [weight]", then "# lines=N"; errors like the CLIs.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+#include "gtx_bed.h"
+
+using namespace gtxhost;
+
+int main(int argc, char **argv)
+{
+  if (argc < 2) { fprintf(stderr, "usage: gtx_packtool ou|os|su|ss [-t N] [-s] [-a] [-l MAX] -c chr1,chr2,... [FILE]\n"); return 2; }
+  PackOptions opt;
+  std::string m = argv[1];
+  if (m == "ou") opt.mode = PACK_OVERLAPS_UNSORTED; else if (m == "os") opt.mode = PACK_OVERLAPS_SORTED;
+  else if (m == "su") opt.mode = PACK_SCAN_UNSORTED; else if (m == "ss") opt.mode = PACK_SCAN_SORTED;
+  else { fprintf(stderr, "unknown mode '%s'\n", argv[1]); return 2; }
+  ChromTable chroms;
+  const char *file = NULL; size_t batch = 1u << 20;
+  for (int a = 2; a < argc; a++) {
+    if (!strcmp(argv[a], "-t") && a + 1 < argc) opt.threads = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "-s")) opt.sorted_by_strand = true;
+    else if (!strcmp(argv[a], "-a")) opt.strand_aware = true;
+    else if (!strcmp(argv[a], "-z")) opt.collect_zero_length = true;
+    else if (!strcmp(argv[a], "-l") && a + 1 < argc) opt.max_label_value = atol(argv[++a]);
+    else if (!strcmp(argv[a], "-b") && a + 1 < argc) batch = (size_t)atol(argv[++a]);
+    else if (!strcmp(argv[a], "-c") && a + 1 < argc) {
+      std::string list = argv[++a];
+      size_t p = 0;
+      while (p <= list.size()) { size_t q = list.find(',', p); if (q == std::string::npos) q = list.size(); if (q > p) chroms.Add(list.substr(p, q - p).c_str()); p = q + 1; }
+    } else file = argv[a];
+  }
+  chroms.Freeze();
+  opt.chroms = &chroms;
+  std::string err;
+  LineSource *src = LineSource::Open(file, &err);
+  if (!src) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+  BedPacker packer(src, opt);
+  PackedBatch b; PackError e; int64_t lines = 0;
+  for (;;) {
+    bool more = packer.NextBatch(&b, batch, &e);
+    if (e.set) {
+      fflush(stdout);
+      if (e.no_prefix) fprintf(stderr, "%s\n", e.msg.c_str()); else fprintf(stderr, "\nError: Line %ld: %s\n", e.line, e.msg.c_str());
+      return 1;
+    }
+    for (size_t i = 0; i + 2 < b.tri.size(); i += 3) {
+      if (b.w.empty()) printf("%d %d %d\n", b.tri[i], b.tri[i + 1], b.tri[i + 2]);
+      else printf("%d %d %d %d\n", b.tri[i], b.tri[i + 1], b.tri[i + 2], b.w[i / 3]);
+    }
+    for (size_t i = 0; i + 2 < b.zero_len.size(); i += 3) printf("# zero %d %d %d\n", b.zero_len[i], b.zero_len[i + 1], b.zero_len[i + 2]);
+    lines += b.n_lines;
+    if (!more) break;
+  }
+  printf("# lines=%ld\n", (long)lines);
+  delete src;
+  return 0;
+}
