@@ -62,7 +62,7 @@ struct gtx_ctx {
 
   int64_t batchReads = 64ll << 20;      // reads per device batch of the host-buffer entry points (768 MiB of triples)
   int chunksPerWave = 0;                // 0 = choose per call from the number of reads
-  int prefetch = 4;                     // reads per lane per step (R) of the streaming kernel
+  int prefetch = 4;                     // reads per lane per step (R) of the streaming kernel (GTX_READS_PER_LANE)
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -103,7 +103,7 @@ gtx_ctx *gtx_create(int device_id)
   if (cpw && atoi(cpw) > 0) c->chunksPerWave = atoi(cpw);
   const char *br = getenv("GTX_BATCH_READS");
   if (br && atoll(br) > 0) c->batchReads = atoll(br);
-  const char *pf = getenv("GTX_PREFETCH");
+  const char *pf = getenv("GTX_READS_PER_LANE");        // tuning knob (1..4), default 4
   if (pf && atoi(pf) > 0) c->prefetch = atoi(pf);
   return c;
 }

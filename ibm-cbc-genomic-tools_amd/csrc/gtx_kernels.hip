@@ -661,38 +661,38 @@ __global__ __launch_bounds__(256) void tile_sums_kernel(const u64 *__restrict__ 
   if (threadIdx.x == 0) { pa[blockIdx.x] = sa; pb[blockIdx.x] = sb; }
 }
 
+// grid (tiles, 2): blockIdx.y picks the histogram (A or B) -- twice the blocks, half the work per block
 __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha, u64 *__restrict__ hb, i64 len,
                                                             const u64 *__restrict__ ta, const u64 *__restrict__ tb,
                                                             u64 *__restrict__ pa, u64 *__restrict__ pb)
 {
   __shared__ u64 lds[4];
-  __shared__ u64 wsum[2][4];
+  __shared__ u64 wsum[4];
+  u64 *__restrict__ h = blockIdx.y ? hb : ha;
+  const u64 *__restrict__ ts = blockIdx.y ? tb : ta;
+  u64 *__restrict__ p = blockIdx.y ? pb : pa;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int tile = blockIdx.x;
-  // thread t owns 4 consecutive slots (two 16-byte loads per array); issued first, used last
+  // thread t owns 4 consecutive slots (two 16-byte loads); issued first, used last
   const i64 i0 = (i64)tile * kTile + (i64)threadIdx.x * 4;
-  u64 va[4], vb[4];
+  u64 v[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) { va[k] = i0 + k < len ? ha[i0 + k] : 0; vb[k] = i0 + k < len ? hb[i0 + k] : 0; }
+  for (int k = 0; k < 4; k++) v[k] = i0 + k < len ? h[i0 + k] : 0;
   // offset of this tile: sum of the tile sums below it
-  u64 oa = 0, ob = 0;
-  for (int t = threadIdx.x; t < tile; t += 256) { oa += ta[t]; ob += tb[t]; }
-  oa = block_sum(oa, lds); ob = block_sum(ob, lds);
-  va[1] += va[0]; va[2] += va[1]; va[3] += va[2];
-  vb[1] += vb[0]; vb[2] += vb[1]; vb[3] += vb[2];
-  u64 xa = va[3], xb = vb[3];                      // inclusive scan of the thread totals across the wave
+  u64 o = 0;
+  for (int t = threadIdx.x; t < tile; t += 256) o += ts[t];
+  o = block_sum(o, lds);
+  v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+  u64 x = v[3];                                    // inclusive scan of the thread totals across the wave
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    u64 ya = __shfl_up(xa, o), yb = __shfl_up(xb, o);
-    if (lane >= o) { xa += ya; xb += yb; }
-  }
-  if (lane == 63) { wsum[0][wv] = xa; wsum[1][wv] = xb; }
+  for (int d = 1; d < 64; d <<= 1) { u64 y = __shfl_up(x, d); if (lane >= d) x += y; }
+  if (lane == 63) wsum[wv] = x;
   __syncthreads();
-  oa += xa - va[3]; ob += xb - vb[3];
-  for (int k = 0; k < wv; k++) { oa += wsum[0][k]; ob += wsum[1][k]; }
+  o += x - v[3];
+  for (int k = 0; k < wv; k++) o += wsum[k];
 #pragma unroll
   for (int k = 0; k < 4; k++)
-    if (i0 + k < len) { pa[i0 + k] = va[k] + oa; pb[i0 + k] = vb[k] + ob; ha[i0 + k] = 0; hb[i0 + k] = 0; }
+    if (i0 + k < len) { p[i0 + k] = v[k] + o; h[i0 + k] = 0; }
 }
 
 __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict__ pa, const u64 *__restrict__ pb,
@@ -930,7 +930,7 @@ hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 
   const int nb = scan_tiles(histLen);
   if (nb > 0) {
     if (!tileSumsValid) tile_sums_kernel<<<nb, 256, 0, st>>>(histA, histB, histLen, tileA, tileB);
-    finalize_scan_kernel<<<nb, 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB);
+    finalize_scan_kernel<<<dim3(nb, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB);
   }
   const i64 work = (m > nb ? m : nb) > 0 ? (m > nb ? m : nb) : 1;
   gather_hits_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(prefA, prefB, posE, posS, classBase, m, hits, tileA, tileB, nb, nextInfo);
@@ -952,7 +952,7 @@ hipError_t launch_coverage_finalize(const CoverArgs &a, i64 histLen, const Cover
 {
   const int nb = scan_tiles(histLen);
   for (int q = 0; q < 8 && nb > 0; q += 2)
-    finalize_scan_kernel<<<nb, 256, 0, st>>>(a.hist[q], a.hist[q + 1], histLen, a.part[q], a.part[q + 1], g.pref[q], g.pref[q + 1]);
+    finalize_scan_kernel<<<dim3(nb, 2), 256, 0, st>>>(a.hist[q], a.hist[q + 1], histLen, a.part[q], a.part[q + 1], g.pref[q], g.pref[q + 1]);
   const i64 work = (m > nb ? m : nb) > 0 ? (m > nb ? m : nb) : 1;
   gather_coverage_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(g, m, cov, nb, nextInfo);
   return hipGetLastError();
