@@ -59,6 +59,74 @@ def make_reads_on_device(n, chrom_ids, seed, device):
     return out
 
 
+def bench_scans(args, eng, reads, n, rank, world, device, rehearse):
+    """BASELINE config 4: sliding-window read counts (1 kb windows) over the reads of this rank's chromosomes;
+    the per-window vectors of the ranks are disjoint by chromosome and are combined with one all-reduce(sum)."""
+    step_bp, size_bp = 1000, 1000
+    off, tot = gtx.scan_layout(synth.CHROM_LEN, step_bp, size_bp)
+    out = torch.zeros(tot, dtype=torch.int64, device=device)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        eng.scan_device(reads.data_ptr(), n, synth.CHROM_LEN, step_bp, size_bp, out.data_ptr())
+        if world > 1:
+            if rehearse:
+                h = out.cpu(); dist.all_reduce(h, op=dist.ReduceOp.SUM); out.copy_(h)
+            else:
+                dist.all_reduce(out, op=dist.ReduceOp.SUM)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    k_ms = float(np.mean([eng.profile_last(b)[0] for b in range(min(args.steps, 64))]))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle import orc
+        ns = min(args.cpu_sample, n)
+        sample = reads[:ns].cpu().numpy()
+        t1 = time.perf_counter()
+        want, _ = orc.scan(sample, synth.CHROM_LEN, step_bp, size_bp, algo=1)
+        cpu_s = time.perf_counter() - t1
+        eng.scan_device(reads.data_ptr(), ns, synth.CHROM_LEN, step_bp, size_bp, out.data_ptr())
+        eng.sync()
+        if not np.array_equal(out.cpu().numpy().view(np.uint64), want):
+            sys.exit("PARITY FAILURE: GPU window counts differ from the CPU oracle on the %d-read sample" % ns)
+        cpu = {"value": ns / cpu_s, "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "first %d reads, sorted-scanner restatement (oracle/gtx_oracle.c) on packed triples; windows bit-equal to the GPU's" % ns}
+    if rank == 0:
+        n_micro = int((synth.CHROM_LEN // step_bp).sum())
+        alg = 12.0 * n + 4.0 * n_micro
+        print(json.dumps({
+            "metric": "window-counted reads/sec, genomic_scans counts 1 kb windows (BASELINE config 4)",
+            "value": world * n * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 4: genomic_scans counts -i -w 1000 -d 1000 over %d 50bp reads/GPU, hg38 chromosome shards, "
+                                   "all-reduce(sum) of the %d-window vector" % (n, tot), "reads_per_gpu": n, "windows": tot},
+            "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "scan_hist_kernel", "kernel_ms": k_ms,
+                         "algorithmic_bytes": alg},
+            "cpu_baseline": cpu}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +135,8 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
     ap.add_argument("--refs", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="reads given to the CPU baseline (0 = skip)")
+    ap.add_argument("--workload", choices=["count", "scans"], default="count",
+                    help="count = BASELINE config 3 (the headline metric); scans = config 4: genomic_scans counts -i -w 1000 -d 1000")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,6 +174,8 @@ def main():
     step_no = [0]
 
     eng = gtx.Engine(local)
+    if args.workload == "scans":
+        return bench_scans(args, eng, reads, n, rank, world, device, rehearse)
     eng.set_refs(refs, synth.n_classes())
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
