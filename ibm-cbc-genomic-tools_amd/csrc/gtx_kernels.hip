@@ -186,19 +186,37 @@ struct Win {
     curW = prevW; prevW = rdlane(W, j);
   }
 
-  // one lane on its own: binary search + atomic
-  __device__ __forceinline__ void lane_add(const Seg &sg, int key, i64 w) const
+  // Lanes on their own (keys scattered over many windows, reads of a class the wave is not following):
+  // every lane of `m` finds its slot with a binary search in segment `sg` and adds itself to the
+  // histogram; the tile sums get ONE atomic per distinct tile of the wave (per-lane atomics on the few
+  // hundred tile counters would serialise on each other).  Called in wave-uniform control flow; sg may
+  // differ per lane.
+  __device__ __forceinline__ void lanes_add(const Seg &sg, int key, i64 w, u64 m, int lane) const
   {
-    int lo = sg.start, hi = sg.end;
-    while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (before(arr[mid], key)) lo = mid + 1; else hi = mid; }
-    const i64 idx = (i64)lo + sg.cls;
-    atomicAdd(&hist[idx], (u64)w);
-    atomicAdd(&part[idx >> kTileShift], (u64)w);
-    if (SUMKEY) { atomicAdd(&hist2[idx], (u64)(w * key)); atomicAdd(&part2[idx >> kTileShift], (u64)(w * key)); }
+    const bool mine = (m >> lane) & 1;
+    int tile = -1;
+    if (mine) {
+      int lo = sg.start, hi = sg.end;
+      while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (before(arr[mid], key)) lo = mid + 1; else hi = mid; }
+      const i64 idx = (i64)lo + sg.cls;
+      atomicAdd(&hist[idx], (u64)w);
+      if (SUMKEY) atomicAdd(&hist2[idx], (u64)(w * key));
+      tile = (int)(idx >> kTileShift);
+    }
+    u64 rem = m;
+    while (rem) {
+      const int t0 = rdlane(tile, __ffsll((unsigned long long)rem) - 1);
+      const u64 g = __ballot(tile == t0) & rem;
+      rem &= ~g;
+      const bool in = (g >> lane) & 1;
+      const i64 s = wave_sum(in ? w : 0);
+      if (lane == 0 && s != 0) atomicAdd(&part[t0], (u64)s);
+      if (SUMKEY) { const i64 q = wave_sum(in ? w * key : 0); if (lane == 0 && q != 0) atomicAdd(&part2[t0], (u64)q); }
+    }
   }
 
   // Add the lanes of m (keys `key`, weights `w`) to the histogram; returns the lanes it left
-  // for lane_add() because their keys are spread over too many windows (then `valid` is dropped).
+  // for lanes_add() because their keys are spread over too many windows (then `valid` is dropped).
   __device__ __forceinline__ u64 walk(const Seg &sg, int key, int w, u64 m, int lane, bool &valid)
   {
     if (!valid) { seek(sg, key, m, lane); valid = true; }
@@ -267,8 +285,10 @@ __device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountA
     st.pc = rdlane(cc, last); st.ps = rdlane(t.s, last);
   }
 
-  // the wave follows the class of its first read
-  const int c0 = rdlane(t.c, 0);
+  // the wave stays with its class while the chunk still has reads of it (interleaved classes: the others
+  // add themselves lane by lane); otherwise it follows the class of the chunk's first read
+  int c0 = rdlane(t.c, 0);
+  if (st.sg.cls >= 0 && (__ballot(t.c == st.sg.cls) & active)) c0 = st.sg.cls;
   if (c0 != st.sg.cls && (unsigned)c0 < (unsigned)a.nClasses) {
     if (st.validA) st.A.flush(st.sg, lane);
     if (st.validB) st.B.flush(st.sg, lane);
@@ -287,16 +307,14 @@ __device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountA
   if (mine && st.sg.start != st.sg.end) {
     u64 ra = st.A.walk(st.sg, t.s, w, mine, lane, st.validA);
     u64 rb = st.B.walk(st.sg, t.e, w, mine, lane, st.validB);
-    if (ra | rb) {
-      if ((ra >> lane) & 1) st.A.lane_add(st.sg, t.s, w);
-      if ((rb >> lane) & 1) st.B.lane_add(st.sg, t.e, w);
-    }
+    if (ra) st.A.lanes_add(st.sg, t.s, w, ra, lane);
+    if (rb) st.B.lanes_add(st.sg, t.e, w, rb, lane);
   }
   if (other) {
-    if ((other >> lane) & 1) {
-      Seg so; so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c;
-      if (so.start != so.end) { st.A.lane_add(so, t.s, w); st.B.lane_add(so, t.e, w); }
-    }
+    Seg so; so.start = 0; so.end = 0; so.cls = 0;
+    if ((other >> lane) & 1) { so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c; }
+    const u64 has = __ballot(so.start != so.end) & other;          // classes without reference regions: nothing to add
+    if (has) { st.A.lanes_add(so, t.s, w, has, lane); st.B.lanes_add(so, t.e, w, has, lane); }
   }
 }
 
@@ -388,7 +406,7 @@ __device__ __forceinline__ void walk_fast(WIN &X, const Seg &sg, const int (&k)[
       // keys spread over many windows: every key above the boundary just passed adds itself
       const int passed = rdlane(X.W, 0);
 #pragma unroll
-      for (int r = 0; r < R; ++r) if (!WIN::below(k[r], passed)) X.lane_add(sg, k[r], 1);
+      for (int r = 0; r < R; ++r) { const u64 ahead = __ballot(!WIN::below(k[r], passed)); if (ahead) X.lanes_add(sg, k[r], 1, ahead, lane); }
       X.j = 0; X.prevW = passed; X.curW = curW; X.pend = 0;
       valid = false;                                         // acc is 0 and nothing is pending: nothing to flush
       return;
@@ -551,7 +569,8 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
     const u64 active = left >= 64 ? ~0ull : ((1ull << left) - 1);
     Tri t; t.c = -1; t.s = 0; t.e = 0; int w = 1;
     if (lane < left) { t = reads[first + at + lane]; if (WEIGHTED) w = weights[first + at + lane]; }
-    const int c0 = rdlane(t.c, 0);
+    int c0 = rdlane(t.c, 0);
+    if (sg.cls >= 0 && (__ballot(t.c == sg.cls) & active)) c0 = sg.cls;
     if (c0 != sg.cls && (unsigned)c0 < (unsigned)a.nClasses) {
       if (vAs) As.flush(sg, lane);
       if (vAe) Ae.flush(sg, lane);
@@ -574,18 +593,16 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
       u64 r1 = Ae.walk(sg, t.e, w, mine, lane, vAe);
       u64 r2 = Bs.walk(sg, t.s, w, mine, lane, vBs);
       u64 r3 = Be.walk(sg, t.e, w, mine, lane, vBe);
-      if (r0 | r1 | r2 | r3) {
-        if ((r0 >> lane) & 1) As.lane_add(sg, t.s, w);
-        if ((r1 >> lane) & 1) Ae.lane_add(sg, t.e, w);
-        if ((r2 >> lane) & 1) Bs.lane_add(sg, t.s, w);
-        if ((r3 >> lane) & 1) Be.lane_add(sg, t.e, w);
-      }
+      if (r0) As.lanes_add(sg, t.s, w, r0, lane);
+      if (r1) Ae.lanes_add(sg, t.e, w, r1, lane);
+      if (r2) Bs.lanes_add(sg, t.s, w, r2, lane);
+      if (r3) Be.lanes_add(sg, t.e, w, r3, lane);
     }
     if (other) {
-      if ((other >> lane) & 1) {
-        Seg so; so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c;
-        if (so.start != so.end) { As.lane_add(so, t.s, w); Ae.lane_add(so, t.e, w); Bs.lane_add(so, t.s, w); Be.lane_add(so, t.e, w); }
-      }
+      Seg so; so.start = 0; so.end = 0; so.cls = 0;
+      if ((other >> lane) & 1) { so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c; }
+      const u64 has = __ballot(so.start != so.end) & other;
+      if (has) { As.lanes_add(so, t.s, w, has, lane); Ae.lanes_add(so, t.e, w, has, lane); Bs.lanes_add(so, t.s, w, has, lane); Be.lanes_add(so, t.e, w, has, lane); }
     }
   }
   if (vAs) As.flush(sg, lane);
