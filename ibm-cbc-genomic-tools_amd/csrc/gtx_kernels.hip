@@ -9,20 +9,27 @@
 //             = sum_q w_q [s_q <= E_k]  -  sum_q w_q [e_q < S_k]          (s_q <= e_q, S_k <= E_k)
 //
 // so one streaming pass over the reads fills two histograms over *ranks*:
-//     HA[#{E_j < s_q}] += w_q        (E sorted ascending inside the class)
-//     HB[#{S_j < e_q + 1}] += w_q    (S sorted ascending inside the class)
+//     HA[#{E_j <  s_q}] += w_q       (E sorted ascending inside the class)
+//     HB[#{S_j <= e_q}] += w_q       (S sorted ascending inside the class)
 // and  hits[k] = prefix(HA)[posE(k)] - prefix(HB)[posS(k)].  Integer adds commute, so any
 // execution order is bit-exact.
 //
-// The streaming kernel is wave-autonomous (no LDS, no barriers): a wave64 owns a contiguous span
-// of reads, takes 64 of them at a time (one 12-byte triple per lane, one coalesced 768-byte
-// request), and "walks" a 63-slot window of sorted boundaries that lives in one VGPR across the
-// wave.  For a boundary value W (wave-uniform, read with v_readlane) the number of reads of the
-// chunk at or below it is popcount(ballot(key <= W)): one v_cmp + a few scalar ops per boundary
-// crossed, nothing per read.  Sorted input crosses ~M/(N/64) boundaries per chunk, so the kernel
-// is bound by the HBM read of the triples.  Any input order is handled exactly (backward walk,
-// re-seek by wave-cooperative 64-ary search, per-lane binary search for scattered chunks); only
-// the speed depends on the order.  No MFMA: this is integer indexing, not a contraction.
+// The streaming kernel (count_walk_kernel) is wave-autonomous -- no LDS, no barriers: a wave64 owns
+// a contiguous span of reads and takes them 4 x 64 at a time (register r of lane l = read 64r+l of
+// the step: four coalesced non-temporal 768-byte requests).  The sorted boundaries of the class it is
+// in live in a 63-slot window in ONE VGPR across the wave (next window prefetched).  For a boundary W
+// (wave-uniform, v_readlane) the number of keys of the step at or below it is
+// popcount(ballot(key <= W)): per boundary crossed a handful of compares and scalar popcounts (a
+// hand-scheduled 27-instruction loop), nothing per read; a step that crosses no boundary costs two
+// compares per array.  Sorted input crosses ~2M/(N/256) boundaries per step, so the kernel is bound by
+// the HBM read of the triples first and by scalar-ALU issue second.  Any input
+// order is handled exactly (backward walk, re-seek by wave-cooperative 64-ary search, lanes that add
+// themselves by binary search); only the speed depends on the order.
+// No MFMA anywhere: this is integer indexing, not a contraction.
+//
+// Kernels in this file: count_walk_kernel (dominant), count_search_kernel (order-agnostic),
+// coverage_walk_kernel (CalcIndexCoverage), tile_sums/finalize_scan/gather_hits/gather_coverage
+// (prefix + gather), scan_hist_kernel + scan_window_kernel (genomic_scans counts).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
