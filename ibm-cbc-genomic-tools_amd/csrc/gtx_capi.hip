@@ -28,6 +28,7 @@ struct gtx_ctx {
   int64_t nRefs = -1, nValid = 0;
   int nClasses = 0;
   int *d_sortedE = nullptr, *d_sortedS = nullptr, *d_segStart = nullptr;
+  int *d_sampE = nullptr, *d_sampS = nullptr; int sampShift = 6, nSamp = 0;   // top level of the search kernel
   int *d_posE = nullptr, *d_posS = nullptr, *d_classBase = nullptr;
   u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr, *d_prefA = nullptr, *d_prefB = nullptr;
   bool histDirty = false;              // a call was abandoned between begin and end
@@ -113,6 +114,7 @@ void gtx_destroy(gtx_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
+  dfree(c->d_sampE); dfree(c->d_sampS);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   dfree(c->d_reads); dfree(c->d_weights); dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
   for (auto &p : c->d_cov) dfree(p);
@@ -183,6 +185,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   }
 
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
+  dfree(c->d_sampE); dfree(c->d_sampS);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB);
   c->nRefs = -1;
   const int64_t histLen = nv + nClasses;
@@ -208,6 +211,16 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   HIPCHK(c, hipMemcpy(c->d_sortedE, sortedE.data(), sizeof(int32_t) * nv, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_sortedS, sortedS.data(), sizeof(int32_t) * nv, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_segStart, seg.data(), sizeof(int32_t) * (nClasses + 1), hipMemcpyHostToDevice));
+  {
+    c->sampShift = gtx::search_sample_shift(nv);
+    c->nSamp = (int)((nv + (1ll << c->sampShift) - 1) >> c->sampShift);
+    std::vector<int32_t> sampE(c->nSamp + 1), sampS(c->nSamp + 1);
+    for (int i = 0; i < c->nSamp; i++) { sampE[i] = sortedE[(int64_t)i << c->sampShift]; sampS[i] = sortedS[(int64_t)i << c->sampShift]; }
+    HIPCHK(c, hipMalloc(&c->d_sampE, sizeof(int32_t) * (c->nSamp + 1)));
+    HIPCHK(c, hipMalloc(&c->d_sampS, sizeof(int32_t) * (c->nSamp + 1)));
+    HIPCHK(c, hipMemcpy(c->d_sampE, sampE.data(), sizeof(int32_t) * (c->nSamp + 1), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_sampS, sampS.data(), sizeof(int32_t) * (c->nSamp + 1), hipMemcpyHostToDevice));
+  }
   if (m > 0) {
     HIPCHK(c, hipMemcpy(c->d_posE, posE.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_posS, posS.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
@@ -238,6 +251,7 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
   a.chunksPerWave = (cpw + r - 1) / r * r;
   a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0; a.prefetch = c->prefetch;
   a.zeroLenOk = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
+  a.sampE = c->d_sampE; a.sampS = c->d_sampS; a.sampShift = c->sampShift; a.nSamp = c->nSamp;
   return a;
 }
 

@@ -28,6 +28,9 @@ struct CountArgs {
   int sortClassShift;
   int prefetch;                  // reads per lane per step of the streaming kernel (1..4)
   int zeroLenOk;                 // start == end+1 is a countable read (sorted-merge semantics)
+  const int *sampE;              // every (1 << sampShift)-th element of sortedE / sortedS: the
+  const int *sampS;              //   search kernel keeps them in LDS as the top level of its searches
+  int sampShift, nSamp;
 };
 
 // coverage: 8 histograms / tile-sum arrays in the order
@@ -61,6 +64,7 @@ struct ScanArgs {
   int sortedRule;                // sorted scanner: no validity test, pos < 1 lands in the first micro-window
 };
 
+int search_sample_shift(long long nValid);   // stride of the sample arrays such that both fit the LDS budget
 int scan_tiles(long long len);
 
 hipError_t launch_count(const void *reads, const void *weights, long long n, const CountArgs &a, bool sortedHint, hipStream_t st);

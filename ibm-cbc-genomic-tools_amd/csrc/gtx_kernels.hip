@@ -46,9 +46,13 @@ static constexpr int kLo = (int)0x80000000;     // -inf sentinel
 static constexpr int kSlots = 63;               // slots per register window (lane 0 holds the boundary below slot 0)
 static constexpr int kTileShift = 10;           // finalize scan tile = 1024 histogram slots
 static constexpr int kTile = 1 << kTileShift;
+static constexpr int kSearchLdsBytes = 128 * 1024;  // LDS top level of the search kernel (both arrays)
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// value of the lane below (lane 0 keeps its own); DPP wave_shr:1 -- call with all lanes active
+__device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 
 __device__ __forceinline__ int wave_min(int v)
 {
@@ -626,24 +630,63 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
 // Order-agnostic count kernel ("search"): every read does two binary searches in the (L2 /
 // Infinity-Cache resident) boundary arrays.  Used when the caller does not claim sorted reads.
 // ---------------------------------------------------------------------------------------------
-template <bool WEIGHTED>
-__global__ __launch_bounds__(256) void count_search_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n,
-                                                           CountArgs a)
+// all lanes of the wave call this; slot < 0 = nothing to add.  One atomic per run of equal slots.
+__device__ __forceinline__ void run_add(u64 *__restrict__ hist, int slot, int lane)
 {
+  const int prev = lane_prev(slot);
+  const bool head = lane == 0 || slot != prev;
+  const u64 heads = __ballot(head);
+  if (head && slot >= 0) {
+    const u64 rest = lane == 63 ? 0 : heads >> (lane + 1);
+    const int len = rest ? __builtin_ctzll(rest) + 1 : 64 - lane;
+    atomicAdd(&hist[slot], (u64)len);
+  }
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(1024) void count_search_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n,
+                                                            CountArgs a)
+{
+  // top level of both searches in LDS: every (1 << sampShift)-th boundary of each array
+  extern __shared__ int smp[];
+  int *__restrict__ se = smp, *__restrict__ ss = smp + a.nSamp;
+  for (int i = threadIdx.x; i < a.nSamp; i += blockDim.x) { se[i] = a.sampE[i]; ss[i] = a.sampS[i]; }
+  __syncthreads();
+  const int sh = a.sampShift, rnd = (1 << sh) - 1;
   i64 nNoClass = 0, nDegen = 0, firstDegen = INT64_MAX;
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
-    Tri t = reads[i];
-    i64 w = WEIGHTED ? (i64)weights[i] : 1;
-    if ((unsigned)t.c >= (unsigned)a.nClasses) { nNoClass++; continue; }
-    if (t.s > t.e + a.zeroLenOk) { nDegen++; if (i < firstDegen) firstDegen = i; continue; }
-    int s0 = a.segStart[t.c], s1 = a.segStart[t.c + 1];
-    if (s0 == s1) continue;
-    int lo = s0, hi = s1;
-    while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (a.sortedE[mid] < t.s) lo = mid + 1; else hi = mid; }
-    atomicAdd(&a.histA[(i64)lo + t.c], (u64)w);
-    lo = s0; hi = s1;
-    while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (a.sortedS[mid] <= t.e) lo = mid + 1; else hi = mid; }
-    atomicAdd(&a.histB[(i64)lo + t.c], (u64)w);
+  const int lane = threadIdx.x & 63;
+  for (i64 base = (i64)blockIdx.x * blockDim.x; base < n; base += (i64)gridDim.x * blockDim.x) {
+    const i64 i = base + threadIdx.x;
+    int slotA = -1, slotB = -1;
+    i64 w = 1;
+    if (i < n) {
+      const Tri t = reads[i];
+      if (WEIGHTED) w = (i64)weights[i];
+      const int s0 = (unsigned)t.c < (unsigned)a.nClasses ? a.segStart[t.c] : 0, s1 = (unsigned)t.c < (unsigned)a.nClasses ? a.segStart[t.c + 1] : 0;
+      if ((unsigned)t.c >= (unsigned)a.nClasses) nNoClass++;
+      else if (t.s > t.e + a.zeroLenOk) { nDegen++; if (i < firstDegen) firstDegen = i; }
+      else if (s0 != s1) {
+        // samples i0..i1-1 are the ones that lie inside the class segment [s0, s1)
+        const int i0 = (int)(((i64)s0 + rnd) >> sh), i1 = (int)(((i64)s1 + rnd) >> sh);
+        int lo = i0, hi = i1;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (se[mid] < t.s) lo = mid + 1; else hi = mid; }
+        int glo = lo == i0 ? s0 : ((lo - 1) << sh) + 1, ghi = lo == i1 ? s1 : lo << sh;
+        while (glo < ghi) { int mid = (int)(((i64)glo + ghi) >> 1); if (a.sortedE[mid] < t.s) glo = mid + 1; else ghi = mid; }
+        slotA = glo + t.c;
+        lo = i0; hi = i1;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (ss[mid] <= t.e) lo = mid + 1; else hi = mid; }
+        glo = lo == i0 ? s0 : ((lo - 1) << sh) + 1; ghi = lo == i1 ? s1 : lo << sh;
+        while (glo < ghi) { int mid = (int)(((i64)glo + ghi) >> 1); if (a.sortedS[mid] <= t.e) glo = mid + 1; else ghi = mid; }
+        slotB = glo + t.c;
+      }
+    }
+    if (WEIGHTED) {
+      if (slotA >= 0) { atomicAdd(&a.histA[slotA], (u64)w); atomicAdd(&a.histB[slotB], (u64)w); }
+    } else {
+      // neighbouring lanes that landed in the same slot (reads that happen to be in order) share one atomic
+      run_add(a.histA, slotA, lane);
+      run_add(a.histB, slotB, lane);
+    }
   }
   if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
   if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen); }
@@ -767,8 +810,6 @@ __global__ __launch_bounds__(256) void gather_coverage_kernel(CoverGather g, i64
 // Sorted reads put runs of equal micro-window index in neighbouring lanes: one atomic per run.
 // ---------------------------------------------------------------------------------------------
 // previous lane's value (lane 0 keeps its own): DPP wave_shr:1, no LDS traffic
-__device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
-
 // micro-window (class, index) of one read, or (-1,-1) when it does not count
 __device__ __forceinline__ void scan_slot(const Tri &t, bool in_range, const ScanArgs &a, int &cls, int &mw)
 {
@@ -923,6 +964,13 @@ __global__ __launch_bounds__(256) void scan_window_kernel(const MT *__restrict__
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+int search_sample_shift(i64 nValid)
+{
+  int sh = 6;
+  while ((((nValid + (1ll << sh) - 1) >> sh) * 2 * (i64)sizeof(int)) > kSearchLdsBytes) sh++;
+  return sh;
+}
+
 int scan_tiles(i64 len) { return (int)((len + kTile - 1) / kTile); }
 
 hipError_t launch_count(const void *reads, const void *weights, i64 n, const CountArgs &a, bool sortedHint, hipStream_t st)
@@ -941,9 +989,18 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
     else if (a.prefetch == 3) count_walk_kernel<false, 3><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else count_walk_kernel<false, 4><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   } else {
-    i64 blocks = (n + 255) / 256; if (blocks > 256 * 32) blocks = 256 * 32;
-    if (weights) count_search_kernel<true><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-    else count_search_kernel<false><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    // one 1024-thread block per CU (the LDS top level fills most of the CU's 160 KB)
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void *)count_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSearchLdsBytes);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)count_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSearchLdsBytes);
+      if (e != hipSuccess) return e;
+      attr = true;
+    }
+    i64 blocks = (n + 1023) / 1024; if (blocks > 512) blocks = 512;
+    const size_t lds = sizeof(int) * 2 * (size_t)a.nSamp;
+    if (weights) count_search_kernel<true><<<(unsigned)blocks, 1024, lds, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else count_search_kernel<false><<<(unsigned)blocks, 1024, lds, st>>>((const Tri *)reads, (const int *)weights, n, a);
   }
   return hipGetLastError();
 }

@@ -57,6 +57,17 @@ def test_more_refs_than_reads(engine):
     check(engine, refs, reads)
 
 
+def test_search_kernel_with_coarse_lds_samples(engine):
+    """> 2^20 boundaries per array: the LDS top level of the order-agnostic kernel samples every 256th
+    boundary instead of every 64th; shuffled reads over 24 chromosomes, one of them without references."""
+    rng = np.random.default_rng(77)
+    refs = synth.genome_intervals(2_300_000, 5, 50, 2000)
+    refs = refs[refs[:, 0] != 3]
+    reads = synth.genome_intervals(150_000, 6, 36, 36)
+    reads = reads[rng.permutation(len(reads))]
+    check(engine, refs, reads, flags=0, n_classes=synth.n_classes())
+
+
 def test_refs_in_file_order_unsorted_and_overlapping(engine):
     rng = np.random.default_rng(8)
     refs = synth.refs_single_chrom(30000, seed=8, chrom_len=2_000_000, max_len=20000)
