@@ -1,0 +1,556 @@
+// gtx_perm.hip -- category permutation test on the MI355X: kernels + C ABI (include/gtx_perm.h).
+//
+// What the reference does (gtools/permutation_test.cpp:555-572): P times { shuffle the per-row value
+// vector, recompute every category's statistic over its membership list, compare with the observed
+// one }.  One permutation at a time, one category at a time, one row at a time.
+//
+// Here the permutation number is the SIMD dimension:
+//   perm_apply_kernel   writes a slab Vp[row][q] = V[pi_q(row)] for a batch of permutations q; pi_q is a
+//                       keyed bijection evaluated independently per (row, q) -- no shuffle state, no
+//                       sequential dependence (definition: include/gtx_perm.h);
+//   perm_stat_kernel    one wave = one category x 64 permutations.  The membership list is wave-uniform
+//                       (scalar loads); each gathered row is one coalesced 256-byte read of the slab;
+//                       every lane accumulates ITS permutation's sums in double, sequentially in list
+//                       order -- the reference's summation order, so the statistic is bit-identical to
+//                       the CPU restatement -- then finishes the statistic, compares and the wave adds
+//                       popcount(ballot) to the category's counter.
+// Blocks are ordered slab-tile-major so that the blocks in flight share a few 64-permutation tiles
+// of the slab (n_rows x 256 B each) through L2 / Infinity Cache.
+// Bound: slab bytes moved = 4 B x (membership entries) x (permutations) -- an HBM/L2 gather stream; the
+// double adds are ~1/10 of the FP64 rate at that bandwidth.  No MFMA: the 0/1 membership matrix is ~1%
+// dense, a dense contraction would do 100x the work.
+//
+// Compiled with -ffp-contract=off: the reference's host compiler does not fuse a*b+c on x86-64, and
+// results are compared with >=.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "gtx.h"
+#include "gtx_perm.h"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+constexpr int kRounds = 10;
+
+struct PermKeys { uint32_t key[kRounds]; u64 fyw; };   // fyw: the whole n <= 16 permutation, one nibble per row
+
+__host__ __device__ inline uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+__host__ __device__ inline u64 mix64(u64 z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+
+__host__ __device__ inline void perm_keys_init(PermKeys &k, u64 seed, u64 q, uint32_t n)
+{
+  const u64 G = 0x9E3779B97F4A7C15ull;
+  u64 s = mix64(mix64(seed + G) ^ ((q + 1) * 0xD6E8FEB86659FD93ull));
+  for (int i = 0; i < kRounds; i += 2) { s += G; const u64 z = mix64(s); k.key[i] = (uint32_t)z; k.key[i + 1] = (uint32_t)(z >> 32); }
+  k.fyw = 0xFEDCBA9876543210ull;
+  if (n <= 16) {
+    uint32_t fy[16];
+    for (int i = 0; i < 16; i += 2) { s += G; const u64 z = mix64(s); fy[i] = (uint32_t)z; fy[i + 1] = (uint32_t)(z >> 32); }
+    u64 w = k.fyw;
+    for (uint32_t i = n - 1; i > 0; i--) {
+      const uint32_t j = (uint32_t)(((u64)fy[i] * (i + 1)) >> 32);
+      const u64 a = (w >> (4 * i)) & 15, b = (w >> (4 * j)) & 15;
+      w ^= ((a ^ b) << (4 * i)) | ((a ^ b) << (4 * j));
+    }
+    k.fyw = w;
+  }
+}
+
+struct PermGeom { uint32_t n, a, b; };      // n > 16: rows live on an a x b grid, a = ceil(sqrt n), b = ceil(n / a)
+
+inline PermGeom perm_geom(uint32_t n)
+{
+  PermGeom g; g.n = n;
+  uint32_t r = (uint32_t)sqrt((double)n);
+  while ((u64)r * r < n) r++;
+  while (r > 1 && (u64)(r - 1) * (r - 1) >= n) r--;
+  g.a = r; g.b = (n + r - 1) / r;
+  return g;
+}
+
+// image of grid cell (L, R) = row L * b + R under permutation k
+__host__ __device__ inline uint32_t perm_at(const PermKeys &k, const PermGeom &g, uint32_t L, uint32_t R)
+{
+  if (g.n <= 16) return (uint32_t)((k.fyw >> (4 * (L * g.b + R))) & 15);
+  uint32_t x;
+  do {
+#pragma unroll
+    for (int i = 0; i < kRounds; i += 2) {
+      L += (uint32_t)(((u64)fmix32(R + k.key[i]) * g.a) >> 32); if (L >= g.a) L -= g.a;
+      R += (uint32_t)(((u64)fmix32(L + k.key[i + 1]) * g.b) >> 32); if (R >= g.b) R -= g.b;
+    }
+    x = L * g.b + R;
+  } while (x >= g.n);                       // cycle walking: spare cells (< 2 sqrt n of them) are stepped over
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// slab writer: Vp[r * pb + j] = V[pi_(first+j)(r)]; blockIdx.x = 256 permutations, blockIdx.y = row chunk
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void perm_apply_kernel(const float *__restrict__ V, const float *__restrict__ Vt, float *__restrict__ Vp,
+                                                         float *__restrict__ Vtp, PermGeom g, uint32_t rowsPerBlock, i64 pb, u64 seed,
+                                                         i64 firstPerm, i64 nPerm)
+{
+  const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= nPerm) return;
+  PermKeys k; perm_keys_init(k, seed, (u64)(firstPerm + j), g.n);
+  const uint32_t r0 = blockIdx.y * rowsPerBlock, r1 = (uint32_t)min((u64)g.n, (u64)r0 + rowsPerBlock);
+  uint32_t L = r0 / g.b, R = r0 % g.b;            // grid cell of the row, stepped along with it
+  for (uint32_t r = r0; r < r1; r++) {
+    const uint32_t src = perm_at(k, g, L, R);
+    Vp[(size_t)r * pb + j] = V[src];
+    if (Vtp) Vtp[(size_t)r * pb + j] = Vt[src];
+    if (++R == g.b) { R = 0; L++; }
+  }
+}
+
+__global__ void perm_list_kernel(int32_t *__restrict__ out, PermGeom g, u64 seed, i64 q)
+{
+  PermKeys k; perm_keys_init(k, seed, (u64)q, g.n);
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < g.n; r += gridDim.x * blockDim.x) out[r] = (int32_t)perm_at(k, g, r / g.b, r % g.b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-category accumulators: add() in membership order, finish() = the reference's closing arithmetic
+// ---------------------------------------------------------------------------------------------
+struct StatConsts { double Vsum, VsumZ, Vsum2, VtotalSum; i64 nRows; i64 tAll; int under; };
+
+template <int STAT, bool TOTALS> struct Acc;
+
+template <bool TOTALS> struct Acc<GTX_STAT_SUM, TOTALS> {                      // :487-520
+  double y = 0, yt = 0;
+  __device__ void add(float v, float vt) { y += v; if (TOTALS) yt += vt; }
+  __device__ double finish(i64 nc, const StatConsts &k) const { double r = TOTALS ? y / yt : y / nc; return k.under ? -r : r; }
+};
+
+template <int STAT, bool TOTALS> struct AccCount {                              // :341-413
+  i64 kk = 0; int under;
+  __device__ void add(float v, float) { kk += under ? v < 0 : v > 0; }
+  __device__ double finish(i64 nc, const StatConsts &k) const
+  {
+    return STAT == GTX_STAT_N ? (double)kk : STAT == GTX_STAT_SENS ? (double)kk / nc : (double)kk / k.tAll;
+  }
+};
+template <bool TOTALS> struct Acc<GTX_STAT_N, TOTALS> : AccCount<GTX_STAT_N, TOTALS> {};
+template <bool TOTALS> struct Acc<GTX_STAT_SENS, TOTALS> : AccCount<GTX_STAT_SENS, TOTALS> {};
+template <bool TOTALS> struct Acc<GTX_STAT_SPEC, TOTALS> : AccCount<GTX_STAT_SPEC, TOTALS> {};
+
+template <int STAT> struct AccMoments {                                          // no totals: :288-307, :430-447
+  double m1 = 0, v1 = 0;
+  __device__ void add(float v, float) { m1 += v; v1 += v * v; }                  // float product, as in the reference
+  __device__ double finish(i64 nc, const StatConsts &k) const
+  {
+    i64 n[2]; double mean[2], var[2];
+    n[1] = nc; mean[1] = m1; var[1] = v1;
+    n[0] = k.nRows - n[1]; mean[0] = k.Vsum - mean[1]; var[0] = k.Vsum2 - var[1];
+    for (int i = 0; i <= 1; i++) { mean[i] /= n[i]; var[i] = var[i] / n[i] - mean[i] * mean[i]; }
+    if (STAT == GTX_STAT_RATIO) return k.under ? mean[0] / mean[1] : mean[1] / mean[0];
+    const double y = (mean[1] - mean[0]) / sqrt(var[1] / n[1] + var[0] / n[0]);
+    return k.under ? -y : y;
+  }
+};
+template <> struct Acc<GTX_STAT_RATIO, false> : AccMoments<GTX_STAT_RATIO> {};
+template <> struct Acc<GTX_STAT_T, false> : AccMoments<GTX_STAT_T> {};
+
+template <> struct Acc<GTX_STAT_RATIO, true> {                                   // :449-470
+  double s1 = 0, t1 = 0;
+  __device__ void add(float v, float vt) { s1 += v; t1 += vt; }
+  __device__ double finish(i64, const StatConsts &k) const
+  {
+    const double t0 = k.VtotalSum - t1, s0 = k.Vsum - s1;
+    const double mean0 = s0 / t0, mean1 = s1 / t1;
+    return k.under ? mean0 / mean1 : mean1 / mean0;
+  }
+};
+
+template <> struct Acc<GTX_STAT_T, true> {                                       // :309-329
+  double s1 = 0, t1 = 0, z1 = 0, q1 = 0;
+  __device__ void add(float v, float vt)
+  {
+    s1 += v; t1 += vt; z1 += v / vt;
+    const double x = (double)v / vt;               // pow(x, 2.0) there; x*x is its correctly rounded value
+    q1 += x * x;
+  }
+  __device__ double finish(i64 nc, const StatConsts &k) const
+  {
+    i64 n[2]; double sum[2], total[2], sumZ[2], sumqZ[2], mean[2], varZ[2];
+    n[1] = nc; sum[1] = s1; total[1] = t1; sumZ[1] = z1; sumqZ[1] = q1;
+    n[0] = k.nRows - n[1]; total[0] = k.VtotalSum - total[1]; sum[0] = k.Vsum - sum[1]; sumZ[0] = k.VsumZ - sumZ[1]; sumqZ[0] = k.Vsum2 - sumqZ[1];
+    for (int i = 0; i <= 1; i++) { mean[i] = sum[i] / total[i]; const double a = sumZ[i] / n[i]; varZ[i] = sumqZ[i] / n[i] - a * a; }
+    const double y = (mean[1] - mean[0]) / sqrt(varZ[1] / n[1] + varZ[0] / n[0]);
+    return k.under ? -y : y;
+  }
+};
+
+template <bool TOTALS> struct Acc<GTX_STAT_CORR, TOTALS> {                       // :527-545, core.cpp:1535-1558
+  double Ex = 0, Ey = 0, Ex2 = 0, Ey2 = 0, Exy = 0; u64 C = 0;
+  __device__ void add(float v, float vt)
+  {
+    const double a = v, b = vt;
+    if (a == a && b == b) { C++; Ex += a; Ex2 += a * a; Ey += b; Ey2 += b * b; Exy += a * b; }
+  }
+  __device__ double finish(i64, const StatConsts &k) const
+  {
+    const double ex = Ex / C, ey = Ey / C, ex2 = Ex2 / C, ey2 = Ey2 / C, exy = Exy / C;
+    double y = (exy - ex * ey) / sqrt((ex2 - ex * ex) * (ey2 - ey * ey));
+    y = fabs(y);
+    return k.under ? 1.0 - y : y;
+  }
+};
+
+enum { MODE_STAT = 0, MODE_GE = 1, MODE_RANK = 2 };
+
+struct StatArgs {
+  const i64 *colPtr; const int32_t *rows;
+  const float *Vp, *Vtp;          // slab(s): element (r, j) at r * rowStride + j * laneStride
+  i64 rowStride; int laneStride;
+  i64 nCols, nPerm;               // permutations in this batch
+  StatConsts k;
+  const double *Yobs;             // MODE_GE
+  double *Yout;                   // MODE_STAT
+  u64 *counts;
+  const i64 *tabPtr; const double *tab; const double *sortedY;   // MODE_RANK
+  i64 colBlocks;                  // blocks per slab tile
+};
+
+constexpr int kWavesPerBlock = 4;
+
+template <int STAT, bool TOTALS, bool HASVT, int MODE>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void perm_stat_kernel(StatArgs a)
+{
+  // slab-tile-major block order: consecutive blocks work on the same 64 permutations
+  const i64 tile = (i64)blockIdx.x / a.colBlocks, cb = (i64)blockIdx.x % a.colBlocks;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const i64 c = cb * kWavesPerBlock + wave;
+  if (c >= a.nCols) return;
+  const i64 j = tile * 64 + lane;
+  const bool valid = j < a.nPerm;
+  const i64 z0 = a.colPtr[c], z1 = a.colPtr[c + 1];
+  const float *__restrict__ vp = a.Vp + j * a.laneStride;
+  const float *__restrict__ vtp = HASVT ? a.Vtp + j * a.laneStride : nullptr;
+  Acc<STAT, TOTALS> acc;
+  if constexpr (STAT == GTX_STAT_N || STAT == GTX_STAT_SENS || STAT == GTX_STAT_SPEC) acc.under = a.k.under;
+  i64 z = z0;
+  // 8 gathers in flight, accumulated in list order
+  for (; z + 8 <= z1; z += 8) {
+    float v[8], vt[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const size_t off = (size_t)a.rows[z + u] * a.rowStride;
+      v[u] = vp[off]; vt[u] = HASVT ? vtp[off] : 1.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc.add(v[u], vt[u]);
+  }
+  for (; z < z1; z++) {
+    const size_t off = (size_t)a.rows[z] * a.rowStride;
+    acc.add(vp[off], HASVT ? vtp[off] : 1.0f);
+  }
+  const i64 nc = z1 - z0;
+  if constexpr (MODE == MODE_RANK) {
+    // approximate p-value by table, then its lower bound among the sorted observed ones
+    const double val = a.tab[a.tabPtr[c] + acc.kk];
+    i64 lo = 0, hi = a.nCols;
+    while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (a.sortedY[mid] < val) lo = mid + 1; else hi = mid; }
+    if (valid && lo < a.nCols) atomicAdd(&a.counts[lo], 1ull);
+  } else {
+    const double y = acc.finish(nc, a.k);
+    if constexpr (MODE == MODE_STAT) { if (j == 0) a.Yout[c] = y; }
+    else {
+      const u64 m = __ballot(valid && y >= a.Yobs[c]);
+      if (lane == 0 && m) atomicAdd(&a.counts[c], (u64)__popcll(m));
+    }
+  }
+}
+
+template <int STAT, bool TOTALS, bool HASVT>
+hipError_t launch_stat_mode(int mode, const StatArgs &a, unsigned grid, hipStream_t st)
+{
+  if (mode == MODE_STAT) perm_stat_kernel<STAT, TOTALS, HASVT, MODE_STAT><<<grid, 64 * kWavesPerBlock, 0, st>>>(a);
+  else if (mode == MODE_GE) perm_stat_kernel<STAT, TOTALS, HASVT, MODE_GE><<<grid, 64 * kWavesPerBlock, 0, st>>>(a);
+  else if constexpr (STAT == GTX_STAT_N) perm_stat_kernel<STAT, TOTALS, HASVT, MODE_RANK><<<grid, 64 * kWavesPerBlock, 0, st>>>(a);
+  return hipGetLastError();
+}
+
+template <int STAT>
+hipError_t launch_stat_t(int mode, bool totals, bool hasVt, const StatArgs &a, unsigned grid, hipStream_t st)
+{
+  // counting statistics never read the totals; the others read them only under use_totals
+  constexpr bool counting = STAT == GTX_STAT_N || STAT == GTX_STAT_SENS || STAT == GTX_STAT_SPEC;
+  if (counting) return launch_stat_mode<STAT, false, false>(mode, a, grid, st);
+  if (STAT == GTX_STAT_CORR) return hasVt ? launch_stat_mode<STAT, true, true>(mode, a, grid, st) : launch_stat_mode<STAT, true, false>(mode, a, grid, st);
+  if (!totals) return launch_stat_mode<STAT, false, false>(mode, a, grid, st);
+  return hasVt ? launch_stat_mode<STAT, true, true>(mode, a, grid, st) : launch_stat_mode<STAT, true, false>(mode, a, grid, st);
+}
+
+hipError_t launch_stat(int stat, int mode, bool totals, bool hasVt, const StatArgs &a, hipStream_t st)
+{
+  const i64 tiles = (a.nPerm + 63) / 64;
+  const i64 blocks = tiles * a.colBlocks;
+  if (blocks <= 0) return hipSuccess;
+  if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)blocks;
+  switch (stat) {
+  case GTX_STAT_SUM: return launch_stat_t<GTX_STAT_SUM>(mode, totals, hasVt, a, grid, st);
+  case GTX_STAT_N: return launch_stat_t<GTX_STAT_N>(mode, totals, hasVt, a, grid, st);
+  case GTX_STAT_SENS: return launch_stat_t<GTX_STAT_SENS>(mode, totals, hasVt, a, grid, st);
+  case GTX_STAT_SPEC: return launch_stat_t<GTX_STAT_SPEC>(mode, totals, hasVt, a, grid, st);
+  case GTX_STAT_RATIO: return launch_stat_t<GTX_STAT_RATIO>(mode, totals, hasVt, a, grid, st);
+  case GTX_STAT_T: return launch_stat_t<GTX_STAT_T>(mode, totals, hasVt, a, grid, st);
+  case GTX_STAT_CORR: return launch_stat_t<GTX_STAT_CORR>(mode, totals, hasVt, a, grid, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+struct gtx_perm {
+  int device = 0; hipStream_t stream = nullptr;
+  std::string err;
+  i64 nRows = -1, nCols = 0, nnz = 0;
+  bool useTotals = false, hasVt = false;
+  double sums[4] = {0, 0, 0, 0};
+  i64 tPos = 0, tNeg = 0;
+  float *d_V = nullptr, *d_Vt = nullptr; i64 *d_colPtr = nullptr; int32_t *d_rows = nullptr;
+  float *d_Vp = nullptr, *d_Vtp = nullptr; size_t capSlab = 0;     // floats per slab
+  double *d_Y = nullptr; u64 *d_counts = nullptr;
+  i64 *d_tabPtr = nullptr; double *d_tab = nullptr, *d_sortedY = nullptr; size_t capTab = 0;
+  hipEvent_t ev[3] = {};
+  float applyMs = 0, statMs = 0;
+  size_t slabBytes = 1ull << 30;                                     // budget per slab batch (GTX_PERM_SLAB_MB)
+};
+
+#define PCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return GTX_E_HIP; } } while (0)
+static int pfail(gtx_perm *p, int code, const char *msg) { p->err = msg; return code; }
+
+extern "C" {
+
+int gtx_perm_create(int device, gtx_perm **out)
+{
+  if (!out) return GTX_E_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return GTX_E_HIP;   // no GPU: fail loudly, there is no CPU path
+  gtx_perm *p = new gtx_perm;
+  p->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete p; return GTX_E_HIP; }
+  for (auto &e : p->ev) if (hipEventCreate(&e) != hipSuccess) { delete p; return GTX_E_HIP; }
+  if (const char *s = getenv("GTX_PERM_SLAB_MB")) { long v = atol(s); if (v > 0) p->slabBytes = (size_t)v << 20; }
+  *out = p;
+  return GTX_OK;
+}
+
+void gtx_perm_destroy(gtx_perm *p)
+{
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  dfree(p->d_V); dfree(p->d_Vt); dfree(p->d_colPtr); dfree(p->d_rows); dfree(p->d_Vp); dfree(p->d_Vtp);
+  dfree(p->d_Y); dfree(p->d_counts); dfree(p->d_tabPtr); dfree(p->d_tab); dfree(p->d_sortedY);
+  for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
+  delete p;
+}
+
+const char *gtx_perm_last_error(const gtx_perm *p) { return p ? p->err.c_str() : "null context"; }
+
+int gtx_perm_set_table(gtx_perm *p, int64_t n_rows, int64_t n_cols, const int64_t *col_ptr, const int32_t *rows, const float *V,
+                       const float *Vtotal, const double *sums, uint32_t flags)
+{
+  if (!p) return GTX_E_ARG;
+  if (n_rows < 1 || n_rows >= 0x7fffffffll || n_cols < 0 || !col_ptr || !V || !sums) return pfail(p, GTX_E_ARG, "gtx_perm_set_table: bad argument");
+  if (col_ptr[0] != 0) return pfail(p, GTX_E_ARG, "gtx_perm_set_table: col_ptr[0] != 0");
+  for (int64_t c = 0; c < n_cols; c++) if (col_ptr[c + 1] < col_ptr[c]) return pfail(p, GTX_E_ARG, "gtx_perm_set_table: col_ptr not monotone");
+  const i64 nnz = col_ptr[n_cols];
+  if (nnz > 0 && !rows) return pfail(p, GTX_E_ARG, "gtx_perm_set_table: rows == NULL");
+  for (i64 z = 0; z < nnz; z++) if (rows[z] < 0 || rows[z] >= n_rows) return pfail(p, GTX_E_RANGE, "gtx_perm_set_table: row id out of range");
+  PCHK(p, hipSetDevice(p->device));
+  p->nRows = -1;
+  dfree(p->d_V); dfree(p->d_Vt); dfree(p->d_colPtr); dfree(p->d_rows); dfree(p->d_Y); dfree(p->d_counts);
+  PCHK(p, hipMalloc(&p->d_V, sizeof(float) * n_rows));
+  PCHK(p, hipMemcpy(p->d_V, V, sizeof(float) * n_rows, hipMemcpyHostToDevice));
+  p->hasVt = Vtotal != nullptr;
+  if (Vtotal) { PCHK(p, hipMalloc(&p->d_Vt, sizeof(float) * n_rows)); PCHK(p, hipMemcpy(p->d_Vt, Vtotal, sizeof(float) * n_rows, hipMemcpyHostToDevice)); }
+  PCHK(p, hipMalloc(&p->d_colPtr, sizeof(i64) * (n_cols + 1)));
+  PCHK(p, hipMemcpy(p->d_colPtr, col_ptr, sizeof(i64) * (n_cols + 1), hipMemcpyHostToDevice));
+  PCHK(p, hipMalloc(&p->d_rows, sizeof(int32_t) * (nnz + 1)));
+  if (nnz) PCHK(p, hipMemcpy(p->d_rows, rows, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+  PCHK(p, hipMalloc(&p->d_Y, sizeof(double) * (n_cols + 1)));
+  PCHK(p, hipMalloc(&p->d_counts, sizeof(u64) * (n_cols + 1)));
+  p->tPos = p->tNeg = 0;
+  for (int64_t r = 0; r < n_rows; r++) { p->tPos += V[r] > 0; p->tNeg += V[r] < 0; }       // t of :343-344, permutation invariant
+  for (int i = 0; i < 4; i++) p->sums[i] = sums[i];
+  p->useTotals = (flags & GTX_PERM_USE_TOTALS) != 0;
+  p->nRows = n_rows; p->nCols = n_cols; p->nnz = nnz;
+  return GTX_OK;
+}
+
+static StatArgs base_args(gtx_perm *p, int under)
+{
+  StatArgs a = {};
+  a.colPtr = p->d_colPtr; a.rows = p->d_rows; a.nCols = p->nCols;
+  a.k.Vsum = p->sums[0]; a.k.VsumZ = p->sums[1]; a.k.Vsum2 = p->sums[2]; a.k.VtotalSum = p->sums[3];
+  a.k.nRows = p->nRows; a.k.under = under ? 1 : 0; a.k.tAll = under ? p->tNeg : p->tPos;
+  a.colBlocks = (p->nCols + kWavesPerBlock - 1) / kWavesPerBlock;
+  return a;
+}
+
+static int check_stat(gtx_perm *p, int stat)
+{
+  if (p->nRows < 0) return pfail(p, GTX_E_STATE, "no table: call gtx_perm_set_table first");
+  if (stat < GTX_STAT_SUM || stat > GTX_STAT_CORR) return pfail(p, GTX_E_ARG, "unknown statistic");
+  if (stat == GTX_STAT_CORR && !p->useTotals) return pfail(p, GTX_E_ARG, "corr needs use_totals (permutation_test.cpp:532-533)");
+  return GTX_OK;
+}
+
+int gtx_perm_statistic(gtx_perm *p, int stat, int under, double *Y)
+{
+  if (!p || !Y) return GTX_E_ARG;
+  if (int rc = check_stat(p, stat)) return rc;
+  if (p->nCols == 0) return GTX_OK;
+  PCHK(p, hipSetDevice(p->device));
+  StatArgs a = base_args(p, under);
+  a.Vp = p->d_V; a.Vtp = p->d_Vt; a.rowStride = 1; a.laneStride = 0; a.nPerm = 1; a.Yout = p->d_Y;
+  PCHK(p, launch_stat(stat, MODE_STAT, p->useTotals, p->hasVt, a, p->stream));
+  PCHK(p, hipMemcpyAsync(Y, p->d_Y, sizeof(double) * p->nCols, hipMemcpyDeviceToHost, p->stream));
+  PCHK(p, hipStreamSynchronize(p->stream));
+  return GTX_OK;
+}
+
+// permutations per slab batch: a multiple of 64 within the byte budget
+static i64 batch_perms(gtx_perm *p, i64 n_perm)
+{
+  i64 pb = (i64)(p->slabBytes / (sizeof(float) * (size_t)p->nRows)) / 64 * 64;
+  if (pb < 64) pb = 64;
+  const i64 need = (n_perm + 63) / 64 * 64;
+  return pb < need ? pb : need;
+}
+
+static int run_batches(gtx_perm *p, int stat, int mode, StatArgs a, bool needVt, uint64_t seed, int64_t first_perm, int64_t n_perm)
+{
+  const i64 pb = batch_perms(p, n_perm);
+  const size_t need = (size_t)pb * (size_t)p->nRows;
+  if (need > p->capSlab || (needVt && !p->d_Vtp)) {
+    dfree(p->d_Vp); dfree(p->d_Vtp); p->capSlab = 0;
+    PCHK(p, hipMalloc(&p->d_Vp, sizeof(float) * need));
+    if (p->hasVt) PCHK(p, hipMalloc(&p->d_Vtp, sizeof(float) * need));
+    p->capSlab = need;
+  }
+  const PermGeom g = perm_geom((uint32_t)p->nRows);
+  p->applyMs = p->statMs = 0;
+  for (i64 done = 0; done < n_perm; done += pb) {
+    const i64 cnt = n_perm - done < pb ? n_perm - done : pb;
+    PCHK(p, hipEventRecord(p->ev[0], p->stream));
+    uint32_t rpb = 128;                                              // rows per block; grid.y stays below 65536
+    while ((p->nRows + rpb - 1) / rpb > 65535) rpb *= 2;
+    dim3 grid((unsigned)((cnt + 255) / 256), (unsigned)((p->nRows + rpb - 1) / rpb));
+    perm_apply_kernel<<<grid, 256, 0, p->stream>>>(p->d_V, needVt ? p->d_Vt : nullptr, p->d_Vp, needVt ? p->d_Vtp : nullptr, g, rpb, pb, seed,
+                                                    first_perm + done, cnt);
+    PCHK(p, hipGetLastError());
+    PCHK(p, hipEventRecord(p->ev[1], p->stream));
+    a.Vp = p->d_Vp; a.Vtp = needVt ? p->d_Vtp : nullptr; a.rowStride = pb; a.laneStride = 1; a.nPerm = cnt;
+    PCHK(p, launch_stat(stat, mode, p->useTotals, needVt, a, p->stream));
+    PCHK(p, hipEventRecord(p->ev[2], p->stream));
+    PCHK(p, hipEventSynchronize(p->ev[2]));
+    float t0 = 0, t1 = 0;
+    PCHK(p, hipEventElapsedTime(&t0, p->ev[0], p->ev[1]));
+    PCHK(p, hipEventElapsedTime(&t1, p->ev[1], p->ev[2]));
+    p->applyMs += t0; p->statMs += t1;
+  }
+  return GTX_OK;
+}
+
+// the totals slab is needed only by the statistics that read Vtotal
+static bool stat_reads_totals(const gtx_perm *p, int stat)
+{
+  if (!p->hasVt) return false;
+  if (stat == GTX_STAT_N || stat == GTX_STAT_SENS || stat == GTX_STAT_SPEC) return false;
+  return stat == GTX_STAT_CORR || p->useTotals;
+}
+
+int gtx_perm_count_ge(gtx_perm *p, int stat, int under, const double *Y, uint64_t seed, int64_t first_perm, int64_t n_perm, uint64_t *counts)
+{
+  if (!p || !counts || !Y) return GTX_E_ARG;
+  if (int rc = check_stat(p, stat)) return rc;
+  if (first_perm < 0 || n_perm < 0) return pfail(p, GTX_E_ARG, "gtx_perm_count_ge: negative permutation range");
+  for (i64 c = 0; c < p->nCols; c++) counts[c] = 0;
+  if (p->nCols == 0 || n_perm == 0) return GTX_OK;
+  PCHK(p, hipSetDevice(p->device));
+  PCHK(p, hipMemcpyAsync(p->d_Y, Y, sizeof(double) * p->nCols, hipMemcpyHostToDevice, p->stream));
+  PCHK(p, hipMemsetAsync(p->d_counts, 0, sizeof(u64) * p->nCols, p->stream));
+  StatArgs a = base_args(p, under);
+  a.Yobs = p->d_Y; a.counts = p->d_counts;
+  if (int rc = run_batches(p, stat, MODE_GE, a, stat_reads_totals(p, stat), seed, first_perm, n_perm)) return rc;
+  PCHK(p, hipMemcpyAsync(counts, p->d_counts, sizeof(u64) * p->nCols, hipMemcpyDeviceToHost, p->stream));
+  PCHK(p, hipStreamSynchronize(p->stream));
+  return GTX_OK;
+}
+
+int gtx_perm_count_rank(gtx_perm *p, int under, const int64_t *tab_ptr, const double *tab, const double *sortedY, uint64_t seed,
+                        int64_t first_perm, int64_t n_perm, uint64_t *counts)
+{
+  if (!p || !counts || !tab_ptr || !tab || !sortedY) return GTX_E_ARG;
+  if (int rc = check_stat(p, GTX_STAT_N)) return rc;
+  if (first_perm < 0 || n_perm < 0) return pfail(p, GTX_E_ARG, "gtx_perm_count_rank: negative permutation range");
+  for (i64 c = 0; c < p->nCols; c++) counts[c] = 0;
+  if (p->nCols == 0 || n_perm == 0) return GTX_OK;
+  // every category's table must cover k = 0 .. n_c
+  std::vector<i64> colPtr(p->nCols + 1);
+  PCHK(p, hipSetDevice(p->device));
+  PCHK(p, hipMemcpy(colPtr.data(), p->d_colPtr, sizeof(i64) * (p->nCols + 1), hipMemcpyDeviceToHost));
+  for (i64 c = 0; c < p->nCols; c++)
+    if (tab_ptr[c] < 0 || tab_ptr[c + 1] - tab_ptr[c] < colPtr[c + 1] - colPtr[c] + 1) return pfail(p, GTX_E_ARG, "gtx_perm_count_rank: table shorter than n_c + 1");
+  const size_t nTab = (size_t)tab_ptr[p->nCols];
+  if (nTab > p->capTab || !p->d_tabPtr) {
+    dfree(p->d_tab); dfree(p->d_tabPtr); dfree(p->d_sortedY); p->capTab = 0;
+    PCHK(p, hipMalloc(&p->d_tab, sizeof(double) * (nTab + 1)));
+    PCHK(p, hipMalloc(&p->d_tabPtr, sizeof(i64) * (p->nCols + 1)));
+    PCHK(p, hipMalloc(&p->d_sortedY, sizeof(double) * (p->nCols + 1)));
+    p->capTab = nTab;
+  }
+  PCHK(p, hipMemcpyAsync(p->d_tab, tab, sizeof(double) * nTab, hipMemcpyHostToDevice, p->stream));
+  PCHK(p, hipMemcpyAsync(p->d_tabPtr, tab_ptr, sizeof(i64) * (p->nCols + 1), hipMemcpyHostToDevice, p->stream));
+  PCHK(p, hipMemcpyAsync(p->d_sortedY, sortedY, sizeof(double) * p->nCols, hipMemcpyHostToDevice, p->stream));
+  PCHK(p, hipMemsetAsync(p->d_counts, 0, sizeof(u64) * p->nCols, p->stream));
+  StatArgs a = base_args(p, under);
+  a.counts = p->d_counts; a.tabPtr = p->d_tabPtr; a.tab = p->d_tab; a.sortedY = p->d_sortedY;
+  if (int rc = run_batches(p, GTX_STAT_N, MODE_RANK, a, false, seed, first_perm, n_perm)) return rc;
+  PCHK(p, hipMemcpyAsync(counts, p->d_counts, sizeof(u64) * p->nCols, hipMemcpyDeviceToHost, p->stream));
+  PCHK(p, hipStreamSynchronize(p->stream));
+  return GTX_OK;
+}
+
+int gtx_perm_permutation(gtx_perm *p, uint64_t seed, int64_t q, int32_t *out)
+{
+  if (!p || !out || q < 0) return GTX_E_ARG;
+  if (p->nRows < 0) return pfail(p, GTX_E_STATE, "no table: call gtx_perm_set_table first");
+  PCHK(p, hipSetDevice(p->device));
+  int32_t *d = nullptr;
+  PCHK(p, hipMalloc(&d, sizeof(int32_t) * p->nRows));
+  perm_list_kernel<<<256, 256, 0, p->stream>>>(d, perm_geom((uint32_t)p->nRows), seed, q);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof(int32_t) * p->nRows, hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  (void)hipFree(d);
+  PCHK(p, e);
+  return GTX_OK;
+}
+
+int gtx_perm_last_ms(gtx_perm *p, float *apply_ms, float *stat_ms)
+{
+  if (!p) return GTX_E_ARG;
+  if (apply_ms) *apply_ms = p->applyMs;
+  if (stat_ms) *stat_ms = p->statMs;
+  return GTX_OK;
+}
+
+}  // extern "C"

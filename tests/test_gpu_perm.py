@@ -1,0 +1,207 @@
+"""Parity of the permutation-test path on the MI355X (include/gtx_perm.h, through the C ABI) against the CPU
+restatement oracle/perm_oracle.c: permutations, statistics and exceed-counts bit for bit (same seed,
+same permutation definition, same summation order); the CLI byte for byte."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gtx import perm
+from oracle import porc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, "ibm-cbc-genomic-tools_amd", "csrc", "permutation_test")
+STATS = ["sum", "n", "sens", "spec", "ratio", "t", "corr"]
+
+
+@pytest.fixture(scope="module")
+def pe():
+    e = perm.PermEngine(0)
+    yield e
+    e.close()
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.array_equal(a.view(np.uint64), b.view(np.uint64)) or (np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]))
+
+
+def tables():
+    """(name, table): the three shapes of StringSets -- one value per row (use_totals with all totals 1),
+    two values (use_totals with real totals), two values normalised (-norm: no totals)."""
+    yield "one-value", perm.PermTable.synthetic(3000, 150, 40, seed=1, values="gamma")
+    yield "binary", perm.PermTable.synthetic(2500, 120, 30, seed=2, values="binary")
+    yield "signed", perm.PermTable.synthetic(1000, 60, 25, seed=3, values="signed")
+    yield "totals", perm.PermTable.synthetic(2000, 100, 35, seed=4, values="normal", totals=True)
+    t = perm.PermTable.synthetic(2000, 100, 35, seed=5, values="gamma", totals=True)
+    yield "normalised", perm.PermTable(t.n_rows, t.col_ptr, t.rows, (t.V / t.Vtotal).astype(np.float32), None, use_totals=False)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 16, 17, 31, 64, 100, 1000, 65537, 300001])
+def test_permutation_matches_definition(pe, n):
+    pe.set_table(perm.PermTable(n, [0, 1], [0], np.zeros(n)))
+    for seed, q in ((0, 0), (12345, 7), (2**63 + 5, 10**9)):
+        got = pe.permutation(seed, q)
+        np.testing.assert_array_equal(got, porc.permutation(seed, q, n))
+        assert np.array_equal(np.sort(got), np.arange(n))
+
+
+@pytest.mark.parametrize("under", [False, True])
+def test_observed_statistics_bit_exact(pe, under):
+    for name, t in tables():
+        pe.set_table(t)
+        for stat in STATS:
+            if stat == "corr" and not t.use_totals:
+                continue
+            got, want = pe.statistic(stat, under), porc.statistic(t, stat, under)
+            assert same_bits(got, want), "%s %s under=%s: max diff %g" % (name, stat, under, np.nanmax(np.abs(got - want)))
+
+
+@pytest.mark.parametrize("under", [False, True])
+def test_exceed_counts_bit_exact(pe, under):
+    for name, t in tables():
+        pe.set_table(t)
+        for stat in STATS:
+            if stat == "corr" and not t.use_totals:
+                continue
+            Y = porc.statistic(t, stat, under)
+            got = pe.count_ge(stat, Y, seed=99, first_perm=0, n_perm=150, under=under)
+            want = porc.count_ge(t, stat, Y, 99, 0, 150, under)
+            np.testing.assert_array_equal(got, want, err_msg="%s %s under=%s" % (name, stat, under))
+            assert got.max() <= 150
+
+
+def test_permutation_range_shards_add_up(pe):
+    t = perm.PermTable.synthetic(5000, 200, 50, seed=8, values="normal")
+    pe.set_table(t)
+    Y = pe.statistic("sum")
+    whole = pe.count_ge("sum", Y, 5, 0, 1000)
+    parts = sum(pe.count_ge("sum", Y, 5, a, b - a).astype(np.int64) for a, b in ((0, 1), (1, 64), (64, 65), (65, 700), (700, 1000)))
+    np.testing.assert_array_equal(whole.astype(np.int64), parts)
+    np.testing.assert_array_equal(whole, porc.count_ge(t, "sum", Y, 5, 0, 1000))
+    assert pe.count_ge("sum", Y, 5, 0, 0).sum() == 0
+
+
+def test_small_slab_budget_batches_give_the_same_counts(pe):
+    t = perm.PermTable.synthetic(40000, 100, 60, seed=9, values="gamma", totals=True)
+    pe.set_table(t)
+    Y = pe.statistic("t")
+    want = pe.count_ge("t", Y, 21, 0, 500)
+    os.environ["GTX_PERM_SLAB_MB"] = "16"                  # 16 MiB / (40000 rows x 4 B) -> 64 permutations per batch
+    try:
+        e2 = perm.PermEngine(0)
+    finally:
+        del os.environ["GTX_PERM_SLAB_MB"]
+    e2.set_table(t)
+    np.testing.assert_array_equal(e2.count_ge("t", Y, 21, 0, 500), want)
+    e2.close()
+
+
+def test_tiny_tables(pe):
+    # 1..17 rows, categories of every size incl. the whole table and an empty one
+    for n in (1, 2, 5, 16, 17):
+        rows, ptr = [], [0]
+        for size in [0, 1, n, max(1, n // 2)]:
+            rows += list(range(size)); ptr.append(len(rows))
+        t = perm.PermTable(n, ptr, rows if rows else [0], np.arange(n) - 1.5)
+        t.rows = np.ascontiguousarray(rows, dtype=np.int32)
+        pe.set_table(t)
+        for stat in ("sum", "n", "t"):
+            Y = porc.statistic(t, stat)
+            assert same_bits(pe.statistic(stat), Y)
+            np.testing.assert_array_equal(pe.count_ge(stat, Y, 3, 0, 100), porc.count_ge(t, stat, Y, 3, 0, 100))
+
+
+@pytest.mark.parametrize("under", [False, True])
+def test_approx_rank_histogram(pe, under):
+    t = perm.PermTable.synthetic(3000, 180, 30, seed=11, values="signed")
+    pe.set_table(t)
+    tab_ptr, tab = porc.hypergeom_table(t, under)
+    k = porc.statistic(t, "n", under).astype(np.int64)
+    sorted_y = np.sort(tab[tab_ptr[:-1] + k], kind="stable")
+    got = pe.count_rank(tab_ptr, tab, sorted_y, 17, 0, 300, under)
+    np.testing.assert_array_equal(got, porc.count_rank(t, tab_ptr, tab, sorted_y, 17, 0, 300, under))
+    assert got.sum() <= 300 * t.n_cols
+
+
+def test_p_values_estimate_the_exact_hypergeometric_tail(pe):
+    """-S n: P(k_perm >= k_obs) is a hypergeometric tail; 20000 permutations must land within 5 binomial
+    standard errors of it for every category (statistical check of the permutation source on the device)."""
+    from scipy import stats
+    t = perm.PermTable.synthetic(4000, 120, 40, seed=13, values="binary")
+    pe.set_table(t)
+    k = pe.statistic("n")
+    P = 20000
+    p_hat = pe.count_ge("n", k, 2024, 0, P) / P
+    n1 = np.diff(t.col_ptr); pos = int((t.V > 0).sum())
+    exact = stats.hypergeom.sf(k - 1, t.n_rows, n1, pos)
+    se = np.sqrt(np.maximum(exact * (1 - exact), 1e-9) / P)
+    assert np.all(np.abs(p_hat - exact) < 5 * se + 2.0 / P), np.max(np.abs(p_hat - exact) / se)
+
+
+def run_both(args, seed):
+    env = dict(os.environ, GTX_PERM_SEED=str(seed))
+    a = subprocess.run([CLI] + args, capture_output=True, env=env)
+    b = porc.run_cli(args, env={"GTX_PERM_SEED": str(seed)})
+    return a, b
+
+
+@pytest.mark.parametrize("args", [
+    ["-h", "-S", "n", "-p", "300", "-q", "0.5"],
+    ["-S", "sum", "-p", "200"],
+    ["-S", "sum", "-u", "-p", "100", "-f"],
+    ["-h", "-S", "sens", "-p", "100", "-kmin", "20"],
+    ["-S", "spec", "-p", "100", "-kmin", "5", "-kmax", "40"],
+    ["-S", "ratio", "-p", "150", "-d", "-q", "0.3"],
+    ["-S", "t", "-p", "150"],
+    ["-h", "-S", "n", "-a", "-p", "200", "-q", "0.05"],
+    ["-S", "n", "-a", "-u", "-p", "100"],
+])
+def test_cli_matches_oracle_cli_one_value_table(args):
+    a, b = run_both(args + [os.path.join(GOLD, "perm_go.txt")], seed=42)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr.decode() + b.stderr.decode()
+    assert a.stdout == b.stdout
+    assert len(a.stdout.splitlines()) > 3
+
+
+@pytest.mark.parametrize("args", [
+    ["-S", "sum", "-p", "100"],
+    ["-S", "ratio", "-p", "100", "-u"],
+    ["-S", "t", "-p", "100"],
+    ["-S", "corr", "-p", "100"],
+    ["-S", "corr", "-u", "-p", "50"],
+    ["-norm", "-S", "t", "-p", "100"],
+    ["-norm", "-S", "ratio", "-p", "100"],
+    ["-norm", "-S", "sum", "-v", "-p", "64"],
+])
+def test_cli_matches_oracle_cli_two_value_table(args):
+    a, b = run_both(args + [os.path.join(GOLD, "perm_go2.txt")], seed=7)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr.decode() + b.stderr.decode()
+    assert a.stdout == b.stdout
+    assert a.stderr == b.stderr
+    assert len(a.stdout.splitlines()) > 3
+
+
+def test_cli_values_from_second_file(tmp_path):
+    lines = open(os.path.join(GOLD, "perm_go.txt")).read().splitlines()
+    cats, vals = tmp_path / "cats.txt", tmp_path / "vals.txt"
+    cats.write_text("".join("%s\t%s\n" % (l.split("\t")[0], l.split("\t")[2]) for l in lines))
+    vals.write_text("".join("%s\n" % l.split("\t")[1] for l in lines))
+    a1, b1 = run_both(["-S", "n", "-p", "100", str(cats), str(vals)], seed=5)
+    a2, _ = run_both(["-S", "n", "-p", "100", os.path.join(GOLD, "perm_go.txt")], seed=5)
+    assert a1.returncode == 0, a1.stderr.decode()
+    assert a1.stdout == b1.stdout == a2.stdout
+
+
+def test_cli_errors_like_the_reference():
+    f = os.path.join(GOLD, "perm_go.txt")
+    a, b = run_both(["-S", "bogus", f], 1)
+    assert a.returncode == 1 and a.stderr == b.stderr == b"Error: unknown statistic 'bogus'!\n"
+    a, b = run_both(["-norm", "-S", "corr", os.path.join(GOLD, "perm_go2.txt")], 1)
+    assert a.returncode == 1 and a.stderr == b.stderr == b"Error: this operation is not permitted!\n"
+    a, _ = run_both(["-S", "sum", "-a", f], 1)
+    assert a.returncode == 1 and a.stderr == b"Error: not implemented yet!\n"
