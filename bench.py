@@ -127,6 +127,79 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse):
         dist.destroy_process_group()
 
 
+def bench_perm(args, rank, world, local, device, rehearse):
+    """BASELINE config 5, second half: permutation_test with 10k shuffles of a GO-like table (20k rows, 5k
+    categories, ~1M memberships) per GPU; ranks take disjoint permutation ranges, exceed-counts are all-reduced."""
+    from gtx import perm
+    n_rows, n_cols, mean_size, P = 20000, 5000, 200, args.shuffles
+    t = perm.PermTable.synthetic(n_rows, n_cols, mean_size, seed=1, values="gamma")
+    nnz = int(t.col_ptr[-1])
+    e = perm.PermEngine(local)
+    e.set_table(t)
+    Y = e.statistic("sum")
+    acc = torch.zeros(n_cols, dtype=torch.int64, device="cpu" if rehearse else device)
+    ms = []
+
+    def step():
+        c = e.count_ge("sum", Y, 2024, rank * P, P)                      # this rank's shuffles: [rank*P, (rank+1)*P)
+        ms.append(e.last_ms())
+        if world > 1:
+            acc.copy_(torch.from_numpy(c.view(np.int64)))
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        return c
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    del ms[:]
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    apply_ms = float(np.mean([m[0] for m in ms])); stat_ms = float(np.mean([m[1] for m in ms]))
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle import porc
+        ps = 24                                                            # ~10-20 s of the scalar restatement
+        t1 = time.perf_counter()
+        want = porc.count_ge(t, "sum", Y, 2024, 0, ps)
+        cpu_s = time.perf_counter() - t1
+        if not np.array_equal(e.count_ge("sum", Y, 2024, 0, ps), want) or not np.array_equal(Y.view(np.uint64), porc.statistic(t, "sum").view(np.uint64)):
+            sys.exit("PARITY FAILURE: GPU exceed-counts differ from the CPU oracle on the %d-shuffle sample" % ps)
+        cpu = {"value": nnz * ps / cpu_s, "unit": "member-sums/s", "cores": 1, "kind": "port",
+               "sample": "first %d shuffles of the same table, oracle/perm_oracle.c (permute + per-category sums + compare); "
+                         "counts bit-equal to the GPU's" % ps}
+    if rank == 0:
+        alg = 4.0 * nnz * P                                               # one 4-byte slab element per (membership, shuffle)
+        print(json.dumps({
+            "metric": "category-member sums/sec, permutation_test -S sum, 10k shuffles (BASELINE config 5)",
+            "value": world * nnz * P * args.steps / elapsed, "unit": "member-sums/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5 (permutation_test part): %d shuffles/GPU of a %d-row x %d-category table with %d "
+                                   "memberships, statistic sum, all-reduce(sum) of the exceed-counts" % (P, n_rows, n_cols, nnz),
+                       "shuffles_per_gpu": P, "rows": n_rows, "categories": n_cols, "memberships": nnz},
+            "roofline": {"bound": "hbm", "achieved": alg / (stat_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (stat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "perm_stat_kernel",
+                         "kernel_ms": stat_ms, "apply_kernel_ms": apply_ms, "algorithmic_bytes": alg,
+                         "note": "slab tiles are re-read from L2/Infinity Cache, so the gather stream can exceed the HBM peak"},
+            "cpu_baseline": cpu}))
+    e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,8 +208,10 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
     ap.add_argument("--refs", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="reads given to the CPU baseline (0 = skip)")
-    ap.add_argument("--workload", choices=["count", "scans"], default="count",
-                    help="count = BASELINE config 3 (the headline metric); scans = config 4: genomic_scans counts -i -w 1000 -d 1000")
+    ap.add_argument("--workload", choices=["count", "scans", "permutation_test"], default="count",
+                    help="count = BASELINE config 3 (the headline metric); scans = config 4: genomic_scans counts -i -w 1000 -d 1000; "
+                         "permutation_test = the shuffle part of config 5")
+    ap.add_argument("--shuffles", type=int, default=10000, help="permutation_test: shuffles per GPU per step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,6 +234,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    if args.workload == "permutation_test":
+        return bench_perm(args, rank, world, local, device, rehearse)
 
     # ---- workload -------------------------------------------------------------------------------
     refs = synth.genome_intervals(args.refs, 43, 50, 2000)                 # 1M refs, all chromosomes, every rank

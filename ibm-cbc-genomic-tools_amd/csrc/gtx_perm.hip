@@ -14,8 +14,8 @@
 //                       order -- the reference's summation order, so the statistic is bit-identical to
 //                       the CPU restatement -- then finishes the statistic, compares and the wave adds
 //                       popcount(ballot) to the category's counter.
-// Blocks are ordered slab-tile-major so that the blocks in flight share a few 64-permutation tiles
-// of the slab (n_rows x 256 B each) through L2 / Infinity Cache.
+// The slab is stored in tiles of 64 permutations (n_rows x 256 B each); every XCD walks its own sequence
+// of tiles, all categories of a tile before the next, so a tile is pulled into ONE L2 and re-read there.
 // Bound: slab bytes moved = 4 B x (membership entries) x (permutations) -- an HBM/L2 gather stream; the
 // double adds are ~1/10 of the FP64 rate at that bandwidth.  No MFMA: the 0/1 membership matrix is ~1%
 // dense, a dense contraction would do 100x the work.
@@ -89,11 +89,13 @@ __host__ __device__ inline uint32_t perm_at(const PermKeys &k, const PermGeom &g
 }
 
 // ---------------------------------------------------------------------------------------------
-// slab writer: Vp[r * pb + j] = V[pi_(first+j)(r)]; blockIdx.x = 256 permutations, blockIdx.y = row chunk
+// slab writer.  Slab layout: tiles of 64 permutations, tile t = [n_rows][64] floats (one 256-byte line per row),
+// element (row r, permutation j) at ((j / 64) * n_rows + r) * 64 + j % 64.  Vp(r, j) = V[pi_(first+j)(r)];
+// blockIdx.x = 256 permutations, blockIdx.y = row chunk
 // ---------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void perm_apply_kernel(const float *__restrict__ V, const float *__restrict__ Vt, float *__restrict__ Vp,
-                                                         float *__restrict__ Vtp, PermGeom g, uint32_t rowsPerBlock, i64 pb, u64 seed,
+                                                         float *__restrict__ Vtp, PermGeom g, uint32_t rowsPerBlock, u64 seed,
                                                          i64 firstPerm, i64 nPerm)
 {
   const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -103,8 +105,9 @@ __global__ __launch_bounds__(256) void perm_apply_kernel(const float *__restrict
   uint32_t L = r0 / g.b, R = r0 % g.b;            // grid cell of the row, stepped along with it
   for (uint32_t r = r0; r < r1; r++) {
     const uint32_t src = perm_at(k, g, L, R);
-    Vp[(size_t)r * pb + j] = V[src];
-    if (Vtp) Vtp[(size_t)r * pb + j] = Vt[src];
+    const size_t at = ((size_t)(j >> 6) * g.n + r) * 64 + (j & 63);
+    Vp[at] = V[src];
+    if (Vtp) Vtp[at] = Vt[src];
     if (++R == g.b) { R = 0; L++; }
   }
 }
@@ -207,8 +210,7 @@ enum { MODE_STAT = 0, MODE_GE = 1, MODE_RANK = 2 };
 
 struct StatArgs {
   const i64 *colPtr; const int32_t *rows;
-  const float *Vp, *Vtp;          // slab(s): element (r, j) at r * rowStride + j * laneStride
-  i64 rowStride; int laneStride;
+  const float *Vp, *Vtp;          // slab(s) in the tile layout above, or (MODE_STAT) the plain value vectors
   i64 nCols, nPerm;               // permutations in this batch
   StatConsts k;
   const double *Yobs;             // MODE_GE
@@ -223,16 +225,24 @@ constexpr int kWavesPerBlock = 4;
 template <int STAT, bool TOTALS, bool HASVT, int MODE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void perm_stat_kernel(StatArgs a)
 {
-  // slab-tile-major block order: consecutive blocks work on the same 64 permutations
-  const i64 tile = (i64)blockIdx.x / a.colBlocks, cb = (i64)blockIdx.x % a.colBlocks;
+  // Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8), and every XCD has its own
+  // 4 MiB L2.  Each XCD therefore walks its own sequence of slab tiles (64 permutations = n_rows x 256 B),
+  // all categories of one tile before the next, so that a tile is pulled into ONE L2 and re-read there.
+  const i64 xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const i64 tile = xcd + 8 * (idx / a.colBlocks), cb = idx % a.colBlocks;
+  if (tile * 64 >= a.nPerm) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const i64 c = cb * kWavesPerBlock + wave;
   if (c >= a.nCols) return;
   const i64 j = tile * 64 + lane;
   const bool valid = j < a.nPerm;
   const i64 z0 = a.colPtr[c], z1 = a.colPtr[c + 1];
-  const float *__restrict__ vp = a.Vp + j * a.laneStride;
-  const float *__restrict__ vtp = HASVT ? a.Vtp + j * a.laneStride : nullptr;
+  // byte offset of (row r, this lane) inside the tile: 32 bits (n_rows < 2^24), so that a gather is one
+  // v_lshl_add_u32 + one global_load with a scalar base.  MODE_STAT reads the unpermuted vectors: row r at r * 4.
+  constexpr int kRowShift = MODE == MODE_STAT ? 2 : 8;
+  const uint32_t laneOff = MODE == MODE_STAT ? 0u : (uint32_t)lane * 4u;
+  const char *__restrict__ vp = (const char *)(a.Vp + (MODE == MODE_STAT ? 0 : (size_t)tile * a.k.nRows * 64));
+  const char *__restrict__ vtp = HASVT ? (const char *)(a.Vtp + (MODE == MODE_STAT ? 0 : (size_t)tile * a.k.nRows * 64)) : nullptr;
   Acc<STAT, TOTALS> acc;
   if constexpr (STAT == GTX_STAT_N || STAT == GTX_STAT_SENS || STAT == GTX_STAT_SPEC) acc.under = a.k.under;
   i64 z = z0;
@@ -241,15 +251,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void perm_stat_kernel(StatArgs
     float v[8], vt[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const size_t off = (size_t)a.rows[z + u] * a.rowStride;
-      v[u] = vp[off]; vt[u] = HASVT ? vtp[off] : 1.0f;
+      const uint32_t off = ((uint32_t)a.rows[z + u] << kRowShift) + laneOff;
+      v[u] = *(const float *)(vp + off); vt[u] = HASVT ? *(const float *)(vtp + off) : 1.0f;
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) acc.add(v[u], vt[u]);
   }
   for (; z < z1; z++) {
-    const size_t off = (size_t)a.rows[z] * a.rowStride;
-    acc.add(vp[off], HASVT ? vtp[off] : 1.0f);
+    const uint32_t off = ((uint32_t)a.rows[z] << kRowShift) + laneOff;
+    acc.add(*(const float *)(vp + off), HASVT ? *(const float *)(vtp + off) : 1.0f);
   }
   const i64 nc = z1 - z0;
   if constexpr (MODE == MODE_RANK) {
@@ -285,13 +295,15 @@ hipError_t launch_stat_t(int mode, bool totals, bool hasVt, const StatArgs &a, u
   if (counting) return launch_stat_mode<STAT, false, false>(mode, a, grid, st);
   if (STAT == GTX_STAT_CORR) return hasVt ? launch_stat_mode<STAT, true, true>(mode, a, grid, st) : launch_stat_mode<STAT, true, false>(mode, a, grid, st);
   if (!totals) return launch_stat_mode<STAT, false, false>(mode, a, grid, st);
+  // sum over all-ones totals: the total is the member count, exactly -- the no-totals form divides by the same number
+  if (STAT == GTX_STAT_SUM && !hasVt) return launch_stat_mode<STAT, false, false>(mode, a, grid, st);
   return hasVt ? launch_stat_mode<STAT, true, true>(mode, a, grid, st) : launch_stat_mode<STAT, true, false>(mode, a, grid, st);
 }
 
 hipError_t launch_stat(int stat, int mode, bool totals, bool hasVt, const StatArgs &a, hipStream_t st)
 {
   const i64 tiles = (a.nPerm + 63) / 64;
-  const i64 blocks = tiles * a.colBlocks;
+  const i64 blocks = 8 * ((tiles + 7) / 8) * a.colBlocks;             // 8 XCD lanes of ceil(tiles / 8) tiles each
   if (blocks <= 0) return hipSuccess;
   if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
   const unsigned grid = (unsigned)blocks;
@@ -367,7 +379,7 @@ int gtx_perm_set_table(gtx_perm *p, int64_t n_rows, int64_t n_cols, const int64_
                        const float *Vtotal, const double *sums, uint32_t flags)
 {
   if (!p) return GTX_E_ARG;
-  if (n_rows < 1 || n_rows >= 0x7fffffffll || n_cols < 0 || !col_ptr || !V || !sums) return pfail(p, GTX_E_ARG, "gtx_perm_set_table: bad argument");
+  if (n_rows < 1 || n_rows >= (1ll << 24) || n_cols < 0 || !col_ptr || !V || !sums) return pfail(p, GTX_E_ARG, "gtx_perm_set_table: bad argument");
   if (col_ptr[0] != 0) return pfail(p, GTX_E_ARG, "gtx_perm_set_table: col_ptr[0] != 0");
   for (int64_t c = 0; c < n_cols; c++) if (col_ptr[c + 1] < col_ptr[c]) return pfail(p, GTX_E_ARG, "gtx_perm_set_table: col_ptr not monotone");
   const i64 nnz = col_ptr[n_cols];
@@ -419,7 +431,7 @@ int gtx_perm_statistic(gtx_perm *p, int stat, int under, double *Y)
   if (p->nCols == 0) return GTX_OK;
   PCHK(p, hipSetDevice(p->device));
   StatArgs a = base_args(p, under);
-  a.Vp = p->d_V; a.Vtp = p->d_Vt; a.rowStride = 1; a.laneStride = 0; a.nPerm = 1; a.Yout = p->d_Y;
+  a.Vp = p->d_V; a.Vtp = p->d_Vt; a.nPerm = 1; a.Yout = p->d_Y;
   PCHK(p, launch_stat(stat, MODE_STAT, p->useTotals, p->hasVt, a, p->stream));
   PCHK(p, hipMemcpyAsync(Y, p->d_Y, sizeof(double) * p->nCols, hipMemcpyDeviceToHost, p->stream));
   PCHK(p, hipStreamSynchronize(p->stream));
@@ -453,11 +465,11 @@ static int run_batches(gtx_perm *p, int stat, int mode, StatArgs a, bool needVt,
     uint32_t rpb = 128;                                              // rows per block; grid.y stays below 65536
     while ((p->nRows + rpb - 1) / rpb > 65535) rpb *= 2;
     dim3 grid((unsigned)((cnt + 255) / 256), (unsigned)((p->nRows + rpb - 1) / rpb));
-    perm_apply_kernel<<<grid, 256, 0, p->stream>>>(p->d_V, needVt ? p->d_Vt : nullptr, p->d_Vp, needVt ? p->d_Vtp : nullptr, g, rpb, pb, seed,
+    perm_apply_kernel<<<grid, 256, 0, p->stream>>>(p->d_V, needVt ? p->d_Vt : nullptr, p->d_Vp, needVt ? p->d_Vtp : nullptr, g, rpb, seed,
                                                     first_perm + done, cnt);
     PCHK(p, hipGetLastError());
     PCHK(p, hipEventRecord(p->ev[1], p->stream));
-    a.Vp = p->d_Vp; a.Vtp = needVt ? p->d_Vtp : nullptr; a.rowStride = pb; a.laneStride = 1; a.nPerm = cnt;
+    a.Vp = p->d_Vp; a.Vtp = needVt ? p->d_Vtp : nullptr; a.nPerm = cnt;
     PCHK(p, launch_stat(stat, mode, p->useTotals, needVt, a, p->stream));
     PCHK(p, hipEventRecord(p->ev[2], p->stream));
     PCHK(p, hipEventSynchronize(p->ev[2]));

@@ -66,7 +66,7 @@ const char *gtx_perm_last_error(const gtx_perm *p);
  *                                             each in the order the reference fills it (ascending row)
  *   V[n_rows], Vtotal[n_rows]                 per-row values; Vtotal == NULL means all 1
  *   sums[4]                                   Vsum, VsumZ, Vsum2, Vtotal_sum as the constructor computes them
- * n_rows < 2^31; the table is copied to the device. */
+ * n_rows < 2^24 (a 64-permutation slab tile is addressed with 32-bit byte offsets); the table is copied to the device. */
 int gtx_perm_set_table(gtx_perm *p, int64_t n_rows, int64_t n_cols, const int64_t *col_ptr, const int32_t *rows,
                        const float *V, const float *Vtotal, const double *sums, uint32_t flags);
 

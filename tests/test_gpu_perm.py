@@ -205,3 +205,11 @@ def test_cli_errors_like_the_reference():
     assert a.returncode == 1 and a.stderr == b.stderr == b"Error: this operation is not permitted!\n"
     a, _ = run_both(["-S", "sum", "-a", f], 1)
     assert a.returncode == 1 and a.stderr == b"Error: not implemented yet!\n"
+
+
+def test_cli_reader_rules_match_oracle(tmp_path):
+    f = tmp_path / "t.txt"
+    f.write_text("g1\t1\ta b \ng2\t0\ta  b  \ng3\t1\ta a\n   g5 \t 2 \t b   c\ng4\t5\tb")
+    for args in (["-kmin", "1", "-S", "n", "-p", "50", "-h"], ["-kmin", "1", "-kmax", "10", "-S", "sum", "-p", "64", "-d"]):
+        a, b = run_both(args + [str(f)], seed=4)
+        assert a.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 10
