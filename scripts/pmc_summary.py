@@ -8,5 +8,5 @@ for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True))
         acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("==", f)
     for k, cs in acc.items():
-        if not k.startswith(("void gtx", "gtx")): continue
+        if "gtx" not in k and "perm_" not in k: continue
         print("  ", k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "n=%d" % len(next(iter(cs.values()))))
