@@ -180,6 +180,12 @@ def bench_perm(args, rank, world, local, device, rehearse):
         cpu = {"value": nnz * ps / cpu_s, "unit": "member-sums/s", "cores": 1, "kind": "port",
                "sample": "first %d shuffles of the same table, oracle/perm_oracle.c (permute + per-category sums + compare); "
                          "counts bit-equal to the GPU's" % ps}
+    traffic = None                                                        # L2->fabric bytes per launch from the committed --pmc pass of this command
+    if P == 10000:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_perm_stat.json")))
+        if cand:
+            traffic = json.load(open(cand[-1])).get("traffic_bytes_per_launch")
     if rank == 0:
         alg = 4.0 * nnz * P                                               # one 4-byte slab element per (membership, shuffle)
         print(json.dumps({
@@ -191,9 +197,10 @@ def bench_perm(args, rank, world, local, device, rehearse):
                                    "memberships, statistic sum, all-reduce(sum) of the exceed-counts" % (P, n_rows, n_cols, nnz),
                        "shuffles_per_gpu": P, "rows": n_rows, "categories": n_cols, "memberships": nnz},
             "roofline": {"bound": "hbm", "achieved": alg / (stat_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (stat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "perm_stat_kernel",
+                         "frac": alg / (stat_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": "perm_stat_kernel",
                          "kernel_ms": stat_ms, "apply_kernel_ms": apply_ms, "algorithmic_bytes": alg,
-                         "note": "slab tiles are re-read from L2/Infinity Cache, so the gather stream can exceed the HBM peak"},
+                         "note": "slab tiles are re-read from the XCD's L2 (hit rate 0.69), so the gathered bytes exceed what reaches the "
+                                 "fabric (traffic, includes Infinity-Cache hits) and the rate can exceed the HBM peak"},
             "cpu_baseline": cpu}))
     e.close()
     if world > 1:

@@ -66,3 +66,33 @@ def test_lpt_balance_for_eight_ranks():
 def test_apportion_is_exact():
     for total in (0, 1, 999, 100_000_000):
         assert int(synth.apportion(total, synth.CHROM_LEN).sum()) == total
+
+
+# ---- permutation_test: ranks take disjoint shuffle ranges, exceed-counts are summed ---------------------
+def _perm_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gtx import perm
+        from oracle import porc
+        t = perm.PermTable.synthetic(600, 40, 20, seed=5, values="gamma")
+        Y = porc.statistic(t, "sum")
+        P = 90                                                   # shuffles per rank
+        c = porc.count_ge(t, "sum", Y, 77, rank * P, P)          # stand-in for gtx_perm_count_ge (same first_perm / n_perm contract)
+        acc = torch.from_numpy(c.view(np.int64).copy())
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            np.save(out, acc.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_split_the_shuffles(tmp_path):
+    from gtx import perm
+    from oracle import porc
+    out = str(tmp_path / "perm_counts.npy")
+    mp.spawn(_perm_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    t = perm.PermTable.synthetic(600, 40, 20, seed=5, values="gamma")
+    want = porc.count_ge(t, "sum", porc.statistic(t, "sum"), 77, 0, 180)
+    np.testing.assert_array_equal(np.load(out), want.view(np.int64))
