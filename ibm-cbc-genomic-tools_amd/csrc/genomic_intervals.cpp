@@ -58,6 +58,16 @@ GenomicInterval::GenomicInterval(const char *chromosome, char strand, long int s
 GenomicInterval::~GenomicInterval() { delete[] CHROMOSOME; }
 
 void GenomicInterval::PrintInterval() { printf("%s %c %ld %ld", CHROMOSOME, STRAND, START, STOP); }
+
+int GenomicInterval::CalcDirection(GenomicInterval *i, bool sorted_by_strand)
+{
+  const int by_chrom = strcmp(CHROMOSOME, i->CHROMOSOME);
+  if (by_chrom != 0) return by_chrom;
+  if (sorted_by_strand && STRAND != i->STRAND) return STRAND - i->STRAND;
+  if (i->STOP < START) return 1;
+  if (STOP < i->START) return -1;
+  return 0;
+}
 void GenomicInterval::PrintInterval(FILE *f) { fprintf(f, "%s %c %ld %ld", CHROMOSOME, STRAND, START, STOP); }
 
 GenomicRegion::GenomicRegion() : n_line(0), LABEL(NULL) {}
@@ -221,6 +231,20 @@ GenomicRegion *GenomicRegionSet::Next(bool retain_current)
   cur_raw = line;
   R[0] = new GenomicRegionBED(line, src->line_no());
   return R[0];
+}
+
+GenomicRegion *GenomicRegionSet::Next(bool sorted_by_strand, bool retain_current)
+{
+  GenomicRegion *r0 = Get();
+  if (r0 == NULL) return NULL;
+  GenomicRegion *r = Next(true);
+  if (r != NULL && r->IsBefore(r0, sorted_by_strand))
+    r->PrintError(std::string("input regions are not sorted (sorted-by-strand = ") + (sorted_by_strand ? "true" : "false") + ")!");
+  if (!load_in_memory) {
+    if (!retain_current) delete r0;
+    if (r == NULL) { R[0] = NULL; n_regions = 0; }            // end of the stream: Get() answers NULL from now on
+  }
+  return r;
 }
 
 LineSource *GenomicRegionSet::DetachStream(std::string *current_line, long int *current_line_no)
@@ -565,6 +589,87 @@ GenomicInterval *GenomicRegionSetScanner::GetInterval()
   const int ns = ignore_strand ? 1 : 2;
   return new GenomicInterval(chrom_names[cur_block / ns].c_str(), (cur_block % ns) ? '-' : '+', win_step * (cur_win - 1) + 1,
                              win_step * (cur_win - 1) + win_size);
+}
+
+// reference filter of `genomic_scans counts -r`: windows are produced by the GPU scan as always; which of them
+// are reported is a host-side question per window (at most one rank query or one merge step each)
+long int GenomicRegionSetScanner::Next(GenomicRegionSet *Ref)
+{
+  if (Ref == NULL) return Next();
+  GenomicRegion *q = Ref->Get();
+  const bool sorted_by_strand = !ignore_strand;
+  while (q != NULL) {
+    const long int c = Next();
+    if (c == -1) return -1;
+    const int ns = ignore_strand ? 1 : 2;
+    GenomicInterval w(chrom_names[cur_block / ns].c_str(), (cur_block % ns) ? '-' : '+', win_step * (cur_win - 1) + 1, win_step * (cur_win - 1) + win_size);
+    while (q != NULL) {
+      const int d = q->I.front()->CalcDirection(&w, sorted_by_strand);
+      if (d < 0) q = Ref->Next(sorted_by_strand, false);
+      else if (d == 0) return c;
+      else break;
+    }
+  }
+  return -1;
+}
+
+long int GenomicRegionSetScanner::Next(GenomicRegionSetIndex *index)
+{
+  if (index == NULL) return Next();
+  while (true) {
+    const long int c = Next();
+    if (c == -1) return -1;
+    const int ns = ignore_strand ? 1 : 2;
+    GenomicInterval w(chrom_names[cur_block / ns].c_str(), (cur_block % ns) ? '-' : '+', win_step * (cur_win - 1) + 1, win_step * (cur_win - 1) + win_size);
+    if (index->GetOverlap(&w, false, ignore_strand) != NULL) return c;
+  }
+}
+
+// ---- GenomicRegionSetIndex ---------------------------------------------------------------------------
+struct GenomicRegionSetIndex::Impl {
+  struct Track { std::vector<long> start; std::vector<long> max_stop; std::vector<long> arg; };   // sorted by start; running max of stop
+  std::map<std::string, Track> by_chrom[3];                       // 0: '+', 1: '-', 2: both strands
+};
+
+GenomicRegionSetIndex::GenomicRegionSetIndex(GenomicRegionSet *regSet, const char *)
+{
+  this->regSet = regSet;
+  impl = new Impl;
+  if (!regSet->load_in_memory) regSet->PrintError("[GenomicRegionSetIndex] the region set must be loaded in memory!");
+  struct Item { long start, stop, k; };
+  std::map<std::string, std::vector<Item>> items[3];
+  for (long k = 0; k < regSet->n_regions; k++) {
+    GenomicRegion *r = regSet->R[k];
+    if (r->I.size() != 1) r->PrintError("multi-interval regions are outside the MI355X path!");
+    GenomicInterval *i = r->I.front();
+    if (i->STOP <= 0 || i->START > i->STOP) continue;              // never found (genomic_intervals.cpp:5659)
+    items[i->STRAND == '-' ? 1 : 0][i->CHROMOSOME].push_back({i->START, i->STOP, k});
+    items[2][i->CHROMOSOME].push_back({i->START, i->STOP, k});
+  }
+  for (int s = 0; s < 3; s++)
+    for (auto &kv : items[s]) {
+      std::stable_sort(kv.second.begin(), kv.second.end(), [](const Item &a, const Item &b) { return a.start < b.start; });
+      Impl::Track &t = impl->by_chrom[s][kv.first];
+      long best = LONG_MIN, who = -1;
+      for (const Item &it : kv.second) {
+        if (it.stop > best) { best = it.stop; who = it.k; }
+        t.start.push_back(it.start); t.max_stop.push_back(best); t.arg.push_back(who);
+      }
+    }
+}
+
+GenomicRegionSetIndex::~GenomicRegionSetIndex() { delete impl; }
+
+GenomicRegion *GenomicRegionSetIndex::GetOverlap(GenomicInterval *i, bool, bool ignore_strand)
+{
+  const auto &m = impl->by_chrom[ignore_strand ? 2 : (i->STRAND == '-' ? 1 : 0)];
+  auto it = m.find(i->CHROMOSOME);
+  if (it == m.end()) return NULL;
+  const Impl::Track &t = it->second;
+  // regions with start <= i->STOP; among them the largest stop must reach i->START
+  const size_t n = (size_t)(std::upper_bound(t.start.begin(), t.start.end(), i->STOP) - t.start.begin());
+  if (n == 0 || t.max_stop[n - 1] < i->START) return NULL;
+  return regSet->R[t.arg[n - 1]];
 }
 
 SortedGenomicRegionSetScanner::SortedGenomicRegionSetScanner(GenomicRegionSet *R, StringLIntMap *bounds, long int win_step, long int win_size,

@@ -12,8 +12,9 @@
 // error of the reference (genomic_intervals.cpp:1001-1006).
 //
 // Scope: BED3..BED6 single-interval regions.  REG/SAM/GFF/SEQ input, BED12
-// blocks, the ~45 Run*/Print* text transforms of GenomicRegionSet, GenomicRegionSetIndex and the
-// per-pair enumeration (GetMatch/NextMatch) are outside the path.
+// blocks, the ~45 Run*/Print* text transforms of GenomicRegionSet, GenomicRegionSetIndex beyond the
+// "does anything overlap" query of the scanners' reference filter, and the per-pair enumeration
+// (GetMatch/NextMatch) are outside the path.
 #ifndef GTX_GENOMIC_INTERVALS_H
 #define GTX_GENOMIC_INTERVALS_H
 
@@ -37,6 +38,7 @@ class GenomicInterval
   void PrintInterval();
   void PrintInterval(FILE *file_ptr);
   size_t GetSize() { return (size_t)(STOP - START + 1); }
+  int CalcDirection(GenomicInterval *i, bool sorted_by_strand);   // <0 before i, 0 overlapping, >0 after (genomic_intervals.cpp:448-459)
 
   char *CHROMOSOME;
   char STRAND;
@@ -80,6 +82,7 @@ class GenomicRegionSet
 
   GenomicRegion *Get();                                           // genomic_intervals.cpp:3845-3849
   GenomicRegion *Next(bool retain_current = false);               // :3855-3867
+  GenomicRegion *Next(bool sorted_by_strand, bool retain_current); // same + order check (:3874-3882)
   void Reset();
   void PrintError(std::string error_msg);                         // "\nError: msg\n", exit(1)
 
@@ -168,6 +171,22 @@ class SortedGenomicRegionSetOverlaps : public GenomicRegionSetOverlaps
   bool sorted_by_strand;
 };
 
+// ---- GenomicRegionSetIndex (genomic_intervals.h:2505) -- only what the scanners' reference filter uses ---
+// "does any region of the (in-memory) set overlap this interval": per chromosome [and strand] the regions
+// sorted by start with a running maximum of their stops.  The bin levels of the reference (bin_bits) are an
+// implementation detail of its search and have no observable effect; NextOverlap enumeration is outside the path.
+class GenomicRegionSetIndex
+{
+ public:
+  GenomicRegionSetIndex(GenomicRegionSet *regSet, const char *bin_bits = NULL);
+  ~GenomicRegionSetIndex();
+  GenomicRegion *GetOverlap(GenomicInterval *i, bool match_gaps, bool ignore_strand);   // an overlapping region or NULL (:5687-5711)
+  GenomicRegionSet *regSet;
+ private:
+  struct Impl;
+  Impl *impl;
+};
+
 // ---- scanners (genomic_intervals.h:2196, 2274, 2330) ---------------------------------------------------
 class GenomicRegionSetScanner
 {
@@ -179,6 +198,8 @@ class GenomicRegionSetScanner
   void PrintInterval(FILE *out_file = stdout);                    // "chr strand start stop" of the current window
   GenomicInterval *GetInterval();                                 // heap object owned by the caller
   long int Next();                                                // next window's value, -1 at the end
+  long int Next(GenomicRegionSet *Ref);                           // ... of the next window that overlaps a region of the sorted set (:4960-4977, :5144-5163)
+  long int Next(GenomicRegionSetIndex *index);                    // ... of the indexed set (:4982-4991, :5168-5178)
 
   GenomicRegionSet *R;
   StringLIntMap *bounds;

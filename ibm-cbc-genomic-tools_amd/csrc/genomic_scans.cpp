@@ -2,7 +2,7 @@
 // (reference driver: gtools/genomic_scans.cpp:73-150 options, :399-436 RunCounts, :449-462).
 // Sliding-window read counts over the chromosomes of a genome file; the histogram + window sums
 // run on the GPU behind the reference's GenomicRegionSetScanner classes.  `peaks` (GSL tail
-// probabilities) and the -r reference filter are outside this path.
+// probabilities) is outside this path; the -r reference filter is a host-side test per reported window.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,7 +35,7 @@ int main(int argc, char *argv[])
   opts.Flag("-S", &SORTED, "input regions are sorted");
   opts.Flag("-Sref", &REF_SORTED, "reference regions (option -r) are sorted");
   opts.Str("-g", &GENOME_REG_FILE, "", "genome region file");
-  opts.Str("-r", &REF_REG_FILE, "", "reference region file (outside the MI355X path)");
+  opts.Str("-r", &REF_REG_FILE, "", "reference region file");
   opts.Flag("-i", &IGNORE_STRAND, "ignore strand information");
   opts.Char("-op", &PREPROCESS, '1', "preprocess operator (1=start, c=center)");
   opts.Long("--max-label-value", &MAX_LABEL_VALUE, 1, "maximum region label value to be used");
@@ -45,7 +45,6 @@ int main(int argc, char *argv[])
   int next_arg = opts.Parse(argc, argv, 2);
   if (HELP || HELP2) { opts.Usage(PROGRAM, "counts", "[OPTIONS] <REG-FILE>"); return 1; }
   _MESSAGES_ = VERBOSE;
-  if (strlen(REF_REG_FILE) > 0) { fprintf(stderr, "Error: the -r reference filter is outside the MI355X path of this build!\n"); return 1; }
 
   char *INPUT_REG_FILE = next_arg == argc ? NULL : argv[next_arg];
   StringLIntMap *bounds = ReadBounds((char *)GENOME_REG_FILE, false);
@@ -53,7 +52,17 @@ int main(int argc, char *argv[])
   GenomicRegionSetScanner *scanner;
   if (SORTED) scanner = new SortedGenomicRegionSetScanner(&InputRegSet, bounds, WIN_DIST, WIN_SIZE, MAX_LABEL_VALUE, IGNORE_STRAND, PREPROCESS);
   else scanner = new UnsortedGenomicRegionSetScanner(&InputRegSet, bounds, WIN_DIST, WIN_SIZE, MAX_LABEL_VALUE, IGNORE_STRAND, PREPROCESS);
-  for (long int v = scanner->Next(); v != -1; v = scanner->Next()) {
+  // reference regions (-r): report only the windows that overlap one of them (genomic_scans.cpp:411-420)
+  GenomicRegionSet *RefRegSet = NULL;
+  GenomicRegionSetIndex *RefIndex = NULL;
+  if (strlen(REF_REG_FILE) > 0) {
+    if (REF_SORTED) RefRegSet = new GenomicRegionSet((char *)REF_REG_FILE, BUFFER_SIZE, VERBOSE, false, true);
+    else {
+      RefRegSet = new GenomicRegionSet((char *)REF_REG_FILE, BUFFER_SIZE, VERBOSE, true, true);
+      RefIndex = new GenomicRegionSetIndex(RefRegSet, "17,20,23,26");
+    }
+  }
+  for (long int v = REF_SORTED ? scanner->Next(RefRegSet) : scanner->Next(RefIndex); v != -1; v = REF_SORTED ? scanner->Next(RefRegSet) : scanner->Next(RefIndex)) {
     if (v >= MIN_READS) {
       printf("%ld\t", v);
       scanner->PrintInterval();
@@ -62,5 +71,7 @@ int main(int argc, char *argv[])
   }
   delete scanner;
   delete bounds;
+  delete RefIndex;
+  delete RefRegSet;
   return 0;
 }

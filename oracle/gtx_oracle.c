@@ -776,21 +776,60 @@ int orc_scan_packed(const int32_t *reads, const int32_t *weights, int64_t n, con
 /*        genomic_scans.cpp:108-121 (options), :399-436 (RunCounts)                            */
 /* ------------------------------------------------------------------------------------------ */
 #ifdef ORC_MAIN
-typedef struct { orc_chroms *ch; const orc_bounds *b; long min_reads; } cli_emit_ctx;
+static void die(void) { fflush(stdout); fprintf(stderr, "%s\n", g_err); exit(1); }
+
+/* reference filter of `counts -r` (genomic_scans.cpp:411-420): mode 1 = Next(GenomicRegionSetIndex*) over the
+ * in-memory set's bin index (genomic_intervals.cpp:4982-4991 / :5168-5178), mode 2 = Next(GenomicRegionSet*) merging
+ * with a sorted streamed set (:4960-4977 / :5144-5163) */
+typedef struct {
+  orc_chroms *ch; const orc_bounds *b; long min_reads;
+  int mode, ign, done;
+  orc_set refset; orc_binindex bx; orc_pull pull;
+} cli_emit_ctx;
+
+static int window_reported(cli_emit_ctx *e, int chrom, char strand, long start, long stop)
+{
+  if (e->mode == 0) return 1;
+  if (e->done) return 0;
+  if (e->mode == 1) {                                                             /* GetOverlap(&w, false, ignore_strand) != NULL */
+    if (!(chrom >= 0 && chrom < e->bx.n_chrom && e->bx.head[chrom])) return 0;
+    orc_region w; memset(&w, 0, sizeof w); w.chrom = chrom; w.strand = strand; w.n_iv = 1; w.iv1[0] = start; w.iv1[1] = stop;
+    long s = start <= 0 ? 1 : start, en = stop;
+    long *nb = e->bx.nbins[chrom];
+    if ((s >> e->bx.bits[0]) >= nb[0]) return 0;
+    for (int l = 0; l < e->bx.n_levels; l++) {
+      long b0 = s >> e->bx.bits[l], b1 = en >> e->bx.bits[l];
+      if (b1 > nb[l] - 1) b1 = nb[l] - 1;
+      for (long bb = b0; bb <= b1; bb++)
+        for (long z = e->bx.head[chrom][l][bb]; z != -1; z = e->bx.next[z]) {
+          const orc_region *r = &e->refset.R[z];
+          if (s <= back_stop(r) && en >= front_start(r) && accept_overlap(e->ch, &w, r, 0, e->ign)) return 1;
+        }
+    }
+    return 0;
+  }
+  while (e->pull.have) {                                                          /* q->CalcDirection(&w, !ignore_strand) */
+    int d = region_direction(e->ch, &e->pull.cur, chrom, strand, start, stop, !e->ign);
+    if (d < 0) { pull_next(&e->pull); if (e->pull.err) die(); }
+    else return d == 0;
+  }
+  e->done = 1;                                                                    /* the set ran out: Next(Ref) answers -1 */
+  return 0;
+}
+
 static void cli_emit(void *c, long value, int bidx, char strand, long start, long stop)
 {
   cli_emit_ctx *e = c;
+  if (!window_reported(e, e->b->chrom[bidx], strand, start, stop)) return;
   if (value >= e->min_reads) printf("%ld\t%s %c %ld %ld\n", value, e->ch->names[e->b->chrom[bidx]], strand, start, stop);   /* genomic_scans.cpp:422-426 */
 }
-
-static void die(void) { fflush(stdout); fprintf(stderr, "%s\n", g_err); exit(1); }
 
 int main(int argc, char **argv)
 {
   if (argc < 2) { fprintf(stderr, "usage: gtx_oracle count|rpkm|counts [OPTIONS] FILES\n"); return 1; }
   const char *op = argv[1]; if (op[0] == '-') op++;                                /* genomic_overlaps.cpp:180-182 */
   int sorted = 0, by_strand = 0, ign = 0, gaps = 0; long mlv = 1; const char *bits = "17,20,23,26";
-  unsigned long min_count = 0; long min_reads = 10, win = 500, dist = 25; char prep = '1'; const char *genome = "";
+  unsigned long min_count = 0; long min_reads = 10, win = 500, dist = 25; char prep = '1'; const char *genome = "", *ref_file = ""; int ref_sorted = 0;
   int is_scan = !strcmp(op, "counts");
   int is_cov = !strcmp(op, "coverage") || !strcmp(op, "density");
   double min_density = 0.0;
@@ -808,6 +847,8 @@ int main(int argc, char **argv)
     else if (!strcmp(o, "--max-label-value")) { NEEDVAL(); mlv = atol(argv[++a]); }
     else if (!strcmp(o, "-min")) { NEEDVAL(); ++a; if (is_scan) min_reads = atol(argv[a]); else if (!strcmp(op, "count") || !strcmp(op, "coverage")) min_count = strtoul(argv[a], NULL, 10); else if (!strcmp(op, "density")) min_density = atof(argv[a]); }
     else if (is_scan && !strcmp(o, "-g")) { NEEDVAL(); genome = argv[++a]; }
+    else if (is_scan && !strcmp(o, "-r")) { NEEDVAL(); ref_file = argv[++a]; }
+    else if (is_scan && !strcmp(o, "-Sref")) ref_sorted = 1;
     else if (is_scan && !strcmp(o, "-w")) { NEEDVAL(); win = atol(argv[++a]); }
     else if (is_scan && !strcmp(o, "-d")) { NEEDVAL(); dist = atol(argv[++a]); }
     else if (is_scan && !strcmp(o, "-op")) { NEEDVAL(); prep = argv[++a][0]; }
@@ -872,8 +913,21 @@ int main(int argc, char **argv)
     }
   orc_reader rd; if (reader_open(&rd, a < argc ? argv[a] : NULL)) die();
   orc_source src; memset(&src, 0, sizeof src); src.chroms = &ch; src.rd = &rd;
+  cli_emit_ctx e; memset(&e, 0, sizeof e); e.ch = &ch; e.b = &b; e.min_reads = min_reads; e.ign = ign;
+  orc_reader rrd; orc_source rsrc;
+  if (ref_file[0]) {
+    if (ref_sorted) {                                                              /* streamed, order checked as it is consumed */
+      if (reader_open(&rrd, ref_file)) die();
+      memset(&rsrc, 0, sizeof rsrc); rsrc.chroms = &ch; rsrc.rd = &rrd;
+      e.mode = 2; e.pull.chroms = &ch; e.pull.src = &rsrc; e.pull.by_strand = !ign;
+      pull_next(&e.pull); if (e.pull.err) die();
+    } else {
+      if (set_load_bed(&ch, ref_file, &e.refset)) die();
+      if (binindex_build(&ch, &e.refset, "17,20,23,26", &e.bx)) die();
+      e.mode = 1;
+    }
+  }
   if (sorted) {
-    cli_emit_ctx e = { &ch, &b, min_reads };
     if (scan_sorted(&ch, &src, &b, dist, win, mlv, ign, prep, cli_emit, &e)) die();
   } else {
     uint64_t **v;
@@ -881,8 +935,7 @@ int main(int argc, char **argv)
     int ns = ign ? 1 : 2;
     for (int i = 0; i < b.n; i++) for (int z = 0; z < ns; z++) {                   /* Next/PrintInterval :5111, :5125-5141 */
       uint64_t *arr = v[i * ns + z];
-      for (uint64_t k = 1; k <= arr[0]; k++)
-        if ((long)arr[k] >= min_reads) printf("%ld\t%s %c %ld %ld\n", (long)arr[k], ch.names[b.chrom[i]], z ? '-' : '+', dist * ((long)k - 1) + 1, dist * ((long)k - 1) + win);
+      for (uint64_t k = 1; k <= arr[0]; k++) cli_emit(&e, (long)arr[k], i, z ? '-' : '+', dist * ((long)k - 1) + 1, dist * ((long)k - 1) + win);
     }
   }
   reader_close(&rd);

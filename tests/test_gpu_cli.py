@@ -85,6 +85,17 @@ def beds(tmp_path_factory):
     write_bed(d / "scan_pos.bed", small, names, None, sstr)
     o2 = np.lexsort((small[:, 1], sstr == "-", small[:, 0]))
     write_bed(d / "scan_strand.bed", small[o2], names, None, sstr[o2])
+    # reference regions for `counts -r` in the scaled genome: sorted by (chrom,start), by (chrom,strand,start), shuffled
+    sref = synth.genome_intervals(400, 34, 200, 60000)
+    sref[:, 1:] = sref[:, 1:] // 50 + 1
+    sref = sref[np.lexsort((sref[:, 1], sref[:, 0]))]
+    sref = sref[sref[:, 0] != 5]                                                     # one chromosome without reference regions
+    rs = rng.choice(["+", "-"], size=len(sref))
+    write_bed(d / "scan_refs.bed", sref, names, ["r%d" % i for i in range(len(sref))], rs)
+    o3 = np.lexsort((sref[:, 1], rs == "-", sref[:, 0]))
+    write_bed(d / "scan_refs_strand.bed", sref[o3], names, ["r%d" % i for i in o3], rs[o3])
+    p3 = rng.permutation(len(sref))
+    write_bed(d / "scan_refs_shuffled.bed", sref[p3], names, ["r%d" % i for i in p3], rs[p3])
     return d
 
 
@@ -138,6 +149,15 @@ SCAN_RUNS = [
     (["counts", "-i", "-op", "c", "-g", "genome.bed", "-w", "2000", "-d", "500", "-min", "2", "scan_pos.bed"]),
     (["counts", "-i", "-g", "genome.bed", "scan_pos.bed"]),                          # defaults -w 500 -d 25 -min 10
     (["counts", "-S", "-g", "genome.bed", "-w", "1000", "-d", "1000", "-min", "1", "scan_pos.bed"]),   # wrong order for strand-aware -S
+    # -r: only windows that overlap a reference region (index of an in-memory set / merge with a sorted stream)
+    (["counts", "-i", "-g", "genome.bed", "-r", "scan_refs_shuffled.bed", "-w", "1000", "-d", "1000", "-min", "1", "scan_pos.bed"]),
+    (["counts", "-g", "genome.bed", "-r", "scan_refs_shuffled.bed", "-w", "500", "-d", "25", "-min", "2", "scan_strand.bed"]),
+    (["counts", "-S", "-i", "-g", "genome.bed", "-r", "scan_refs.bed", "-w", "500", "-d", "100", "-min", "1", "scan_pos.bed"]),
+    (["counts", "-i", "-Sref", "-g", "genome.bed", "-r", "scan_refs.bed", "-w", "1000", "-d", "1000", "-min", "1", "scan_pos.bed"]),
+    (["counts", "-S", "-i", "-Sref", "-g", "genome.bed", "-r", "scan_refs.bed", "-w", "500", "-d", "25", "-min", "2", "scan_pos.bed"]),
+    (["counts", "-Sref", "-g", "genome.bed", "-r", "scan_refs_strand.bed", "-w", "500", "-d", "25", "-min", "2", "scan_strand.bed"]),
+    (["counts", "-i", "-Sref", "-g", "genome.bed", "-r", "scan_refs_shuffled.bed", "-w", "1000", "-d", "1000", "-min", "1", "scan_pos.bed"]),   # -Sref on unsorted regions
+    (["counts", "-Sref", "-g", "genome.bed", "-r", "scan_refs.bed", "-w", "1000", "-d", "1000", "-min", "1", "scan_strand.bed"]),              # sorted by start, not by strand
 ]
 
 
@@ -150,6 +170,8 @@ def test_scans_cli_equals_oracle_cli(beds, args):
         assert got[1] == want[1]
     else:
         assert got[2].strip() == want[2].strip()
+        if "-Sref" in args:
+            assert got[1] == want[1]                 # windows reported before the unsorted reference region was reached
 
 
 # ---- G1: the reference's own example data, examples/genes.bed.gz (4785 overlapping,
@@ -244,3 +266,21 @@ def test_no_gpu_free_paths_fail_loudly(tmp_path):
     assert rc == 1 and "Unknown operation" in err
     rc, out, err = product("overlaps", ["count", "-Q", "refs.bed"], cwd=tmp_path)
     assert rc == 1 and "unknown option '-Q'" in err
+
+
+def test_scans_reference_filter_keeps_exactly_the_overlapping_windows(beds):
+    base = ["counts", "-i", "-g", "genome.bed", "-w", "1000", "-d", "500", "-min", "1"]
+    allw = product("scans", base + ["scan_pos.bed"], cwd=beds)[1].splitlines()
+    kept = product("scans", base + ["-r", "scan_refs_shuffled.bed", "scan_pos.bed"], cwd=beds)[1].splitlines()
+    kept2 = product("scans", base + ["-Sref", "-r", "scan_refs.bed", "scan_pos.bed"], cwd=beds)[1].splitlines()
+    assert kept == kept2 and 0 < len(kept) < len(allw)
+    refs = {}
+    for l in open(beds / "scan_refs.bed"):
+        c, s, e = l.split("\t")[:3]
+        refs.setdefault(c, []).append((int(s) + 1, int(e)))
+
+    def overlaps(line):
+        _, iv = line.split("\t")
+        c, _, s, e = iv.split(" ")
+        return any(rs <= int(e) and int(s) <= re for rs, re in refs.get(c, []))
+    assert [l for l in allw if overlaps(l)] == kept
