@@ -516,7 +516,7 @@ GenomicRegionSetScanner::GenomicRegionSetScanner(GenomicRegionSet *R, StringLInt
   this->max_label_value = max_label_value; this->ignore_strand = ignore_strand; this->preprocess = preprocess;
   if (win_step <= 0 || win_size % win_step != 0) { std::cerr << "Error: window size must be a multiple of window step in 'GenomicRegionSetScanner'!\n"; exit(1); }
   n_win_combine = win_size / win_step;
-  cur_block = 0; cur_win = 0; computed = false;
+  cur_block = 0; cur_win = 0; computed = false; total_label_value = 0;
 }
 
 GenomicRegionSetScanner::~GenomicRegionSetScanner() {}
@@ -557,6 +557,7 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
   DrainSet(R, opt, [&](const PackedBatch &b) {
     if (sorted_rules && preprocess != '1') { fprintf(stderr, "Error: [SortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
     if (!sorted_rules && preprocess != '1' && preprocess != 'c') { fprintf(stderr, "Error: [UnsortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
+    total_label_value += (long int)b.label_sum;
     tri.insert(tri.end(), b.tri.begin(), b.tri.end());
     w.insert(w.end(), b.w.begin(), b.w.end());
   });
@@ -565,6 +566,19 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
   CheckGtx(ctx, gtx_scan(ctx, tri.data(), w.empty() ? NULL : w.data(), (int64_t)(tri.size() / 3), class_len.data(), n_chrom * ns,
                          (int32_t)win_step, (int32_t)win_size, prep, sorted_rules ? GTX_ZERO_LENGTH_OK : 0,
                          (uint64_t *)values.data(), class_off.data()));
+}
+
+long int GenomicRegionSetScanner::TotalLabelValue()
+{
+  if (!computed) Compute(false);
+  return total_label_value;
+}
+
+unsigned long int CalcBoundSize(StringLIntMap *bounds)
+{
+  unsigned long int y = 0;
+  for (StringLIntMap::iterator x = bounds->begin(); x != bounds->end(); x++) y += (unsigned long int)x->second;
+  return y;
 }
 
 long int GenomicRegionSetScanner::Next()

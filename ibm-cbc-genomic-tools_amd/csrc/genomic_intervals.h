@@ -198,6 +198,9 @@ class GenomicRegionSetScanner
   void PrintInterval(FILE *out_file = stdout);                    // "chr strand start stop" of the current window
   GenomicInterval *GetInterval();                                 // heap object owned by the caller
   long int Next();                                                // next window's value, -1 at the end
+  // MI355X path: sum of GetLabelValue(max_label_value) over every region of the input, collected by the same pass that
+  // fills the windows -- what the reference gets from a separate read of the file (CountGenomicRegions, :6206-6214)
+  long int TotalLabelValue();
   long int Next(GenomicRegionSet *Ref);                           // ... of the next window that overlaps a region of the sorted set (:4960-4977, :5144-5163)
   long int Next(GenomicRegionSetIndex *index);                    // ... of the indexed set (:4982-4991, :5168-5178)
 
@@ -216,6 +219,7 @@ class GenomicRegionSetScanner
   size_t cur_block;
   long int cur_win;                                               // 1-based inside the block
   bool computed;
+  long int total_label_value;
 };
 
 class SortedGenomicRegionSetScanner : public GenomicRegionSetScanner
@@ -231,6 +235,8 @@ class UnsortedGenomicRegionSetScanner : public GenomicRegionSetScanner
   UnsortedGenomicRegionSetScanner(GenomicRegionSet *R, StringLIntMap *bounds, long int win_step, long int win_size, long int max_label_value,
                                   bool ignore_strand, char preprocess);
 };
+
+unsigned long int CalcBoundSize(StringLIntMap *bounds);          // sum of the chromosome lengths (genomic_intervals.cpp:6021-6026)
 
 // chromosome -> length from a genome region file (genomic_intervals.cpp:5997-6015)
 StringLIntMap *ReadBounds(char *genome_reg_file, bool verbose = false);

@@ -226,6 +226,7 @@ struct Piece {                       // one thread's share of a block
   std::vector<int32_t> tri, w, zero_len;
   std::vector<int32_t> tri_minus, w_minus;   // strand-aware runs: '-' reads are grouped behind the '+' reads of the batch
   PackError err;
+  int64_t label_sum = 0;
   // order-check context of the regions in this piece
   bool any = false;
   std::string first_chrom, last_chrom; char first_strand = '+', last_strand = '+';
@@ -291,6 +292,9 @@ void ParsePiece(Piece *p, const PackOptions &o)
     if (cache_id == -2 || cache_name != f.chrom) { cache_name = f.chrom; cache_id = o.chroms->Find(f.chrom); }
     const int id = cache_id;
     bool zero_len = false;
+    long wv = 1;                                                         // GetLabelValue (genomic_intervals.cpp:1081-1085)
+    if (weighted) { long v = f.label ? FastAtol(f.label) : 0; wv = v < o.max_label_value ? v : o.max_label_value; }
+    p->label_sum += wv;
     switch (o.mode) {
       case PACK_OVERLAPS_UNSORTED:
         if (id < 0) continue;                                            // unknown chromosome: never validated
@@ -315,8 +319,7 @@ void ParsePiece(Piece *p, const PackOptions &o)
     const int32_t cls = (int32_t)(id + (minus ? n_chrom : 0));
     std::vector<int32_t> &dst = minus ? p->tri_minus : p->tri;
     dst.push_back(cls); dst.push_back((int32_t)f.start); dst.push_back((int32_t)f.stop);
-    long wv = 1;
-    if (weighted) { long v = f.label ? FastAtol(f.label) : 0; wv = v < o.max_label_value ? v : o.max_label_value; (minus ? p->w_minus : p->w).push_back((int32_t)wv); }
+    if (weighted) (minus ? p->w_minus : p->w).push_back((int32_t)wv);
     if (zero_len && o.collect_zero_length) { p->zero_len.push_back(cls); p->zero_len.push_back((int32_t)f.start); p->zero_len.push_back((int32_t)wv); }
   }
   p->n_lines = line_no - (p->first_line - 1);
@@ -409,6 +412,7 @@ bool BedPacker::PackBlock(char *block, size_t got, long first_line, PackedBatch 
   for (int t = 0; t < T; t++) {
     out->zero_len.insert(out->zero_len.end(), pieces[t].zero_len.begin(), pieces[t].zero_len.end());
     out->n_lines += pieces[t].n_lines;
+    out->label_sum += pieces[t].label_sum;
   }
   return true;
 }

@@ -119,6 +119,7 @@ struct PackedBatch {
   RawVec w;                          // empty unless max_label_value > 1
   std::vector<int32_t> zero_len;     // (class, start, weight) triples, see collect_zero_length
   int64_t n_lines = 0;               // lines consumed (regions seen), including dropped ones
+  int64_t label_sum = 0;             // sum of GetLabelValue(max_label_value) over ALL regions seen (CountGenomicRegions, genomic_intervals.cpp:6206-6214)
 };
 
 // Packs blocks of lines from `src` until about `target_reads` reads are in `out` or the input ends.

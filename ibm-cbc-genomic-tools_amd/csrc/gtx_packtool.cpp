@@ -14,6 +14,7 @@
 #include <string>
 
 #include "gtx_bed.h"
+#include "gtx_stats.h"
 
 using namespace gtxhost;
 
@@ -22,6 +23,19 @@ int main(int argc, char **argv)
   if (argc < 2) { fprintf(stderr, "usage: gtx_packtool ou|os|su|ss [-t N] [-s] [-a] [-l MAX] -c chr1,chr2,... [FILE]\n"); return 2; }
   PackOptions opt;
   std::string m = argv[1];
+  if (m == "stats") {
+    // the host-side tail probabilities of `genomic_scans peaks` (gtx_stats.h), one "b K P N" / "p K MU" / "g X" query per stdin line
+    char kind; double x, y, z;
+    char line[256];
+    while (fgets(line, sizeof line, stdin)) {
+      int n = sscanf(line, " %c %lf %lf %lf", &kind, &x, &y, &z);
+      if (n >= 4 && kind == 'b') printf("%.17g\n", gtxstats::BinomialQ((long)x, y, (long)z));
+      else if (n >= 3 && kind == 'p') printf("%.17g\n", gtxstats::PoissonQ((long)x, y));
+      else if (n >= 2 && kind == 'g') printf("%.17g\n", gtxstats::GaussianQ(x));
+      else { fprintf(stderr, "bad query: %s", line); return 2; }
+    }
+    return 0;
+  }
   if (m == "ou") opt.mode = PACK_OVERLAPS_UNSORTED; else if (m == "os") opt.mode = PACK_OVERLAPS_SORTED;
   else if (m == "su") opt.mode = PACK_SCAN_UNSORTED; else if (m == "ss") opt.mode = PACK_SCAN_SORTED;
   else { fprintf(stderr, "unknown mode '%s'\n", argv[1]); return 2; }

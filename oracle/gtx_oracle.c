@@ -26,6 +26,7 @@
 #include <string.h>
 #include <stdint.h>
 #include <zlib.h>
+#include <math.h>
 
 /* ------------------------------------------------------------------------------------------ */
 /* errors: the reference prints to stderr and exit(1)s (genomic_intervals.cpp:1001-1006).     */
@@ -775,6 +776,91 @@ int orc_scan_packed(const int32_t *reads, const int32_t *weights, int64_t n, con
 /*   gtx_oracle counts -g GENOME [-S] [-i] [-op 1|c] [-w W] [-d D] [-min m] [--max-label-value V] [READS] */
 /*        genomic_scans.cpp:108-121 (options), :399-436 (RunCounts)                            */
 /* ------------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------------ */
+/* tail probabilities used by `genomic_scans peaks` (genomic_scans.cpp:317-356): what              */
+/* gsl_cdf_binomial_Q / gsl_cdf_poisson_Q / gsl_cdf_ugaussian_Q stand for.  GSL is absent; these   */
+/* sum the tail away from the mean term by term (saddle-point point mass, exact term ratio) and    */
+/* take the complement on the other side.  Tolerance parity with GSL only (~1e-13 relative).       */
+/* ------------------------------------------------------------------------------------------ */
+#define ORC_EPS 2.220446049250313e-16
+
+/* Saddle-point form of the point masses (C. Loader, "Fast and accurate computation of binomial probabilities", */
+/* 2000): the large log-gamma terms are never formed, so the relative error stays ~1e-15 for any n. */
+static double orc_stirling_error(double n)                  /* lgamma(n+1) - [(n + 1/2) log n - n + log(2 pi)/2] */
+{
+  if (n < 16.0) return lgamma(n + 1.0) - ((n + 0.5) * log(n) - n + 0.918938533204672741780329736406);
+  const double n2 = n * n;
+  return (1.0 / 12.0 - (1.0 / 360.0 - (1.0 / 1260.0 - (1.0 / 1680.0 - (1.0 / 1188.0) / n2) / n2) / n2) / n2) / n;
+}
+
+static double orc_deviance(double x, double np)             /* x log(x / np) + np - x, without cancellation */
+{
+  if (fabs(x - np) < 0.1 * (x + np)) {
+    double v = (x - np) / (x + np), s = (x - np) * v, ej = 2.0 * x * v;
+    v = v * v;
+    for (int j = 1; j < 1000; j++) {
+      ej *= v;
+      const double s1 = s + ej / (2 * j + 1);
+      if (s1 == s) return s1;
+      s = s1;
+    }
+    return s;
+  }
+  return x * log(x / np) + np - x;
+}
+
+static double binom_mass(long k, long n, double p)    /* 0 < p < 1 */
+{
+  const double q = 1.0 - p;
+  if (k == 0) return exp(n * log1p(-p));
+  if (k == n) return exp(n * log(p));
+  const double lc = orc_stirling_error((double)n) - orc_stirling_error((double)k) - orc_stirling_error((double)(n - k)) - orc_deviance((double)k, n * p) - orc_deviance((double)(n - k), n * q);
+  const double lf = 1.837877066409345483560659472811 + log((double)k) + log1p(-(double)k / n);
+  return exp(lc - 0.5 * lf);
+}
+
+static double pois_mass(long k, double mu)            /* mu > 0 */
+{
+  if (k == 0) return exp(-mu);
+  return exp(-orc_stirling_error((double)k) - orc_deviance((double)k, mu)) / sqrt(6.283185307179586476925286766559 * k);
+}
+double orc_binomial_Q(long k, double p, long n)
+{
+  if (p < 0.0 || p > 1.0 || n < 0) return NAN;
+  if (k < 0) return 1.0;
+  if (k >= n) return 0.0;
+  if (p == 0.0) return 0.0;
+  if (p == 1.0) return 1.0;
+  const double odds = p / (1.0 - p);
+  if ((double)k + 1.0 > n * p) {
+    long i = k + 1;
+    double term = binom_mass(i, n, p), sum = term;
+    for (; i < n; i++) { term *= (double)(n - i) / (i + 1.0) * odds; sum += term; if (term < sum * ORC_EPS) break; }
+    return sum;
+  }
+  long i = k;
+  double term = binom_mass(i, n, p), sum = term;
+  for (; i > 0; i--) { term *= (double)i / (n - i + 1.0) / odds; sum += term; if (term < sum * ORC_EPS) break; }
+  return 1.0 - sum;
+}
+double orc_poisson_Q(long k, double mu)
+{
+  if (mu < 0.0) return NAN;
+  if (k < 0) return 1.0;
+  if (mu == 0.0) return 0.0;
+  if ((double)k + 1.0 > mu) {
+    long i = k + 1;
+    double term = pois_mass(i, mu), sum = term;
+    for (;; i++) { term *= mu / (i + 1.0); sum += term; if (term < sum * ORC_EPS) break; }
+    return sum;
+  }
+  long i = k;
+  double term = pois_mass(i, mu), sum = term;
+  for (; i > 0; i--) { term *= (double)i / mu; sum += term; if (term < sum * ORC_EPS) break; }
+  return 1.0 - sum;
+}
+double orc_gaussian_Q(double x) { return 0.5 * erfc(x / M_SQRT2); }
+
 #ifdef ORC_MAIN
 static void die(void) { fflush(stdout); fprintf(stderr, "%s\n", g_err); exit(1); }
 
@@ -824,13 +910,148 @@ static void cli_emit(void *c, long value, int bidx, char strand, long start, lon
   if (value >= e->min_reads) printf("%ld\t%s %c %ld %ld\n", value, e->ch->names[e->b->chrom[bidx]], strand, start, stop);   /* genomic_scans.cpp:422-426 */
 }
 
+/* ---- peaks: PeakFinder (genomic_scans.cpp:209-380) + ComputeQValues (:162-205) ---------------------- */
+typedef struct { long value; int bidx; char strand; long start, stop; } win_row;
+typedef struct { win_row *w; long n, cap; } win_list;
+static void collect_emit(void *c, long value, int bidx, char strand, long start, long stop)
+{
+  win_list *l = c;
+  if (l->n == l->cap) { l->cap = l->cap ? 2 * l->cap : 1 << 16; l->w = realloc(l->w, sizeof(win_row) * (size_t)l->cap); }
+  win_row r = { value, bidx, strand, start, stop }; l->w[l->n++] = r;
+}
+
+/* CountGenomicRegions (genomic_intervals.cpp:6206-6214): a pass of its own over the file */
+static long count_regions(orc_chroms *ch, const char *file, long mlv)
+{
+  orc_reader rd; if (reader_open(&rd, file)) die();
+  orc_source src; memset(&src, 0, sizeof src); src.chroms = ch; src.rd = &rd;
+  orc_region r; int k; long n = 0;
+  while ((k = source_next(&src, &r)) == 1) { n += label_value(&r, mlv); region_free(&r); }
+  if (k < 0) die();
+  reader_close(&rd);
+  return n;
+}
+
+static void scan_file(orc_chroms *ch, const orc_bounds *b, const char *file, int sorted, long dist, long win, long mlv, int ign, win_list *out)
+{
+  memset(out, 0, sizeof *out);
+  orc_reader rd; if (reader_open(&rd, file)) die();
+  orc_source src; memset(&src, 0, sizeof src); src.chroms = ch; src.rd = &rd;
+  if (sorted) { if (scan_sorted(ch, &src, b, dist, win, mlv, ign, '1', collect_emit, out)) die(); }
+  else {
+    uint64_t **v;
+    if (scan_unsorted(ch, &src, b, dist, win, mlv, ign, 'c', &v)) die();
+    int ns = ign ? 1 : 2;
+    for (int i = 0; i < b->n; i++) for (int z = 0; z < ns; z++) {
+      uint64_t *arr = v[i * ns + z];
+      for (uint64_t k = 1; k <= arr[0]; k++) collect_emit(out, (long)arr[k], i, z ? '-' : '+', dist * ((long)k - 1) + 1, dist * ((long)k - 1) + win);
+    }
+  }
+  reader_close(&rd);
+}
+
+static int cmp_dbl(const void *a, const void *b) { double x = *(const double *)a, y = *(const double *)b; return x < y ? -1 : x > y; }
+
+static double compute_q_values(const double *pval, const double *pval_rnd, long n, long n_permutations, double qval_cutoff)
+{
+  if (n == 0) return -1.0;
+  double *a = xmalloc(sizeof(double) * n), *b = xmalloc(sizeof(double) * n);
+  memcpy(a, pval, sizeof(double) * n); memcpy(b, pval_rnd, sizeof(double) * n);
+  qsort(a, n, sizeof(double), cmp_dbl); qsort(b, n, sizeof(double), cmp_dbl);       /* list::sort */
+  unsigned long *counts = xmalloc(sizeof(unsigned long) * n);
+  for (long k = 0; k < n; k++) counts[k] = 0;
+  long k = 0;
+  for (long i = 0, j = 0; i < n && j < n; j++) {
+    while (i < n && b[j] > a[i]) { i++; k++; }
+    if (k < n - 1) counts[k]++;
+  }
+  double *q = xmalloc(sizeof(double) * n);
+  for (long c = 0; c < n; c++) {
+    q[c] = (float)counts[c] / n_permutations / (c + 1);
+    if (c + 1 == n) break;
+    counts[c + 1] += counts[c];
+  }
+  float min_q = q[n - 1];
+  double cutoff = -1.0;
+  long p = n - 1;
+  for (long c = n - 2; c >= 0; c--, p--) {
+    if (min_q <= qval_cutoff) { cutoff = a[p]; break; }
+    if (q[c] > min_q) q[c] = min_q; else min_q = q[c];
+  }
+  free(a); free(b); free(counts); free(q);
+  return cutoff;
+}
+
+static double max_d(double x, double y) { return x > y ? x : y; }
+
+static int run_peaks(orc_chroms *ch, const orc_bounds *b, const char *signal, const char *control, int sorted, long dist, long win, long mlv,
+                     int ign, long min_reads, const char *method, int norm, int cmp, double pval_cut, double qval_cut)
+{
+  if (!control) { fprintf(stderr, "oracle: peaks without a control draws random numbers (genomic_scans.cpp:299) and is not restated\n"); return 2; }
+  unsigned long eff = 0; for (int i = 0; i < b->n; i++) eff += (unsigned long)b->len[i];            /* CalcBoundSize */
+  fprintf(stderr, "* Effective genome size = %lu\n", eff);
+  long n_signal = count_regions(ch, signal, mlv);
+  double p_signal = (double)n_signal / eff;
+  win_list S, C; scan_file(ch, b, signal, sorted, dist, win, mlv, ign, &S);
+  long n_control = count_regions(ch, control, mlv);
+  double p_control = (double)n_control / eff;
+  scan_file(ch, b, control, sorted, dist, win, mlv, ign, &C);
+  double p_ratio = p_signal / p_control;
+  fprintf(stderr, "* Signal input file = %s (reads = %lu; background probability = %.2e)\n", signal, n_signal, p_signal);
+  fprintf(stderr, "* Control input file = %s (reads = %lu; background probability = %.2e)\n", control, n_control, p_control);
+  fprintf(stderr, "* Signal/Control background probability = %f\n", p_ratio);
+  long cap = 1024, n = 0; double *p1 = xmalloc(sizeof(double) * cap), *p2 = xmalloc(sizeof(double) * cap); long *idx = xmalloc(sizeof(long) * cap);
+  for (long t = 0; t < S.n; t++) {
+    long v1 = S.w[t].value, v2 = C.w[t].value, v0 = win;
+    if (v1 > v0) v1 = v0;
+    if (v2 > v0) v2 = v0;
+    if (norm) { if (p_ratio < 1.0) v2 = (long)floor((float)v2 * p_ratio); else v1 = (long)floor((float)v1 / p_ratio); }
+    if (v1 < min_reads) continue;
+    double pval1, pval2;
+    if (cmp) {
+      if (!strcmp(method, "binomial")) {
+        float pp_control = ((float)v2 + 1.0) / (v0 + 1.0);
+        pval1 = orc_binomial_Q(v1, max_d(pp_control, p_signal), v0 + 1);
+        float pp_signal = ((float)v1 + 1.0) / (v0 + 1.0);
+        pval2 = orc_binomial_Q(v2, max_d(pp_signal, p_control), v0 + 1);
+      } else if (!strcmp(method, "poisson")) {
+        long pseudo = 5;
+        pval1 = orc_poisson_Q(v1 + pseudo, (double)(v2 + pseudo)); pval2 = orc_poisson_Q(v2 + pseudo, (double)(v1 + pseudo));
+      } else if (!strcmp(method, "binomial2")) {
+        double pp_control = (double)(v2 + 1) / n_control, pp_signal = (double)(v1 + 1) / n_signal;
+        pval1 = orc_binomial_Q(v1 + 1, pp_control, n_signal); pval2 = orc_binomial_Q(v2 + 1, pp_signal, n_control);
+      } else if (!strcmp(method, "cbinomial")) {
+        pval1 = orc_binomial_Q(v1 + 1, 0.5, v1 + v2 + 2); pval2 = orc_binomial_Q(v2 + 1, 0.5, v1 + v2 + 2);
+      } else if (!strcmp(method, "normal")) {
+        double pp_control = (double)(v2 + 1) / n_control, pp_signal = (double)(v1 + 1) / n_signal;
+        pval1 = orc_gaussian_Q((v1 + 1 - n_signal * pp_control) / sqrt(n_signal * pp_control));
+        pval2 = orc_gaussian_Q((v2 + 1 - n_control * pp_signal) / sqrt(n_control * pp_signal));
+      } else { fprintf(stderr, "Error: unknown probability distribution!\n"); exit(1); }
+    } else {
+      if (!strcmp(method, "binomial")) { pval1 = orc_binomial_Q(v1, p_signal, v0 + 1); pval2 = orc_binomial_Q(v2, p_control, v0 + 1); }
+      else if (!strcmp(method, "poisson")) { long pseudo = 5; pval1 = orc_poisson_Q(v1 + pseudo, (double)(v2 + pseudo)); pval2 = orc_poisson_Q(v2 + pseudo, (double)(v1 + pseudo)); }
+      else { fprintf(stderr, "Error: unknown probability distribution!\n"); exit(1); }
+    }
+    if (pval1 <= pval_cut) {
+      if (n == cap) { cap *= 2; p1 = realloc(p1, sizeof(double) * cap); p2 = realloc(p2, sizeof(double) * cap); idx = realloc(idx, sizeof(long) * cap); }
+      p1[n] = pval1; p2[n] = pval2; idx[n] = t; n++;
+    }
+  }
+  double cutoff = compute_q_values(p1, p2, n, 1, qval_cut);
+  for (long k = 0; k < n; k++)
+    if (p1[k] <= cutoff) { const win_row *w = &S.w[idx[k]]; printf("%.4e\t%s %c %ld %ld\n", p1[k], ch->names[b->chrom[w->bidx]], w->strand, w->start, w->stop); }
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   if (argc < 2) { fprintf(stderr, "usage: gtx_oracle count|rpkm|counts [OPTIONS] FILES\n"); return 1; }
   const char *op = argv[1]; if (op[0] == '-') op++;                                /* genomic_overlaps.cpp:180-182 */
   int sorted = 0, by_strand = 0, ign = 0, gaps = 0; long mlv = 1; const char *bits = "17,20,23,26";
   unsigned long min_count = 0; long min_reads = 10, win = 500, dist = 25; char prep = '1'; const char *genome = "", *ref_file = ""; int ref_sorted = 0;
-  int is_scan = !strcmp(op, "counts");
+  int is_peaks = !strcmp(op, "peaks");
+  int is_scan = !strcmp(op, "counts") || is_peaks;
+  const char *method = "binomial"; int norm = 0, cmp = 0; double pval_cut = 1.0, qval_cut = 0.05;
   int is_cov = !strcmp(op, "coverage") || !strcmp(op, "density");
   double min_density = 0.0;
   if (strcmp(op, "count") && strcmp(op, "rpkm") && !is_cov && !is_scan) { fprintf(stderr, "Unknown operation '%s'!\n", op); return 1; }
@@ -851,7 +1072,13 @@ int main(int argc, char **argv)
     else if (is_scan && !strcmp(o, "-Sref")) ref_sorted = 1;
     else if (is_scan && !strcmp(o, "-w")) { NEEDVAL(); win = atol(argv[++a]); }
     else if (is_scan && !strcmp(o, "-d")) { NEEDVAL(); dist = atol(argv[++a]); }
-    else if (is_scan && !strcmp(o, "-op")) { NEEDVAL(); prep = argv[++a][0]; }
+    else if (is_scan && !is_peaks && !strcmp(o, "-op")) { NEEDVAL(); prep = argv[++a][0]; }
+    else if (is_peaks && !strcmp(o, "-M")) { NEEDVAL(); method = argv[++a]; }
+    else if (is_peaks && !strcmp(o, "-norm")) norm = 1;
+    else if (is_peaks && !strcmp(o, "-cmp")) cmp = 1;
+    else if (is_peaks && !strcmp(o, "-pval")) { NEEDVAL(); pval_cut = atof(argv[++a]); }
+    else if (is_peaks && !strcmp(o, "-qval")) { NEEDVAL(); qval_cut = atof(argv[++a]); }
+    else if (is_peaks && !strcmp(o, "-D")) ;
     else { fprintf(stderr, "Error: unknown option '%s'!\n", o); return 1; }
   }
   orc_chroms ch; memset(&ch, 0, sizeof ch);
@@ -897,6 +1124,7 @@ int main(int argc, char **argv)
     return 0;
   }
   /* counts */
+  if (is_peaks && !genome[0]) genome = "genome.reg+";                              /* genomic_scans.cpp:126 */
   if (!genome[0]) { fprintf(stderr, "Error: genome region file is necessary for this operation!\n"); return 1; }
   orc_set g; if (set_load_bed(&ch, genome, &g)) die();
   orc_bounds b; b.n = 0; b.chrom = xmalloc(sizeof(int) * (g.n + 1)); b.len = xmalloc(sizeof(long) * (g.n + 1));
@@ -911,6 +1139,10 @@ int main(int argc, char **argv)
       int tc = b.chrom[j]; b.chrom[j] = b.chrom[j - 1]; b.chrom[j - 1] = tc;
       long tl = b.len[j]; b.len[j] = b.len[j - 1]; b.len[j - 1] = tl;
     }
+  if (is_peaks) {
+    if (argc - a < 1) { fprintf(stderr, "usage: gtx_oracle peaks [OPTIONS] SIGNAL-REG-FILE CONTROL-REG-FILE\n"); return 1; }
+    return run_peaks(&ch, &b, argv[a], a + 1 < argc ? argv[a + 1] : NULL, sorted, dist, win, mlv, ign, min_reads, method, norm, cmp, pval_cut, qval_cut);
+  }
   orc_reader rd; if (reader_open(&rd, a < argc ? argv[a] : NULL)) die();
   orc_source src; memset(&src, 0, sizeof src); src.chroms = &ch; src.rd = &rd;
   cli_emit_ctx e; memset(&e, 0, sizeof e); e.ch = &ch; e.b = &b; e.min_reads = min_reads; e.ign = ign;

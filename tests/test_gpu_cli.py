@@ -96,6 +96,25 @@ def beds(tmp_path_factory):
     write_bed(d / "scan_refs_strand.bed", sref[o3], names, ["r%d" % i for i in o3], rs[o3])
     p3 = rng.permutation(len(sref))
     write_bed(d / "scan_refs_shuffled.bed", sref[p3], names, ["r%d" % i for i in p3], rs[p3])
+    # peaks: control = background, signal = background + 60 clusters of ~40 reads within 400 bp; both sorted by (chrom,start)
+    def reads50(n, seed):
+        r = synth.genome_intervals(n, seed, 50, 51)
+        r[:, 1:] = r[:, 1:] // 50 + 1
+        r[:, 2] = r[:, 1] + 49
+        return r
+    ctrl = reads50(30000, 35)
+    bg = reads50(30000, 36)
+    centers = reads50(60, 37)
+    cl = np.repeat(centers, 40, axis=0)
+    cl[:, 1] += rng.integers(0, 400, size=len(cl)); cl[:, 2] = cl[:, 1] + 49
+    sig = np.concatenate([bg, cl])
+    for name, arr in (("peaks_signal", sig), ("peaks_control", ctrl)):
+        arr = arr[np.lexsort((arr[:, 1], arr[:, 0]))]
+        st = rng.choice(["+", "-"], size=len(arr))
+        lab = rng.integers(0, 4, size=len(arr))
+        write_bed(d / (name + ".bed"), arr, names, lab, st)
+        o = np.lexsort((arr[:, 1], st == "-", arr[:, 0]))
+        write_bed(d / (name + "_strand.bed"), arr[o], names, lab[o], st[o])
     return d
 
 
@@ -284,3 +303,53 @@ def test_scans_reference_filter_keeps_exactly_the_overlapping_windows(beds):
         c, _, s, e = iv.split(" ")
         return any(rs <= int(e) and int(s) <= re for rs, re in refs.get(c, []))
     assert [l for l in allw if overlaps(l)] == kept
+
+
+PEAK_RUNS = [
+    (["peaks", "-i", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-i", "-g", "genome.bed", "-w", "1000", "-d", "250", "-min", "5", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-i", "-cmp", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-i", "-M", "poisson", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-i", "-cmp", "-M", "poisson", "-qval", "0.2", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-i", "-cmp", "-M", "binomial2", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-i", "-cmp", "-M", "cbinomial", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-i", "-cmp", "-M", "normal", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-i", "-norm", "-pval", "1e-4", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-g", "genome.bed", "-min", "6", "peaks_signal.bed", "peaks_control.bed"]),                     # strand-aware windows
+    (["peaks", "-S", "-i", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),                      # sorted scanners, -op 1
+    (["peaks", "-S", "-g", "genome.bed", "-min", "6", "peaks_signal_strand.bed", "peaks_control_strand.bed"]),
+    (["peaks", "-i", "--max-label-value", "3", "-g", "genome.bed", "-min", "12", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-i", "-M", "bogus", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-S", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),                            # not sorted by strand -> error
+]
+
+
+@pytest.mark.parametrize("args", PEAK_RUNS, ids=[" ".join(a) for a in PEAK_RUNS])
+def test_peaks_cli_equals_oracle_cli(beds, args):
+    """genomic_scans peaks with a control: window counts from the GPU scans, tests on the host; p-values are printed
+    with five digits, product and oracle use the same tail sums (tolerance parity with GSL)"""
+    want = oracle(args, cwd=beds)
+    got = product("scans", args, cwd=beds)
+    assert got[0] == want[0]
+    assert got[1] == want[1]
+    assert got[2].strip().splitlines()[-1:] == want[2].strip().splitlines()[-1:]
+    if want[0] == 0:
+        assert got[2] == want[2]                       # the "* Effective genome size ..." report lines
+        if "bogus" not in args:
+            assert len(got[1].splitlines()) >= 10      # the planted clusters are found
+
+
+def test_peaks_finds_the_planted_clusters(beds):
+    out = product("scans", ["peaks", "-i", "-g", "genome.bed", "-qval", "0.01", "peaks_signal.bed", "peaks_control.bed"], cwd=beds)[1].splitlines()
+    assert len(out) > 100
+    pv = [float(l.split("\t")[0]) for l in out]
+    assert max(pv) < 1e-3
+
+
+def test_peaks_without_control_runs(beds):
+    import os as _os
+    env = dict(_os.environ, GTX_SEED="5")
+    r = subprocess.run([TOOLS["scans"], "peaks", "-i", "-g", "genome.bed", "peaks_signal.bed"], capture_output=True, cwd=beds, env=env)
+    assert r.returncode == 0 and len(r.stdout.decode().splitlines()) > 50
+    r2 = subprocess.run([TOOLS["scans"], "peaks", "-i", "-g", "genome.bed", "peaks_signal.bed"], capture_output=True, cwd=beds, env=env)
+    assert r.stdout == r2.stdout                       # GTX_SEED fixes the background draws
