@@ -54,6 +54,20 @@ __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_re
 // value of the lane below (lane 0 keeps its own); DPP wave_shr:1 -- call with all lanes active
 __device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 
+// inclusive prefix sum over the 64 lanes, DPP only (no LDS): Hillis-Steele inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8 with zero fill), then row_bcast15 hands a row's total to the next odd row and
+// row_bcast31 the total of lanes 0..31 to the upper half.  Call with all lanes active.
+__device__ __forceinline__ int wave_scan_add(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
 __device__ __forceinline__ int wave_min(int v)
 {
 #pragma unroll
@@ -549,6 +563,36 @@ __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__
 // always contribute 0 and are left out.  This kernel is the general per-chunk form (no hand-tuned fast
 // path yet): correctness first for this "next" row.
 // ---------------------------------------------------------------------------------------------
+// Fast form of Win::walk for one full chunk of the coverage pass (unweighted, all 64 lanes of the wave's class,
+// window placed).  When the keys are non-decreasing across the lanes -- sorted reads: always for the starts,
+// for the ends whenever the read length does not shrink faster than the starts grow -- the lanes at or
+// below a boundary are a PREFIX of the wave, so the key sum of a slot is a difference of two entries of the
+// lane-wise prefix sum of the keys: one v_readlane per boundary instead of a 64-lane reduction.  Keys are
+// taken relative to lane 0's (spread < 2^24, so 64 of them fit 32 bits).  Anything else goes to walk().
+template <class WIN>
+__device__ __forceinline__ u64 walk_cov_chunk(WIN &X, const Seg &sg, int key, int lane, bool &valid)
+{
+  const int kbase = rdlane(key, 0), ktop = rdlane(key, 63);
+  const int prev = lane_prev(key);
+  const bool ok = valid && (unsigned)(ktop - kbase) < (1u << 24) && __ballot(key < prev) == 0 && !WIN::below(kbase, X.prevW);
+  if (!ok) return X.walk(sg, key, 1, ~0ull, lane, valid);
+  const int rel = key - kbase;
+  const int p = wave_scan_add(rel);                            // inclusive prefix sum of the relative keys
+  const int q = p - rel;                                       // exclusive: sum over the lanes below
+  const int total = rdlane(p, 63);
+  int cprev = 0, sprev = 0, adv = 0;
+  for (;;) {
+    const int c = __popcll(__ballot(WIN::below(key, X.curW)));  // = number of leading lanes at or below the boundary
+    const int srel = c == 64 ? total : rdlane(q, c);
+    const int dc = c - cprev;
+    X.pend += dc;
+    X.pend2 += (i64)kbase * dc + (srel - sprev);
+    cprev = c; sprev = srel;
+    if (c == 64) return 0;
+    if (X.fwd(sg, lane) && ++adv > 2) { X.flush(sg, lane); valid = false; return ~0ull << c; }   // the lanes not yet placed add themselves
+  }
+}
+
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CoverArgs a)
 {
@@ -575,11 +619,16 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
   Seg sg; sg.start = 0; sg.end = 0; sg.cls = -1;
   int nNoClass = 0, nDegen = 0; i64 firstDegen = INT64_MAX;
 
+  // the next chunk's reads are requested before the current chunk is worked on (3-4 waves per SIMD at this
+  // register count: the load latency would otherwise sit in front of every chunk)
+  Tri tn; tn.c = -1; tn.s = 0; tn.e = 0; int wn = 1;
+  if (lane < nMine) { tn = load_tri((const char *)(reads + first + lane)); if (WEIGHTED) wn = weights[first + lane]; }
   for (int at = 0; at < nMine; at += 64) {
     const int left = nMine - at;
     const u64 active = left >= 64 ? ~0ull : ((1ull << left) - 1);
-    Tri t; t.c = -1; t.s = 0; t.e = 0; int w = 1;
-    if (lane < left) { t = reads[first + at + lane]; if (WEIGHTED) w = weights[first + at + lane]; }
+    const Tri t = tn; const int w = wn;
+    tn.c = -1; tn.s = 0; tn.e = 0; wn = 1;
+    if (at + 64 + lane < nMine) { tn = load_tri((const char *)(reads + first + at + 64 + lane)); if (WEIGHTED) wn = weights[first + at + 64 + lane]; }
     int c0 = rdlane(t.c, 0);
     if (sg.cls >= 0 && (__ballot(t.c == sg.cls) & active)) c0 = sg.cls;
     if (c0 != sg.cls && (unsigned)c0 < (unsigned)a.nClasses) {
@@ -600,10 +649,18 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
       if (inv) { nDegen += __popcll(inv); i64 p = first + at + (__ffsll((unsigned long long)inv) - 1); if (p < firstDegen) firstDegen = p; }
     }
     if (mine && sg.start != sg.end) {
-      u64 r0 = As.walk(sg, t.s, w, mine, lane, vAs);
-      u64 r1 = Ae.walk(sg, t.e, w, mine, lane, vAe);
-      u64 r2 = Bs.walk(sg, t.s, w, mine, lane, vBs);
-      u64 r3 = Be.walk(sg, t.e, w, mine, lane, vBe);
+      u64 r0, r1, r2, r3;
+      if (!WEIGHTED && mine == ~0ull) {
+        r0 = walk_cov_chunk(As, sg, t.s, lane, vAs);
+        r1 = walk_cov_chunk(Ae, sg, t.e, lane, vAe);
+        r2 = walk_cov_chunk(Bs, sg, t.s, lane, vBs);
+        r3 = walk_cov_chunk(Be, sg, t.e, lane, vBe);
+      } else {
+        r0 = As.walk(sg, t.s, w, mine, lane, vAs);
+        r1 = Ae.walk(sg, t.e, w, mine, lane, vAe);
+        r2 = Bs.walk(sg, t.s, w, mine, lane, vBs);
+        r3 = Be.walk(sg, t.e, w, mine, lane, vBe);
+      }
       if (r0) As.lanes_add(sg, t.s, w, r0, lane);
       if (r1) Ae.lanes_add(sg, t.e, w, r1, lane);
       if (r2) Bs.lanes_add(sg, t.s, w, r2, lane);
