@@ -41,11 +41,13 @@ int main(int argc, char **argv)
   else { fprintf(stderr, "unknown mode '%s'\n", argv[1]); return 2; }
   ChromTable chroms;
   const char *file = NULL; size_t batch = 1u << 20;
+  bool quiet = false; long long checksum = 0, n_reads = 0;                    // -q: timing runs, print only a checksum
   for (int a = 2; a < argc; a++) {
     if (!strcmp(argv[a], "-t") && a + 1 < argc) opt.threads = atoi(argv[++a]);
     else if (!strcmp(argv[a], "-s")) opt.sorted_by_strand = true;
     else if (!strcmp(argv[a], "-a")) opt.strand_aware = true;
     else if (!strcmp(argv[a], "-z")) opt.collect_zero_length = true;
+    else if (!strcmp(argv[a], "-q")) quiet = true;
     else if (!strcmp(argv[a], "-l") && a + 1 < argc) opt.max_label_value = atol(argv[++a]);
     else if (!strcmp(argv[a], "-b") && a + 1 < argc) batch = (size_t)atol(argv[++a]);
     else if (!strcmp(argv[a], "-c") && a + 1 < argc) {
@@ -68,6 +70,7 @@ int main(int argc, char **argv)
       if (e.no_prefix) fprintf(stderr, "%s\n", e.msg.c_str()); else fprintf(stderr, "\nError: Line %ld: %s\n", e.line, e.msg.c_str());
       return 1;
     }
+    if (quiet) { long long cs = 0; for (size_t i = 0; i < b.tri.size(); i++) cs += b.tri[i]; checksum += cs; n_reads += (long long)(b.tri.size() / 3); b.tri.clear(); b.w.clear(); b.zero_len.clear(); lines += b.n_lines; b.n_lines = 0; if (!more) break; continue; }
     for (size_t i = 0; i + 2 < b.tri.size(); i += 3) {
       if (b.w.empty()) printf("%d %d %d\n", b.tri[i], b.tri[i + 1], b.tri[i + 2]);
       else printf("%d %d %d %d\n", b.tri[i], b.tri[i + 1], b.tri[i + 2], b.w[i / 3]);
@@ -76,6 +79,7 @@ int main(int argc, char **argv)
     lines += b.n_lines;
     if (!more) break;
   }
+  if (quiet) printf("# reads=%lld checksum=%lld\n", n_reads, checksum);
   printf("# lines=%ld\n", (long)lines);
   delete src;
   return 0;
