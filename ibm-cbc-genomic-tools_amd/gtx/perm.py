@@ -75,11 +75,15 @@ class PermTable:
         """Random membership lists (sizes ~ geometric around mean_size, ascending rows) and values."""
         rng = np.random.default_rng(seed)
         sizes = np.clip(rng.geometric(1.0 / mean_size, size=n_cols), 1, n_rows)
-        col_ptr = np.zeros(n_cols + 1, dtype=np.int64)
-        np.cumsum(sizes, out=col_ptr[1:])
-        rows = np.empty(col_ptr[-1], dtype=np.int32)
+        lists = []
         for c in range(n_cols):
-            rows[col_ptr[c]:col_ptr[c + 1]] = np.sort(rng.choice(n_rows, size=sizes[c], replace=False))
+            if n_rows <= 100_000:
+                lists.append(np.sort(rng.choice(n_rows, size=sizes[c], replace=False)))
+            else:                                                    # large tables: draw with replacement, keep the distinct rows
+                lists.append(np.unique(rng.integers(0, n_rows, size=sizes[c])))
+        col_ptr = np.zeros(n_cols + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in lists], out=col_ptr[1:])
+        rows = np.concatenate(lists).astype(np.int32) if lists else np.zeros(0, dtype=np.int32)
         if values == "normal":
             V = rng.normal(size=n_rows)
         elif values == "binary":
