@@ -29,6 +29,11 @@ struct gtx_ctx {
   int nClasses = 0;
   int *d_sortedE = nullptr, *d_sortedS = nullptr, *d_segStart = nullptr;
   int *d_sampE = nullptr, *d_sampS = nullptr; int sampShift = 6, nSamp = 0;   // top level of the search kernel
+  // unsorted reads, bucket path (gtx_bucket.hip): table built with the references, scratch sized by the largest call
+  int *d_bkt = nullptr; int nB = 0;                  // posHi | eLo | eHi | sLo | sHi | cls (nB each) | clsStart (nClasses+1)
+  unsigned *d_bktCnt = nullptr;                      // count | offset (nB+1) | cursor
+  unsigned short *d_bktIds = nullptr; void *d_bktReads = nullptr; int *d_bktWeights = nullptr; size_t capBkt = 0;
+  int64_t bucketMinReads = 1 << 18;                  // below this the per-read search kernel is used (GTX_BUCKET_MIN_READS)
   int *d_posE = nullptr, *d_posS = nullptr, *d_classBase = nullptr;
   u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr, *d_prefA = nullptr, *d_prefB = nullptr;
   bool histDirty = false;              // a call was abandoned between begin and end
@@ -104,6 +109,7 @@ gtx_ctx *gtx_create(int device_id)
   if (cpw && atoi(cpw) > 0) c->chunksPerWave = atoi(cpw);
   const char *br = getenv("GTX_BATCH_READS");
   if (br && atoll(br) > 0) c->batchReads = atoll(br);
+  if (const char *bm = getenv("GTX_BUCKET_MIN_READS")) c->bucketMinReads = atoll(bm);   // unsorted reads: batches below this use the search kernel
   const char *pf = getenv("GTX_READS_PER_LANE");        // tuning knob (1..4), default 4
   if (pf && atoi(pf) > 0) c->prefetch = atoi(pf);
   return c;
@@ -114,7 +120,7 @@ void gtx_destroy(gtx_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
-  dfree(c->d_sampE); dfree(c->d_sampS);
+  dfree(c->d_bktIds); dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_bkt); dfree(c->d_bktCnt);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   dfree(c->d_reads); dfree(c->d_weights); dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
   for (auto &p : c->d_cov) dfree(p);
@@ -185,7 +191,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   }
 
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
-  dfree(c->d_sampE); dfree(c->d_sampS);
+  dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_bkt); dfree(c->d_bktCnt);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB);
   c->nRefs = -1;
   const int64_t histLen = nv + nClasses;
@@ -221,6 +227,34 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
     HIPCHK(c, hipMemcpy(c->d_sampE, sampE.data(), sizeof(int32_t) * (c->nSamp + 1), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_sampS, sampS.data(), sizeof(int32_t) * (c->nSamp + 1), hipMemcpyHostToDevice));
   }
+  {
+    // bucket table of the unsorted path: cuts of the ends array every bucket_e_size() boundaries, never across classes
+    const int kE = gtx::bucket_e_size(), kS = gtx::bucket_s_size();
+    std::vector<int32_t> posHi, eLo, eHi, sLo, sHi, cls, clsStart(nClasses + 1, 0);
+    for (int cl = 0; cl < nClasses; cl++) {
+      clsStart[cl] = (int32_t)posHi.size();
+      const int32_t s0 = seg[cl], s1 = seg[cl + 1];
+      for (int32_t e0 = s0; e0 < s1; e0 += kE) {
+        const int32_t e1 = std::min<int64_t>((int64_t)e0 + kE, s1);
+        posHi.push_back(e1 == s1 ? INT32_MAX : sortedE[e1 - 1]);
+        eLo.push_back(e0); eHi.push_back(e1); cls.push_back(cl);
+        // a read of this bucket starts above E[e0-1], so it ends at or above it: ranks in the starts array begin here
+        const int32_t lo = e0 == s0 ? s0 : (int32_t)(std::upper_bound(sortedS.begin() + s0, sortedS.begin() + s1, sortedE[e0 - 1]) - sortedS.begin());
+        sLo.push_back(lo); sHi.push_back((int32_t)std::min<int64_t>((int64_t)lo + kS, s1));
+      }
+    }
+    clsStart[nClasses] = (int32_t)posHi.size();
+    c->nB = (int)posHi.size();
+    if (c->nB > 8192) c->nB = 0;                                   // too many buckets for the LDS tables: the search kernel serves
+    if (c->nB > 0) {
+      std::vector<int32_t> all;
+      for (auto *v : {&posHi, &eLo, &eHi, &sLo, &sHi, &cls, &clsStart}) all.insert(all.end(), v->begin(), v->end());
+      HIPCHK(c, hipMalloc(&c->d_bkt, sizeof(int32_t) * all.size()));
+      HIPCHK(c, hipMemcpy(c->d_bkt, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMalloc(&c->d_bktCnt, sizeof(unsigned) * (3 * (size_t)c->nB + 4)));
+      HIPCHK(c, hipMemset(c->d_bktCnt, 0, sizeof(unsigned) * (3 * (size_t)c->nB + 4)));
+    }
+  }
   if (m > 0) {
     HIPCHK(c, hipMemcpy(c->d_posE, posE.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_posS, posS.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
@@ -253,6 +287,31 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
   a.zeroLenOk = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   a.sampE = c->d_sampE; a.sampS = c->d_sampS; a.sampShift = c->sampShift; a.nSamp = c->nSamp;
   return a;
+}
+
+// reads in no particular order: bucket partition + LDS counting for large batches, per-read search kernel otherwise
+static int launch_unsorted(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, const gtx::CountArgs &a)
+{
+  if (c->nB == 0 || n < c->bucketMinReads || n >= (1ll << 31)) {
+    HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, a, false, c->stream));
+    return GTX_OK;
+  }
+  if ((size_t)n > c->capBkt) {
+    dfree(c->d_bktIds); dfree(c->d_bktReads); dfree(c->d_bktWeights); c->capBkt = 0;
+    HIPCHK(c, hipMalloc(&c->d_bktIds, sizeof(unsigned short) * (size_t)n));
+    HIPCHK(c, hipMalloc(&c->d_bktReads, 12 * (size_t)n));
+    HIPCHK(c, hipMalloc(&c->d_bktWeights, 4 * (size_t)n));
+    c->capBkt = (size_t)n;
+  }
+  gtx::BucketTable t;
+  const int nB = c->nB;
+  t.posHi = c->d_bkt; t.eLo = c->d_bkt + nB; t.eHi = c->d_bkt + 2 * nB; t.sLo = c->d_bkt + 3 * nB; t.sHi = c->d_bkt + 4 * nB;
+  t.cls = c->d_bkt + 5 * nB; t.clsStart = c->d_bkt + 6 * nB; t.nB = nB;
+  gtx::BucketWork w;
+  w.count = c->d_bktCnt; w.offset = c->d_bktCnt + nB; w.cursor = c->d_bktCnt + 2 * nB + 1;
+  w.ids = c->d_bktIds; w.tmpReads = c->d_bktReads; w.tmpWeights = c->d_bktWeights;
+  HIPCHK(c, gtx::launch_count_bucketed(d_reads, d_weights, n, a, t, w, c->stream));
+  return GTX_OK;
 }
 
 // begin: zero histograms + info; accumulate: one kernel per resident batch; end: prefix + gather
@@ -288,7 +347,8 @@ int gtx_count_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int
   int rc = count_begin(c); if (rc) return rc;
   if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
   if (!(flags & GTX_READS_SORTED)) c->tileSumsValid = false;
-  HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), (flags & GTX_READS_SORTED) != 0, c->stream));
+  if (flags & GTX_READS_SORTED) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), true, c->stream));
+  else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n)); if (rc) return rc; }
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   rc = count_end(c, d_hits); if (rc) return rc;
   if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
@@ -356,7 +416,8 @@ int gtx_count_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int6
     HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
     if (weights) HIPCHK(c, hipMemcpyAsync(c->d_weights, weights + off, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
     if (!(flags & GTX_READS_SORTED)) c->tileSumsValid = false;
-    HIPCHK(c, gtx::launch_count(c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags, cnt), (flags & GTX_READS_SORTED) != 0, c->stream));
+    if (flags & GTX_READS_SORTED) HIPCHK(c, gtx::launch_count(c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags, cnt), true, c->stream));
+    else { int rcu = launch_unsorted(c, c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags, cnt)); if (rcu) return rcu; }
     // fold this batch's info (indices are batch-relative) and reset the device block for the next one
     HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + c->infoCur, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));

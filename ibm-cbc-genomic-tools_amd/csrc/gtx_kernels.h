@@ -64,6 +64,27 @@ struct ScanArgs {
   int sortedRule;                // sorted scanner: no validity test, pos < 1 lands in the first micro-window
 };
 
+// ---- unsorted reads: partition into buckets, count per bucket in LDS (gtx_bucket.hip) ----
+struct BucketTable {               // built by gtx_set_refs; a bucket = <= bucket_e_size() consecutive boundaries of ONE class
+  const int *posHi;                // [nB] largest read start the bucket takes (INT_MAX for the last bucket of its class)
+  const int *eLo, *eHi;            // [nB] its range of the ends array; histogram A slots eLo+cls .. eHi+cls
+  const int *sLo, *sHi;            // [nB] the slice of the starts array kept in LDS; histogram B slots sLo+cls .. sHi+cls
+  const int *cls;                  // [nB]
+  const int *clsStart;             // [nClasses+1] buckets of each class
+  int nB;
+};
+struct BucketWork {                // scratch of one call
+  unsigned *count;                 // [nB] reads per bucket (zero between calls)
+  unsigned *offset;                // [nB+1]
+  unsigned *cursor;                // [nB]
+  unsigned short *ids;             // [n] bucket of every read, 0xFFFF = not counted
+  void *tmpReads; int *tmpWeights; // [n] the reads grouped by bucket
+};
+int bucket_e_size();
+int bucket_s_size();
+hipError_t launch_count_bucketed(const void *reads, const void *weights, long long n, const CountArgs &a, const BucketTable &t,
+                                 const BucketWork &w, hipStream_t st);
+
 int search_sample_shift(long long nValid);   // stride of the sample arrays such that both fit the LDS budget
 int scan_tiles(long long len);
 

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""100M shuffled reads x 1M refs through the bucket path (run under rocprofv3 --kernel-trace --stats for the per-kernel split)."""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R, "ibm-cbc-genomic-tools_amd")); sys.path.insert(0, R)
+import numpy as np, torch, gtx
+from gtx import synth
+from bench import make_reads_on_device
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+dev = torch.device("cuda", 0)
+eng = gtx.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream); eng.profile(True)
+reads = make_reads_on_device(n, np.arange(24), 1000, dev)
+reads = reads[torch.randperm(n, device=dev)]
+eng.set_refs(synth.genome_intervals(1_000_000, 43, 50, 2000), 24)
+hits = torch.zeros(eng.n_refs, dtype=torch.int64, device=dev)
+for _ in range(5): eng.count_device(reads.data_ptr(), n, hits.data_ptr(), None, 0)
+eng.sync(); print("bucket path: %.3f ms" % np.mean([eng.profile_last(b)[0] for b in range(3)]))

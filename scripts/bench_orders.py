@@ -30,4 +30,18 @@ run("same reads grouped by strand class (what the packer emits)", g)
 p = reads[torch.randperm(n, device=dev)]
 eng.set_refs(synth.genome_intervals(1_000_000, 43, 50, 2000), 24)
 run("random order, walk kernel (hint is wrong)", p[:20_000_000])
-run("random order, search kernel", p[:20_000_000], 0)
+run("random order, bucket path (default for unsorted)", p[:20_000_000], 0)
+# the two order-agnostic paths side by side (GTX_BUCKET_MIN_READS is read when the context is created)
+os.environ["GTX_BUCKET_MIN_READS"] = str(1 << 40)
+eng2 = gtx.Engine(0); eng2.set_stream(torch.cuda.current_stream().cuda_stream); eng2.profile(True)
+eng2.set_refs(synth.genome_intervals(1_000_000, 43, 50, 2000), 24)
+def run2(name, r):
+    hits = torch.zeros(eng2.n_refs, dtype=torch.int64, device=dev)
+    for _ in range(3): eng2.count_device(r.data_ptr(), r.shape[0], hits.data_ptr(), None, 0)
+    eng2.sync(); k = np.mean([eng2.profile_last(b)[0] for b in range(2)])
+    print("%-55s kernel %.3f ms  %.3g reads/s" % (name, k, r.shape[0] / (k * 1e-3)), flush=True)
+run2("random order, per-read search kernel only", p[:20_000_000])
+del v, s, g
+pp = reads[torch.randperm(n, device=dev)]
+run("random order, all %d reads, bucket path" % n, pp, 0)
+run2("random order, all %d reads, search kernel" % n, pp)

@@ -1,0 +1,113 @@
+"""The bucket path for reads in no particular order (gtx_bucket.hip: partition by position bucket, count in LDS)
+against the CPU oracle.  GTX_BUCKET_MIN_READS=1 sends every unsorted call through it, however small."""
+import os
+
+import numpy as np
+import pytest
+
+import gtx
+from gtx import synth
+from oracle import orc
+from test_gpu_fuzz import gen, orders
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def beng():
+    os.environ["GTX_BUCKET_MIN_READS"] = "1"
+    try:
+        e = gtx.Engine(0)
+    finally:
+        del os.environ["GTX_BUCKET_MIN_READS"]
+    yield e
+    e.close()
+
+
+def check(e, refs, reads, n_classes, w=None, flags=0):
+    e.set_refs(refs, n_classes)
+    got, info = e.count(reads, w, flags)
+    sel = reads[:, 0] < n_classes
+    want = orc.count(refs, reads[sel], None if w is None else w[sel], algo=orc.BIN_INDEX)
+    np.testing.assert_array_equal(got, want)
+    return info
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_small_tables(beng, seed):
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(10):
+        n = int(rng.choice([0, 1, 63, 257, 1000, 5000]))
+        m = int(rng.choice([0, 1, 2, 64, 500, 3000, 9000]))
+        n_classes = int(rng.choice([1, 2, 5, 40]))
+        span = int(rng.choice([10, 300, 100000]))
+        refs, reads = gen(rng, n, m, n_classes, span, allow_invalid_refs=True)
+        for r in (orders(rng, reads) if n else [reads]):
+            info = check(beng, refs, r, n_classes)
+            assert info["n_no_class"] == int((reads[:, 0] >= n_classes).sum())
+        if n:
+            w = rng.integers(-2, 6, size=n).astype(np.int32)
+            check(beng, refs, reads, n_classes, w)
+
+
+def test_many_buckets_per_class_shuffled(beng):
+    # 300k regions on 24 chromosomes: ~160 buckets; 2M shuffled reads, one chromosome without regions
+    rng = np.random.default_rng(5)
+    refs = synth.genome_intervals(300_000, 5, 50, 2000)
+    refs = refs[refs[:, 0] != 7]
+    reads = synth.genome_intervals(2_000_000, 6, 36, 36)
+    reads = reads[rng.permutation(len(reads))]
+    check(beng, refs, reads, synth.n_classes())
+    w = rng.integers(0, 4, size=len(reads)).astype(np.int32)
+    check(beng, refs, reads, synth.n_classes(), w)
+
+
+def test_reads_longer_than_a_bucket_fall_back_for_the_starts_histogram(beng):
+    # dense short regions (a bucket spans ~40 kb) and reads of up to 5 Mb: their ends lie far beyond the LDS slice
+    rng = np.random.default_rng(6)
+    m = 60_000
+    rs = np.sort(rng.integers(1, 1_200_000, size=m))
+    refs = np.stack([np.zeros(m, dtype=np.int64), rs, rs + rng.integers(0, 30, size=m)], axis=1).astype(np.int32)
+    n = 200_000
+    qs = rng.integers(1, 1_200_000, size=n)
+    ql = rng.choice([10, 1000, 200_000, 5_000_000], size=n)
+    reads = np.stack([np.zeros(n, dtype=np.int64), qs, qs + ql], axis=1).astype(np.int32)
+    check(beng, refs, reads, 1)
+
+
+def test_duplicate_boundaries_across_bucket_cuts(beng):
+    # 10k regions that all end at one of 3 positions: equal boundaries straddle every bucket cut
+    rng = np.random.default_rng(8)
+    m = 10_000
+    ends = rng.choice([1000, 2000, 3000], size=m)
+    refs = np.stack([np.zeros(m, dtype=np.int64), ends - rng.integers(0, 900, size=m), ends], axis=1).astype(np.int32)
+    n = 50_000
+    qs = rng.choice([999, 1000, 1001, 1999, 2000, 2001, 2999, 3000, 3001, 1, 5000], size=n)
+    reads = np.stack([np.zeros(n, dtype=np.int64), qs, qs + rng.integers(0, 3, size=n)], axis=1).astype(np.int32)
+    check(beng, refs, reads, 1)
+
+
+def test_sorted_semantics_flags_and_degenerate_reads(beng):
+    rng = np.random.default_rng(9)
+    refs = synth.refs_single_chrom(5000, seed=3, chrom_len=1_000_000)
+    reads = synth.reads_single_chrom(20000, seed=4, chrom_len=1_000_000)
+    reads[::50, 2] = reads[::50, 1] - 1                        # zero-length
+    reads[::333, 2] = reads[::333, 1] - 5                      # inverted: reported, never counted
+    reads = reads[rng.permutation(len(reads))]
+    beng.set_refs(refs)
+    got, info = beng.count(reads, None, 0)
+    ok = reads[:, 1] <= reads[:, 2]
+    np.testing.assert_array_equal(got, orc.count(refs, reads[ok], algo=orc.BIN_INDEX))
+    assert info["n_degenerate"] == int((~ok).sum())
+    got, info = beng.count(reads, None, gtx.ZERO_LENGTH_OK)
+    assert info["n_degenerate"] == int((reads[:, 1] > reads[:, 2] + 1).sum())
+
+
+def test_streamed_unsorted_batches_add_up(beng):
+    rng = np.random.default_rng(10)
+    refs = synth.genome_intervals(40_000, 11, 50, 3000)
+    reads = synth.genome_intervals(300_000, 12, 30, 200)
+    reads = reads[rng.permutation(len(reads))]
+    beng.set_refs(refs, synth.n_classes())
+    got, _ = beng.count_stream([(b, None) for b in np.array_split(reads, 7)], 0)
+    np.testing.assert_array_equal(got, orc.count(refs, reads, algo=orc.BIN_INDEX))
