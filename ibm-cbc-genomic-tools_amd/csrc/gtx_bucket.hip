@@ -19,10 +19,11 @@
 //                          searches + two LDS atomics per read, contiguous atomic flush.  A read whose end lies
 //                          beyond the bucket's slice of the starts array (longer than the bucket is wide)
 //                          falls back to a global search + atomic for histogram B.
-// Traffic: 12 B/read read three times + written once + 2 x 2 B ids: ~5 GB for 100 M reads.
+// Traffic per read: 12 B read twice, 8 B (start, end) written and read once, 2 x 2 B ids: ~4.4 GB for 100 M reads.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <type_traits>
 #include "gtx_kernels.h"
 
 namespace gtx {
@@ -105,26 +106,28 @@ __global__ __launch_bounds__(1024) void bucket_scatter_kernel(const Tri3 *__rest
     cnt[i] = 0;
   }
   __syncthreads();
-  Tri3 *__restrict__ out = (Tri3 *)w.tmpReads;
+  int2 *__restrict__ out = (int2 *)w.tmpReads;                  // (start, end): the class is the bucket's
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     if (id[k] == kNoBucket) continue;
     const i64 i = first + k * 1024 + threadIdx.x;
     const unsigned pos = base[id[k]] + atomicAdd(&cnt[id[k]], 1u);
-    out[pos] = reads[i];
+    const Tri3 r = reads[i];
+    out[pos] = make_int2(r.s, r.e);
     if (WEIGHTED) w.tmpWeights[pos] = weights[i];
   }
 }
 
 // all lanes of the wave call this; slot < 0 = nothing to add.  One LDS atomic per run of equal slots.
-__device__ __forceinline__ void lds_run_add(u64 *hist, int slot, int lane)
+template <class H>
+__device__ __forceinline__ void lds_run_add(H *hist, int slot, int lane)
 {
   const int prev = __builtin_amdgcn_update_dpp(slot, slot, 0x138, 0xf, 0xf, false);     // lane below (wave_shr:1)
   const bool head = lane == 0 || slot != prev;
   const u64 heads = __ballot(head);
   if (head && slot >= 0) {
     const u64 rest = lane == 63 ? 0 : heads >> (lane + 1);
-    atomicAdd(&hist[slot], (u64)(rest ? __builtin_ctzll(rest) + 1 : 64 - lane));
+    atomicAdd(&hist[slot], (H)(rest ? __builtin_ctzll(rest) + 1 : 64 - lane));
   }
 }
 
@@ -134,19 +137,21 @@ template <bool WEIGHTED>
 __global__ __launch_bounds__(512) void bucket_count_kernel(CountArgs a, BucketTable t, BucketWork w, int splits)
 {
   __shared__ int sE[kBktE], sS[kBktS];
-  __shared__ u64 hA[kBktE + 1], hB[kBktS + 1];
+  typedef typename std::conditional<WEIGHTED, u64, unsigned>::type hist_t;   // a block sees < 2^32 reads
+  __shared__ hist_t hA[kBktE + 1], hB[kBktS + 1];
   const int b = blockIdx.x / splits, k = blockIdx.x % splits;
   const unsigned off = w.offset[b], cntB = w.offset[b + 1] - off;
   const unsigned r0 = off + (unsigned)((u64)cntB * k / splits), r1 = off + (unsigned)((u64)cntB * (k + 1) / splits);
   if (r0 == r1) return;
   const int eLo = t.eLo[b], nE = t.eHi[b] - eLo, sLo = t.sLo[b], sHi = t.sHi[b], nS = sHi - sLo, cls = t.cls[b];
   const int segEnd = a.segStart[cls + 1];
-  for (int i = threadIdx.x; i < nE; i += blockDim.x) sE[i] = a.sortedE[eLo + i];
-  for (int i = threadIdx.x; i < nS; i += blockDim.x) sS[i] = a.sortedS[sLo + i];
+  // slices padded with +inf to their full power-of-two size: the searches below are branch-free with a fixed trip count
+  for (int i = threadIdx.x; i < kBktE; i += blockDim.x) sE[i] = i < nE ? a.sortedE[eLo + i] : INT_MAX;
+  for (int i = threadIdx.x; i < kBktS; i += blockDim.x) sS[i] = i < nS ? a.sortedS[sLo + i] : INT_MAX;
   for (int i = threadIdx.x; i <= nE; i += blockDim.x) hA[i] = 0;
   for (int i = threadIdx.x; i <= nS; i += blockDim.x) hB[i] = 0;
   __syncthreads();
-  const Tri3 *__restrict__ reads = (const Tri3 *)w.tmpReads;
+  const int2 *__restrict__ reads = (const int2 *)w.tmpReads;
   const int lane = threadIdx.x & 63;
   const unsigned cnt = r1 - r0;
   for (unsigned at = 0; at < cnt; at += blockDim.x) {            // wave-uniform trip count: the run compression below needs all lanes
@@ -155,13 +160,18 @@ __global__ __launch_bounds__(512) void bucket_count_kernel(CountArgs a, BucketTa
     int slotA = -1, slotB = -1;
     u64 wt = 1;
     if (live) {
-      const Tri3 r = reads[i];
+      const int2 se = reads[i];
+      struct { int s, e; } r = {se.x, se.y};
       if (WEIGHTED) wt = (u64)(i64)w.tmpWeights[i];
-      int lo = 0, hi = nE;                                        // #{E < s} inside the slice
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (sE[mid] < r.s) lo = mid + 1; else hi = mid; }
+      int lo = 0;                                                 // #{E < s} inside the slice
+#pragma unroll
+      for (int half = kBktE / 2; half >= 1; half >>= 1) lo += sE[lo + half - 1] < r.s ? half : 0;
+      lo += sE[lo] < r.s ? 1 : 0;
       slotA = lo;
-      lo = 0; hi = nS;                                            // #{S <= e} inside the slice
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (sS[mid] <= r.e) lo = mid + 1; else hi = mid; }
+      lo = 0;                                                     // #{S <= e} inside the slice (coordinates are < INT_MAX)
+#pragma unroll
+      for (int half = kBktS / 2; half >= 1; half >>= 1) lo += sS[lo + half - 1] <= r.e ? half : 0;
+      lo += sS[lo] <= r.e ? 1 : 0;
       if (lo < nS || sHi == segEnd) slotB = lo;
       else {                                                      // the read ends beyond the slice: global search above it
         int glo = sHi, ghi = segEnd;
@@ -170,8 +180,8 @@ __global__ __launch_bounds__(512) void bucket_count_kernel(CountArgs a, BucketTa
       }
     }
     if (WEIGHTED) {
-      if (slotA >= 0) atomicAdd(&hA[slotA], wt);
-      if (slotB >= 0) atomicAdd(&hB[slotB], wt);
+      if (slotA >= 0) atomicAdd(&hA[slotA], (hist_t)wt);
+      if (slotB >= 0) atomicAdd(&hB[slotB], (hist_t)wt);
     } else {
       // neighbouring lanes in the same slot (input that was in order before the partition) share one LDS atomic
       lds_run_add(hA, slotA, lane);

@@ -299,7 +299,7 @@ static int launch_unsorted(gtx_ctx *c, const void *d_reads, const void *d_weight
   if ((size_t)n > c->capBkt) {
     dfree(c->d_bktIds); dfree(c->d_bktReads); dfree(c->d_bktWeights); c->capBkt = 0;
     HIPCHK(c, hipMalloc(&c->d_bktIds, sizeof(unsigned short) * (size_t)n));
-    HIPCHK(c, hipMalloc(&c->d_bktReads, 12 * (size_t)n));
+    HIPCHK(c, hipMalloc(&c->d_bktReads, 8 * (size_t)n));
     HIPCHK(c, hipMalloc(&c->d_bktWeights, 4 * (size_t)n));
     c->capBkt = (size_t)n;
   }
