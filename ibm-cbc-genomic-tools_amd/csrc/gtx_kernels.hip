@@ -593,7 +593,117 @@ __device__ __forceinline__ u64 walk_cov_chunk(WIN &X, const Seg &sg, int key, in
   }
 }
 
-template <bool WEIGHTED>
+// The same for a whole step of 4 x 64 reads (register r of lane l = read 64 r + l): keys non-decreasing over all
+// 256, prefix sums per register, and per boundary one count over the four registers + ONE v_readlane in the
+// register the boundary falls into.  The per-step bookkeeping (class / validity tests, window checks, scans) is
+// paid once per 256 reads instead of once per 64.  cov_step4_ok() says whether a window can take the step.
+template <class WIN>
+__device__ __forceinline__ bool cov_step4_ok(const WIN &X, const int (&k)[4], int lane, bool valid)
+{
+  if (!valid) return false;
+  const int kbase = rdlane(k[0], 0), ktop = rdlane(k[3], 63);
+  if ((unsigned)(ktop - kbase) >= (1u << 22) || WIN::below(kbase, X.prevW)) return false;
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int prev = lane_prev(k[r]);
+    if (r > 0) { const int last = rdlane(k[r - 1], 63); prev = lane == 0 ? last : prev; }
+    bad |= k[r] < prev;
+  }
+  return __ballot(bad) == 0;
+}
+
+template <class WIN>
+__device__ __forceinline__ void cov_step4_run(WIN &X, const Seg &sg, const int (&k)[4], int lane, bool &valid)
+{
+  const int kbase = rdlane(k[0], 0);
+  int q[4], tot[4];                                             // exclusive in-register prefix of the relative keys; register totals
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const int rel = k[r] - kbase; const int p = wave_scan_add(rel); q[r] = p - rel; tot[r] = rdlane(p, 63); }
+  const int cum1 = tot[0], cum2 = cum1 + tot[1], cum3 = cum2 + tot[2], cum4 = cum3 + tot[3];
+  int cprev = 0, sprev = 0, adv = 0;
+  for (;;) {
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c += __popcll(__ballot(WIN::below(k[r], X.curW)));
+    // the keys are ordered, so the c keys at or below the boundary are registers 0 .. c/64-1 entirely + the first c%64 lanes of the next
+    const int rc = c >> 6, lc = c & 63;
+    const int qsel = rc == 0 ? q[0] : rc == 1 ? q[1] : rc == 2 ? q[2] : q[3];
+    const int below = rc == 0 ? 0 : rc == 1 ? cum1 : rc == 2 ? cum2 : rc == 3 ? cum3 : cum4;
+    const int srel = below + (rc < 4 ? rdlane(qsel, lc) : 0);
+    const int dc = c - cprev;
+    X.pend += dc;
+    X.pend2 += (i64)kbase * dc + (srel - sprev);
+    cprev = c; sprev = srel;
+    if (c == 256) return;
+    if (X.fwd(sg, lane) && ++adv > 2) {
+      X.flush(sg, lane); valid = false;
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) {                             // the reads not yet placed add themselves
+        const int kr = r == 0 ? k[0] : r == 1 ? k[1] : r == 2 ? k[2] : k[3];
+        const u64 m = __ballot(64 * r + lane >= c);
+        if (m) X.lanes_add(sg, kr, 1, m, lane);
+      }
+      return;
+    }
+  }
+}
+
+// per-wave state of one coverage pass.  The pass over one boundary array (STRICT = false: the ends array,
+// true: the starts array) walks two windows, keyed by the read starts (Ws) and by the read ends (We).  The two
+// arrays are two launches: half the live state per wave (twice the waves per SIMD) and half the code in the
+// instruction cache for one extra streaming read of the 12-byte triples.
+template <bool WEIGHTED, bool STRICT>
+struct CovState {
+  Win<WEIGHTED, STRICT, true> Ws, We;
+  bool vs, ve;
+  Seg sg;
+  int nNoClass, nDegen; i64 firstDegen;
+};
+
+// one chunk of 64 reads, any mix of classes / invalid reads (`active` masks a partial chunk)
+template <bool WEIGHTED, bool STRICT>
+__device__ __forceinline__ void cov_chunk(CovState<WEIGHTED, STRICT> &st, const CoverArgs &a, const Tri &t, int w, u64 active, i64 firstIndex, int lane)
+{
+  Seg &sg = st.sg;
+  int c0 = rdlane(t.c, 0);
+  if (sg.cls >= 0 && (__ballot(t.c == sg.cls) & active)) c0 = sg.cls;
+  if (c0 != sg.cls && (unsigned)c0 < (unsigned)a.nClasses) {
+    if (st.vs) st.Ws.flush(sg, lane);
+    if (st.ve) st.We.flush(sg, lane);
+    st.vs = st.ve = false;
+    sg.start = rfl(a.segStart[c0]); sg.end = rfl(a.segStart[c0 + 1]); sg.cls = c0;
+  }
+  const u64 noclass = __ballot((unsigned)t.c >= (unsigned)a.nClasses) & active;
+  const u64 degen = __ballot(t.s > t.e) & active & ~noclass;        // zero-length or inverted: contributes nothing
+  const u64 mine = __ballot(t.c == sg.cls) & active & ~degen & ~noclass;
+  const u64 other = active & ~mine & ~degen & ~noclass;
+  if (!STRICT && (degen | noclass)) {                                 // reported once, by the pass over the ends array
+    st.nNoClass += __popcll(noclass);
+    const u64 inv = __ballot(t.s > t.e + 1) & degen;                // only these are reported (the packer's business)
+    if (inv) { st.nDegen += __popcll(inv); i64 p = firstIndex + (__ffsll((unsigned long long)inv) - 1); if (p < st.firstDegen) st.firstDegen = p; }
+  }
+  if (mine && sg.start != sg.end) {
+    u64 r0, r1;
+    if (!WEIGHTED && mine == ~0ull) {
+      r0 = walk_cov_chunk(st.Ws, sg, t.s, lane, st.vs);
+      r1 = walk_cov_chunk(st.We, sg, t.e, lane, st.ve);
+    } else {
+      r0 = st.Ws.walk(sg, t.s, w, mine, lane, st.vs);
+      r1 = st.We.walk(sg, t.e, w, mine, lane, st.ve);
+    }
+    if (r0) st.Ws.lanes_add(sg, t.s, w, r0, lane);
+    if (r1) st.We.lanes_add(sg, t.e, w, r1, lane);
+  }
+  if (other) {
+    Seg so; so.start = 0; so.end = 0; so.cls = 0;
+    if ((other >> lane) & 1) { so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c; }
+    const u64 has = __ballot(so.start != so.end) & other;
+    if (has) { st.Ws.lanes_add(so, t.s, w, has, lane); st.We.lanes_add(so, t.e, w, has, lane); }
+  }
+}
+
+template <bool WEIGHTED, bool STRICT>
 __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CoverArgs a)
 {
   const int lane = threadIdx.x & 63;
@@ -603,83 +713,56 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
   i64 cnt = n - first; if (cnt > (i64)a.chunksPerWave * 64) cnt = (i64)a.chunksPerWave * 64;
   const int nMine = (int)cnt;
 
-  Win<WEIGHTED, false, true> As, Ae;          // ends array:   #{E_j <  key}
-  Win<WEIGHTED, true, true> Bs, Be;           // starts array: #{S_j <= key}
-  As.arr = Ae.arr = a.sortedE; Bs.arr = Be.arr = a.sortedS;
-  As.hist = a.hist[0]; As.hist2 = a.hist[1]; As.part = a.part[0]; As.part2 = a.part[1];
-  Ae.hist = a.hist[2]; Ae.hist2 = a.hist[3]; Ae.part = a.part[2]; Ae.part2 = a.part[3];
-  Bs.hist = a.hist[4]; Bs.hist2 = a.hist[5]; Bs.part = a.part[4]; Bs.part2 = a.part[5];
-  Be.hist = a.hist[6]; Be.hist2 = a.hist[7]; Be.part = a.part[6]; Be.part2 = a.part[7];
-  As.acc = Ae.acc = Bs.acc = Be.acc = 0; As.acc2 = Ae.acc2 = Bs.acc2 = Be.acc2 = 0;
-  As.pend = Ae.pend = Bs.pend = Be.pend = 0; As.pend2 = Ae.pend2 = Bs.pend2 = Be.pend2 = 0;
-  As.j = Ae.j = Bs.j = Be.j = 0; As.base = Ae.base = Bs.base = Be.base = 0;
-  As.W = As.Wn = Ae.W = Ae.Wn = Bs.W = Bs.Wn = Be.W = Be.Wn = kHi;
-  As.prevW = Ae.prevW = Bs.prevW = Be.prevW = kLo; As.curW = Ae.curW = Bs.curW = Be.curW = kHi;
-  bool vAs = false, vAe = false, vBs = false, vBe = false;
-  Seg sg; sg.start = 0; sg.end = 0; sg.cls = -1;
-  int nNoClass = 0, nDegen = 0; i64 firstDegen = INT64_MAX;
+  CovState<WEIGHTED, STRICT> st;
+  constexpr int h0 = STRICT ? 4 : 0;                              // histograms 0..3 belong to the ends array, 4..7 to the starts array
+  st.Ws.arr = st.We.arr = STRICT ? a.sortedS : a.sortedE;
+  st.Ws.hist = a.hist[h0]; st.Ws.hist2 = a.hist[h0 + 1]; st.Ws.part = a.part[h0]; st.Ws.part2 = a.part[h0 + 1];
+  st.We.hist = a.hist[h0 + 2]; st.We.hist2 = a.hist[h0 + 3]; st.We.part = a.part[h0 + 2]; st.We.part2 = a.part[h0 + 3];
+  st.Ws.acc = st.We.acc = 0; st.Ws.acc2 = st.We.acc2 = 0; st.Ws.pend = st.We.pend = 0; st.Ws.pend2 = st.We.pend2 = 0;
+  st.Ws.j = st.We.j = 0; st.Ws.base = st.We.base = 0;
+  st.Ws.W = st.Ws.Wn = st.We.W = st.We.Wn = kHi;
+  st.Ws.prevW = st.We.prevW = kLo; st.Ws.curW = st.We.curW = kHi;
+  st.vs = st.ve = false;
+  st.sg.start = 0; st.sg.end = 0; st.sg.cls = -1;
+  st.nNoClass = 0; st.nDegen = 0; st.firstDegen = INT64_MAX;
 
-  // the next chunk's reads are requested before the current chunk is worked on (3-4 waves per SIMD at this
-  // register count: the load latency would otherwise sit in front of every chunk)
-  Tri tn; tn.c = -1; tn.s = 0; tn.e = 0; int wn = 1;
-  if (lane < nMine) { tn = load_tri((const char *)(reads + first + lane)); if (WEIGHTED) wn = weights[first + lane]; }
-  for (int at = 0; at < nMine; at += 64) {
+  // Steps of 4 x 64 reads wherever both windows can take them (one class, valid reads, ordered keys); otherwise ONE
+  // chunk goes through the general code and the next step is tried right after it -- steps need no alignment.
+  // The general code exists once (it is large; two copies of it would not share the instruction cache well).
+  const char *base = (const char *)(reads + first) + (size_t)lane * 12;
+  int at = 0;
+  while (at < nMine) {
+    if (!WEIGHTED && at + 256 <= nMine && st.sg.cls >= 0) {
+      Tri t[4];
+      const char *p = base + (size_t)at * 12;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[r] = load_tri(p + 768 * r);
+      bool odd = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) odd |= t[r].c != st.sg.cls || t[r].s > t[r].e;
+      if (__ballot(odd) == 0) {
+        if (st.sg.start == st.sg.end) { at += 256; continue; }    // a class without reference regions
+        const int ks[4] = {t[0].s, t[1].s, t[2].s, t[3].s}, ke[4] = {t[0].e, t[1].e, t[2].e, t[3].e};
+        if (cov_step4_ok(st.Ws, ks, lane, st.vs) && cov_step4_ok(st.We, ke, lane, st.ve)) {
+          cov_step4_run(st.Ws, st.sg, ks, lane, st.vs);
+          cov_step4_run(st.We, st.sg, ke, lane, st.ve);
+          at += 256;
+          continue;
+        }
+      }
+    }
     const int left = nMine - at;
     const u64 active = left >= 64 ? ~0ull : ((1ull << left) - 1);
-    const Tri t = tn; const int w = wn;
-    tn.c = -1; tn.s = 0; tn.e = 0; wn = 1;
-    if (at + 64 + lane < nMine) { tn = load_tri((const char *)(reads + first + at + 64 + lane)); if (WEIGHTED) wn = weights[first + at + 64 + lane]; }
-    int c0 = rdlane(t.c, 0);
-    if (sg.cls >= 0 && (__ballot(t.c == sg.cls) & active)) c0 = sg.cls;
-    if (c0 != sg.cls && (unsigned)c0 < (unsigned)a.nClasses) {
-      if (vAs) As.flush(sg, lane);
-      if (vAe) Ae.flush(sg, lane);
-      if (vBs) Bs.flush(sg, lane);
-      if (vBe) Be.flush(sg, lane);
-      vAs = vAe = vBs = vBe = false;
-      sg.start = rfl(a.segStart[c0]); sg.end = rfl(a.segStart[c0 + 1]); sg.cls = c0;
-    }
-    const u64 noclass = __ballot((unsigned)t.c >= (unsigned)a.nClasses) & active;
-    const u64 degen = __ballot(t.s > t.e) & active & ~noclass;        // zero-length or inverted: contributes nothing
-    const u64 mine = __ballot(t.c == sg.cls) & active & ~degen & ~noclass;
-    const u64 other = active & ~mine & ~degen & ~noclass;
-    if (degen | noclass) {
-      nNoClass += __popcll(noclass);
-      const u64 inv = __ballot(t.s > t.e + 1) & degen;                // only these are reported (the packer's business)
-      if (inv) { nDegen += __popcll(inv); i64 p = first + at + (__ffsll((unsigned long long)inv) - 1); if (p < firstDegen) firstDegen = p; }
-    }
-    if (mine && sg.start != sg.end) {
-      u64 r0, r1, r2, r3;
-      if (!WEIGHTED && mine == ~0ull) {
-        r0 = walk_cov_chunk(As, sg, t.s, lane, vAs);
-        r1 = walk_cov_chunk(Ae, sg, t.e, lane, vAe);
-        r2 = walk_cov_chunk(Bs, sg, t.s, lane, vBs);
-        r3 = walk_cov_chunk(Be, sg, t.e, lane, vBe);
-      } else {
-        r0 = As.walk(sg, t.s, w, mine, lane, vAs);
-        r1 = Ae.walk(sg, t.e, w, mine, lane, vAe);
-        r2 = Bs.walk(sg, t.s, w, mine, lane, vBs);
-        r3 = Be.walk(sg, t.e, w, mine, lane, vBe);
-      }
-      if (r0) As.lanes_add(sg, t.s, w, r0, lane);
-      if (r1) Ae.lanes_add(sg, t.e, w, r1, lane);
-      if (r2) Bs.lanes_add(sg, t.s, w, r2, lane);
-      if (r3) Be.lanes_add(sg, t.e, w, r3, lane);
-    }
-    if (other) {
-      Seg so; so.start = 0; so.end = 0; so.cls = 0;
-      if ((other >> lane) & 1) { so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c; }
-      const u64 has = __ballot(so.start != so.end) & other;
-      if (has) { As.lanes_add(so, t.s, w, has, lane); Ae.lanes_add(so, t.e, w, has, lane); Bs.lanes_add(so, t.s, w, has, lane); Be.lanes_add(so, t.e, w, has, lane); }
-    }
+    Tri t; t.c = -1; t.s = 0; t.e = 0; int w = 1;
+    if (lane < left) { t = load_tri(base + (size_t)at * 12); if (WEIGHTED) w = weights[first + at + lane]; }
+    cov_chunk(st, a, t, w, active, first + at, lane);
+    at += 64;
   }
-  if (vAs) As.flush(sg, lane);
-  if (vAe) Ae.flush(sg, lane);
-  if (vBs) Bs.flush(sg, lane);
-  if (vBe) Be.flush(sg, lane);
-  if (lane == 0) {
-    if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
-    if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen); }
+  if (st.vs) st.Ws.flush(st.sg, lane);
+  if (st.ve) st.We.flush(st.sg, lane);
+  if (!STRICT && lane == 0) {
+    if (st.nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)st.nNoClass);
+    if (st.nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)st.nDegen); atomicMin((i64 *)&a.info->first_degenerate, st.firstDegen); }
   }
 }
 
@@ -1081,8 +1164,14 @@ hipError_t launch_coverage(const void *reads, const void *weights, i64 n, const 
   const i64 nChunks = (n + 63) >> 6;
   const i64 waves = (nChunks + a.chunksPerWave - 1) / a.chunksPerWave;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  if (weights) coverage_walk_kernel<true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-  else coverage_walk_kernel<false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  // one pass per boundary array (see CovState)
+  if (weights) {
+    coverage_walk_kernel<true, false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    coverage_walk_kernel<true, true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  } else {
+    coverage_walk_kernel<false, false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    coverage_walk_kernel<false, true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  }
   return hipGetLastError();
 }
 
