@@ -8,6 +8,7 @@
 #include <string.h>
 #include <algorithm>
 #include <future>
+#include <thread>
 #include <iostream>
 
 #include "gtx.h"
@@ -186,6 +187,8 @@ void GenomicRegionSet::Init()
 
   if (load_in_memory) {
     std::vector<GenomicRegion *> regs;
+    // (building the region objects in parallel does not pay: the load is bound by first-touch page faults of the
+    // ~200 B of heap per region, which the kernel serialises)
     for (; line; line = src->Next()) regs.push_back(new GenomicRegionBED(line, src->line_no()));
     n_regions = (long int)regs.size();
     R = n_regions > 0 ? new GenomicRegion *[n_regions] : NULL;
@@ -386,16 +389,19 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool ignore_s
 
   // ---- index side ----
   ChromTable chroms;
+  const char *last_name = NULL;                                                     // region files repeat a chromosome many times in a row
   for (long int k = 0; k < M; k++) {
     GenomicInterval *i = IndexSet->R[k]->I.front();
     if (!sorted && (i->START > i->STOP || i->STOP <= 0)) continue;                 // :5609, :5659
-    chroms.Add(i->CHROMOSOME);
+    if (last_name && strcmp(last_name, i->CHROMOSOME) == 0) continue;
+    chroms.Add(i->CHROMOSOME); last_name = i->CHROMOSOME;
   }
   chroms.Freeze();
   const int n_chrom = chroms.size();
   const bool strand_aware = !ignore_strand;
   bool zero_length_refs = false;
   std::vector<int32_t> refs((size_t)3 * (M > 0 ? M : 1));
+  last_name = NULL; int last_id = -1;
   for (long int k = 0; k < M; k++) {
     GenomicRegion *r = IndexSet->R[k];
     GenomicInterval *i = r->I.front();
@@ -407,7 +413,8 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool ignore_s
     }
     if (i->START >= INT_MAX - 1 || i->STOP >= INT_MAX - 1 || i->START <= INT_MIN + 1 || i->STOP <= INT_MIN + 1)
       r->PrintError("coordinate does not fit the packed 32-bit representation of the MI355X path!");
-    int id = chroms.Find(i->CHROMOSOME);
+    if (!last_name || strcmp(last_name, i->CHROMOSOME) != 0) { last_name = i->CHROMOSOME; last_id = chroms.Find(i->CHROMOSOME); }
+    const int id = last_id;
     if (id < 0) { refs[3 * k] = 0; refs[3 * k + 1] = 1; refs[3 * k + 2] = 0; continue; }   // invalid region: never matches
     refs[3 * k] = id + ((strand_aware && i->STRAND == '-') ? n_chrom : 0);
     refs[3 * k + 1] = (int32_t)i->START; refs[3 * k + 2] = (int32_t)i->STOP;

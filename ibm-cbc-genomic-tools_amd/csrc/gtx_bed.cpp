@@ -187,6 +187,42 @@ BedStatus ParseBedLine(char *line, BedFields *o, char **bad)
   return BED_OK;
 }
 
+// One pass over a line of the common shape -- TAB-separated, no blanks anywhere, 3..11 columns, a plain strand
+// column -- doing what ParseBedLine does for it (the tokenizer rules only differ from a plain split when blanks
+// are involved).  Returns the character after the line's '\n', or NULL when the line is not of that shape (the
+// line is left untouched and goes through ParseBedLine) or the block ends without a '\n'.
+static inline char *ParseTabbedLine(char *line, char *end, BedFields *o)
+{
+  char *tab[6]; int nt = 0;
+  char *p = line, *last_tab = nullptr;
+  for (; p < end; p++) {
+    const char ch = *p;
+    if (ch == '\n') break;
+    if (ch == ' ') return nullptr;
+    if (ch == '\t') { if (nt < 6) tab[nt] = p; nt++; last_tab = p; }
+  }
+  if (p >= end || nt < 2) return nullptr;
+  // tokens as CountTokens sees them: one per TAB, plus the piece after the last TAB unless it is empty
+  const int n_tokens = nt + (p > last_tab + 1 ? 1 : 0);
+  if (n_tokens < 3 || n_tokens > 11) return nullptr;
+  char strand = '+';
+  if (n_tokens >= 6) {
+    const char *t = tab[4] + 1, *te = nt >= 6 ? tab[5] : p;
+    const long len = te - t;
+    if (len == 1 && (t[0] == '+' || t[0] == '.' || t[0] == '1')) strand = '+';
+    else if ((len == 1 && t[0] == '-') || (len == 2 && t[0] == '-' && t[1] == '1')) strand = '-';
+    else return nullptr;                                        // the general path words the error
+  }
+  o->n_tokens = n_tokens;
+  o->chrom = line; *tab[0] = 0;
+  o->start = FastAtol(tab[0] + 1) + 1;
+  o->stop = FastAtol(tab[1] + 1);
+  o->strand = strand;
+  o->label = nullptr;
+  if (n_tokens >= 4) { o->label = tab[2] + 1; if (nt >= 4) *tab[3] = 0; else *p = 0; }
+  return p + 1;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // ChromTable
 // ---------------------------------------------------------------------------------------------------
@@ -267,14 +303,18 @@ void ParsePiece(Piece *p, const PackOptions &o)
   p->tri.reserve(est * 3);
   if (weighted) p->w.reserve(est);
   while (cur < p->end) {
-    char *nl = (char *)memchr(cur, '\n', (size_t)(p->end - cur));
-    if (!nl) break;
-    *nl = 0;
-    char *line = cur;
-    cur = nl + 1;
-    line_no++;
     BedFields f; char *bad = nullptr;
-    BedStatus st = ParseBedLine(line, &f, &bad);
+    BedStatus st = BED_OK;
+    if (char *next = ParseTabbedLine(cur, p->end, &f)) { cur = next; line_no++; }
+    else {
+      char *nl = (char *)memchr(cur, '\n', (size_t)(p->end - cur));
+      if (!nl) break;
+      *nl = 0;
+      char *line = cur;
+      cur = nl + 1;
+      line_no++;
+      st = ParseBedLine(line, &f, &bad);
+    }
     if (st == BED_TOO_FEW_TOKENS) { SetErr(&p->err, line_no, "number of tokens should be at least 3 for BED format!"); break; }
     if (st == BED_BAD_STRAND) { SetErr(&p->err, line_no, std::string("Error: invalid strand '") + bad + "'!", true); break; }
     if (f.n_tokens == 12) { SetErr(&p->err, line_no, "multi-interval (BED12) regions are outside the MI355X counting path!"); break; }

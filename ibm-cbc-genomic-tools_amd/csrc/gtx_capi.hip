@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 #include "gtx.h"
 #include "gtx_kernels.h"
@@ -178,8 +179,14 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
     itS[i] = {tri[3 * (int64_t)k], tri[3 * (int64_t)k + 1], k};
   }
   auto cmp = [](const Item &a, const Item &b) { return a.cls != b.cls ? a.cls < b.cls : (a.val != b.val ? a.val < b.val : a.k < b.k); };
-  std::sort(itE.begin(), itE.end(), cmp);
-  std::sort(itS.begin(), itS.end(), cmp);
+  if (nv > (1 << 16)) {                                      // the two orders are independent: sort them side by side
+    std::thread other([&] { std::sort(itS.begin(), itS.end(), cmp); });
+    std::sort(itE.begin(), itE.end(), cmp);
+    other.join();
+  } else {
+    std::sort(itE.begin(), itE.end(), cmp);
+    std::sort(itS.begin(), itS.end(), cmp);
+  }
 
   std::vector<int32_t> sortedE(nv + 1), sortedS(nv + 1), seg(nClasses + 1, 0), posE(m > 0 ? m : 1, -1), posS(m > 0 ? m : 1, -1), classBase(m > 0 ? m : 1, -1);
   for (int64_t i = 0; i < nv; i++) seg[itE[i].cls + 1]++;
