@@ -27,9 +27,10 @@
 // themselves by binary search); only the speed depends on the order.
 // No MFMA anywhere: this is integer indexing, not a contraction.
 //
-// Kernels in this file: count_walk_kernel (dominant), count_search_kernel (order-agnostic),
-// coverage_walk_kernel (CalcIndexCoverage), tile_sums/finalize_scan/gather_hits/gather_coverage
-// (prefix + gather), scan_hist_kernel + scan_window_kernel (genomic_scans counts).
+// Kernels in this file: count_walk_kernel (dominant), count_search_kernel (order-agnostic, small batches; large
+// unsorted batches take the bucket path of gtx_bucket.hip), coverage_walk_kernel (CalcIndexCoverage, one launch
+// per boundary array), tile_sums/finalize_scan/gather_hits/gather_coverage (prefix + gather), scan_hist_kernel +
+// scan_window_kernel (genomic_scans counts).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
