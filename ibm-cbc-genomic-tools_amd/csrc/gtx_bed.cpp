@@ -166,6 +166,17 @@ static inline long FastAtol(const char *p)
   return neg ? -(long)v : (long)v;
 }
 
+// the same on a token that ends at `end` instead of a NUL
+static inline long FastAtolTo(const char *p, const char *end)
+{
+  while (p < end && (*p == ' ' || (*p >= '\t' && *p <= '\r'))) p++;
+  bool neg = false;
+  if (p < end && *p == '-') { neg = true; p++; } else if (p < end && *p == '+') p++;
+  unsigned long v = 0;
+  while (p < end && *p >= '0' && *p <= '9') { v = v * 10 + (unsigned long)(*p - '0'); p++; }
+  return neg ? -(long)v : (long)v;
+}
+
 BedStatus ParseBedLine(char *line, BedFields *o, char **bad)
 {
   const char sep = strchr(line, '\t') ? '\t' : ' ';
@@ -215,8 +226,8 @@ static inline char *ParseTabbedLine(char *line, char *end, BedFields *o)
   }
   o->n_tokens = n_tokens;
   o->chrom = line; *tab[0] = 0;
-  o->start = FastAtol(tab[0] + 1) + 1;
-  o->stop = FastAtol(tab[1] + 1);
+  o->start = FastAtolTo(tab[0] + 1, tab[1]) + 1;
+  o->stop = FastAtolTo(tab[1] + 1, nt >= 3 ? tab[2] : p);
   o->strand = strand;
   o->label = nullptr;
   if (n_tokens >= 4) { o->label = tab[2] + 1; if (nt >= 4) *tab[3] = 0; else *p = 0; }
@@ -305,7 +316,9 @@ void ParsePiece(Piece *p, const PackOptions &o)
   while (cur < p->end) {
     BedFields f; char *bad = nullptr;
     BedStatus st = BED_OK;
-    if (char *next = ParseTabbedLine(cur, p->end, &f)) { cur = next; line_no++; }
+    static const bool fast_lines = getenv("GTX_NO_FAST_PARSE") == nullptr;      // (the tests compare both ways)
+    char *next = fast_lines ? ParseTabbedLine(cur, p->end, &f) : nullptr;
+    if (next) { cur = next; line_no++; }
     else {
       char *nl = (char *)memchr(cur, '\n', (size_t)(p->end - cur));
       if (!nl) break;

@@ -130,3 +130,33 @@ def test_bed12_and_range_are_rejected():
     assert rc == 1 and "BED12" in err
     rc, _, _, err = pack(["ou", "-c", "chr1"], stdin=b"chr1\t0\t3000000000\n")
     assert rc == 1 and "32-bit" in err
+
+
+@pytest.mark.parametrize("mode,extra", [("ou", []), ("os", ["-z"]), ("su", ["-a"]), ("ss", ["-a", "-l", "3"]), ("ou", ["-a", "-l", "4"])])
+def test_one_pass_tab_parser_agrees_with_the_general_tokenizer(tmp_path, mode, extra):
+    """The fast path for plain TAB-separated lines must be indistinguishable from the tokenizer that follows the
+    reference's rules: random lines built from digits, signs, letters, dots and TABs (no blanks), 1..13 columns,
+    empty columns, trailing TABs, odd strand tokens -- same triples, weights, line counts and the same first error."""
+    rng = np.random.default_rng(len(mode) * 100 + len(extra))
+    alphabet = list("0123456789") * 3 + list("-+.ax1")
+    for trial in range(int(os.environ.get("GTX_PARSE_TRIALS", "60"))):
+        lines = []
+        for _ in range(int(rng.integers(1, 40))):
+            ncol = int(rng.choice([1, 2, 3, 3, 4, 5, 6, 6, 6, 7, 11, 12, 13]))
+            cols = []
+            for c in range(ncol):
+                if c == 0:
+                    cols.append(str(rng.choice(["chr1", "chr2", "chr9", "chrX", ""])))
+                elif c in (1, 2) and rng.random() < 0.85:
+                    cols.append(str(int(rng.integers(-5, 5000))))
+                elif c == 5 and rng.random() < 0.8:
+                    cols.append(str(rng.choice(["+", "-", ".", "1", "-1", "+1", "--", ""])))
+                else:
+                    cols.append("".join(rng.choice(alphabet, size=int(rng.integers(0, 4)))))
+            lines.append("\t".join(cols) + ("\t" if rng.random() < 0.1 else ""))
+        f = tmp_path / ("t%d.bed" % trial)
+        f.write_text("\n".join(lines) + "\n")
+        args = [mode] + extra + ["-t", "3", "-c", "chr1,chr2,chrX", str(f)]
+        fast = subprocess.run([TOOL] + args, capture_output=True)
+        slow = subprocess.run([TOOL] + args, capture_output=True, env=dict(os.environ, GTX_NO_FAST_PARSE="1"))
+        assert (fast.returncode, fast.stdout, fast.stderr) == (slow.returncode, slow.stdout, slow.stderr), lines
