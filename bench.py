@@ -226,6 +226,9 @@ def main():
                     help="count = BASELINE config 3 (the headline metric); scans = config 4: genomic_scans counts -i -w 1000 -d 1000; "
                          "permutation_test = the shuffle part of config 5")
     ap.add_argument("--shuffles", type=int, default=10000, help="permutation_test: shuffles per GPU per step")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="count, N=1: after the timed region also time the same steps alternating two contexts on two HIP streams "
+                         "(extra 'two_streams' object; off by default so that a kernel trace of the default command sees only the timed steps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -375,7 +378,7 @@ def main():
     # finalize launches of one step run under the streaming kernel of the next (N=1 only; reported for information,
     # the per-kernel roofline above is measured without this overlap)
     two_streams = None
-    if rank == 0 and world == 1 and os.environ.get("GTX_BENCH_TWO_STREAMS", "1") == "1":
+    if rank == 0 and world == 1 and args.two_streams:
         s2 = torch.cuda.Stream()
         eng2 = gtx.Engine(local)
         eng2.set_refs(refs, synth.n_classes())

@@ -5,7 +5,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
 tag = sys.argv[1]; rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
 src = R + "gpurun_out/refresh_%s/" % tag
 for a, b in (("bench_line", "bench_line"), ("bench_scans_line", "bench_scans_line"), ("bench_perm_line", "bench_perm_line"),
-             ("bench_line_under_rocprof", "bench_line_under_rocprof")):
+             ("bench_line_under_rocprof", "bench_line_under_rocprof"), ("bench_line_two_streams", "bench_line_two_streams")):
     shutil.copy(src + a + ".json", R + "profiles/%s_%s.json" % (rnd, b))
 shutil.copy(glob.glob(src + "stats/*/*kernel_stats.csv")[0], R + "profiles/%s_bench_kernel_stats.csv" % rnd)
 lines, keep = [], False
@@ -32,4 +32,6 @@ out = {"kernel": "count_walk_kernel<false,4>",
        "algorithmic_bytes_per_launch": 1.2e9, "counters": ctr}
 json.dump(out, open(R + "profiles/%s_pmc_count_walk.json" % rnd, "w"), indent=1)
 d = json.load(open(R + "profiles/%s_bench_line.json" % rnd))
+d2 = json.load(open(R + "profiles/%s_bench_line_two_streams.json" % rnd))
+d["two_streams"] = d2.get("two_streams")
 print("value %.4g  ms/step %.4f  kernel_ms %.4f  frac %.3f  traffic %.4g  two_streams %s" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], out["traffic_bytes_per_launch"], (d.get("two_streams") or {}).get("value")))
