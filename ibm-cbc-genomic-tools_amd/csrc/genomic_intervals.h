@@ -236,6 +236,9 @@ class UnsortedGenomicRegionSetScanner : public GenomicRegionSetScanner
                                   bool ignore_strand, char preprocess);
 };
 
+void GtxMark(const char *what);                                  // GTX_TIMING=1: wall-clock mark on stderr (not in the reference)
+void GtxFinish(int code);                                        // flush and leave without the teardown (see genomic_intervals.cpp)
+
 unsigned long int CalcBoundSize(StringLIntMap *bounds);          // sum of the chromosome lengths (genomic_intervals.cpp:6021-6026)
 
 // chromosome -> length from a genome region file (genomic_intervals.cpp:5997-6015)

@@ -89,6 +89,8 @@ int main(int argc, char *argv[])
       printf("%s\t%.4e\n", RefRegSet.R[k]->LABEL, rpkm);
     }
   }
+  GtxMark("output written");
+  GtxFinish(0);
   delete[] hits;
   delete overlaps;
   return 0;

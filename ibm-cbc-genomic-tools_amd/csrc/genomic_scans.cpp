@@ -151,6 +151,7 @@ static int RunPeaks(char *signal_reg_file, char *control_reg_file, char *uniq_re
     if (pval1_list[k] <= pval_cutoff) { printf("%.4e\t", pval1_list[k]); interval_list[k]->PrintInterval(); printf("\n"); }
     delete interval_list[k];
   }
+  GtxFinish(0);
   delete signal_scanner; delete control_scanner; delete ControlRegSet; delete bounds;
   return 0;
 }
@@ -234,6 +235,7 @@ int main(int argc, char *argv[])
       printf("\n");
     }
   }
+  GtxFinish(0);
   delete scanner;
   delete bounds;
   delete RefIndex;

@@ -384,6 +384,12 @@ int main(int argc, char *argv[])
     if (DETAILS) { printf("\t"); INPUT.PrintGOGenes(R[c]); }
     printf("\n");
   }
+  // everything is written: skip the teardown of the HIP runtime unless a profiler needs the exit handlers
+  fflush(stdout); fflush(stderr);
+  {
+    const char *pre = getenv("LD_PRELOAD");
+    if (!(getenv("GTX_FULL_EXIT") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("HSA_TOOLS_LIB") || (pre && strstr(pre, "rocprof")))) _exit(0);
+  }
   delete[] VAL; delete[] PVAL; delete[] FDR;
   return 0;
 }

@@ -12,3 +12,5 @@ pd.DataFrame({"c": names[refs[:,0]], "s": refs[:,1]-1, "e": refs[:,2], "l": ["g%
 pd.DataFrame({"c": names[reads[:,0]], "s": reads[:,1]-1, "e": reads[:,2]}).to_csv("/tmp/t_reads.bed", sep="\t", header=False, index=False)
 PY
 GTX_TIMING=1 ./ibm-cbc-genomic-tools_amd/csrc/genomic_overlaps count -S -i /tmp/t_refs.bed /tmp/t_reads.bed 2>&1 >/dev/null | grep gtx
+# whole-process wall time, output to a file (three runs)
+for i in 1 2 3; do s=$(date +%s%N); ./ibm-cbc-genomic-tools_amd/csrc/genomic_overlaps count -S -i /tmp/t_refs.bed /tmp/t_reads.bed > /tmp/t_out.txt; e=$(date +%s%N); echo "wall $(( (e - s) / 1000000 )) ms, $(wc -l < /tmp/t_out.txt) lines"; done
