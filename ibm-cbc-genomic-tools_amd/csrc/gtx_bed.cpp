@@ -272,6 +272,9 @@ struct Piece {                       // one thread's share of a block
   long first_line = 0; long n_lines = 0;
   std::vector<int32_t> tri, w, zero_len;
   std::vector<int32_t> tri_minus, w_minus;   // strand-aware runs: '-' reads are grouped behind the '+' reads of the batch
+  // strand-blind runs write straight into the batch (room for one read per line was made there): no per-piece
+  // buffer, no copy -- fresh memory is what packing costs (first-touch page faults do not run in parallel)
+  int32_t *dtri = nullptr, *dw = nullptr; size_t nd = 0;
   PackError err;
   int64_t label_sum = 0;
   // order-check context of the regions in this piece
@@ -311,8 +314,7 @@ void ParsePiece(Piece *p, const PackOptions &o)
   long line_no = p->first_line - 1;
   char *cur = p->begin;
   size_t est = (size_t)(p->end - p->begin) / 20 + 16;
-  p->tri.reserve(est * 3);
-  if (weighted) p->w.reserve(est);
+  if (!p->dtri) { p->tri.reserve(est * 3); if (weighted) p->w.reserve(est); }
   while (cur < p->end) {
     BedFields f; char *bad = nullptr;
     BedStatus st = BED_OK;
@@ -370,9 +372,16 @@ void ParsePiece(Piece *p, const PackOptions &o)
     if (p->err.set) break;
     const bool minus = o.strand_aware && f.strand == '-';
     const int32_t cls = (int32_t)(id + (minus ? n_chrom : 0));
-    std::vector<int32_t> &dst = minus ? p->tri_minus : p->tri;
-    dst.push_back(cls); dst.push_back((int32_t)f.start); dst.push_back((int32_t)f.stop);
-    if (weighted) (minus ? p->w_minus : p->w).push_back((int32_t)wv);
+    if (p->dtri) {
+      int32_t *d = p->dtri + 3 * p->nd;
+      d[0] = cls; d[1] = (int32_t)f.start; d[2] = (int32_t)f.stop;
+      if (weighted) p->dw[p->nd] = (int32_t)wv;
+      p->nd++;
+    } else {
+      std::vector<int32_t> &dst = minus ? p->tri_minus : p->tri;
+      dst.push_back(cls); dst.push_back((int32_t)f.start); dst.push_back((int32_t)f.stop);
+      if (weighted) (minus ? p->w_minus : p->w).push_back((int32_t)wv);
+    }
     if (zero_len && o.collect_zero_length) { p->zero_len.push_back(cls); p->zero_len.push_back((int32_t)f.start); p->zero_len.push_back((int32_t)wv); }
   }
   p->n_lines = line_no - (p->first_line - 1);
@@ -426,6 +435,20 @@ bool BedPacker::PackBlock(char *block, size_t got, long first_line, PackedBatch 
   }
   long ln = first_line;
   for (int t = 0; t < T; t++) { pieces[t].first_line = ln; ln += pieces[t].n_lines; }
+  const bool direct = !opt_.strand_aware;
+  const bool weighted = opt_.max_label_value > 1;
+  const size_t base_tri = out->tri.size(), base_w = out->w.size();
+  if (direct) {
+    const size_t total = (size_t)(ln - first_line);
+    out->tri.resize(base_tri + 3 * total);
+    if (weighted) out->w.resize(base_w + total);
+    size_t before = 0;
+    for (int t = 0; t < T; t++) {
+      pieces[t].dtri = out->tri.data() + base_tri + 3 * before;
+      pieces[t].dw = weighted ? out->w.data() + base_w + before : nullptr;
+      before += (size_t)pieces[t].n_lines;
+    }
+  }
   {
     std::vector<std::thread> th;
     for (int t = 1; t < T; t++) th.emplace_back([&pieces, t, this] { ParsePiece(&pieces[t], opt_); });
@@ -439,8 +462,27 @@ bool BedPacker::PackBlock(char *block, size_t got, long first_line, PackedBatch 
         SortsBefore(p.first_chrom.c_str(), p.first_strand, p.first_start, prev_chrom_.c_str(), prev_strand_, prev_start_, opt_.sorted_by_strand)) {
       if (!p.err.set || p.err.line > p.first_region_line) { p.err = PackError(); SetErr(&p.err, p.first_region_line, NotSortedMsg(opt_)); }
     }
-    if (p.err.set) { *err = p.err; return false; }
+    if (p.err.set) { *err = p.err; if (direct) { out->tri.resize(base_tri); out->w.resize(base_w); } return false; }
     if (sorted_mode && p.any) { have_prev_ = true; prev_chrom_ = p.last_chrom; prev_strand_ = p.last_strand; prev_start_ = p.last_start; }
+  }
+  if (direct) {
+    // close the gaps that dropped lines left (unknown chromosomes, reads outside the rules): usually there are none
+    size_t wpos = 0, before = 0;
+    for (int t = 0; t < T; t++) {
+      if (wpos != before && pieces[t].nd) {
+        memmove(out->tri.data() + base_tri + 3 * wpos, pieces[t].dtri, pieces[t].nd * 3 * sizeof(int32_t));
+        if (weighted) memmove(out->w.data() + base_w + wpos, pieces[t].dw, pieces[t].nd * sizeof(int32_t));
+      }
+      wpos += pieces[t].nd; before += (size_t)pieces[t].n_lines;
+    }
+    out->tri.resize(base_tri + 3 * wpos);
+    if (weighted) out->w.resize(base_w + wpos);
+    for (int t = 0; t < T; t++) {
+      out->zero_len.insert(out->zero_len.end(), pieces[t].zero_len.begin(), pieces[t].zero_len.end());
+      out->n_lines += pieces[t].n_lines;
+      out->label_sum += pieces[t].label_sum;
+    }
+    return true;
   }
   // concatenate the pieces (each thread copies its own piece to its final place): all '+' parts in
   // file order, then all '-' parts in file order -- counting does not depend on the order of the
@@ -473,8 +515,8 @@ bool BedPacker::PackBlock(char *block, size_t got, long first_line, PackedBatch 
 bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
 {
   out->tri.clear(); out->w.clear(); out->zero_len.clear(); out->n_lines = 0;
-  out->tri.reserve(target_reads * 3 + (8u << 20));       // one allocation; its pages are first touched by the copy threads
-  if (opt_.max_label_value > 1) out->w.reserve(target_reads + (3u << 20));
+  out->tri.reserve(target_reads * 3 + (24u << 20));       // one allocation; its pages are first touched by the copy threads
+  if (opt_.max_label_value > 1) out->w.reserve(target_reads + (8u << 20));
   if (primed_set_) {
     primed_set_ = false;
     if (!PackBlock(primed_.data(), primed_.size(), primed_first_line_, out, err)) return false;
@@ -482,13 +524,13 @@ bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
   if (!src_ || exhausted_) return false;
   // the next block is read (and inflated, for .gz) while the current one is parsed
   const size_t block_bytes = 64u << 20;
-  auto read_block = [this, block_bytes]() { Ahead a; long fl = 0; a.got = src_->NextBlockView(a.data, &a.view, block_bytes, &fl); return a; };
-  if (!ahead_.valid()) ahead_ = std::async(std::launch::async, read_block);
+  auto read_block = [this, block_bytes](int buf) { Ahead a; long fl = 0; a.buf = buf; a.got = src_->NextBlockView(blocks_[buf], &a.view, block_bytes, &fl); return a; };
+  if (!ahead_.valid()) { ahead_ = std::async(std::launch::async, read_block, next_buf_); next_buf_ ^= 1; }
   while (out->tri.size() / 3 < target_reads) {
     Ahead cur = ahead_.get();
     if (cur.got == 0) { ahead_ = std::future<Ahead>(); exhausted_ = true; return false; }
     const long first_line = src_->line_no() + 1;
-    ahead_ = std::async(std::launch::async, read_block);
+    ahead_ = std::async(std::launch::async, read_block, next_buf_); next_buf_ ^= 1;      // the other buffer: cur's is being parsed
     const int64_t before = out->n_lines;
     bool ok = PackBlock(cur.view, cur.got, first_line, out, err);
     src_->AdvanceLines((long)(out->n_lines - before));

@@ -136,8 +136,9 @@ class BedPacker {
  private:
   bool PackBlock(char *block, size_t got, long first_line, PackedBatch *out, PackError *err);
   std::vector<char> primed_; long primed_first_line_ = 0; bool primed_set_ = false;
-  struct Ahead { std::vector<char> data; char *view = nullptr; size_t got = 0; };   // block read ahead of the parsers
+  struct Ahead { int buf = 0; char *view = nullptr; size_t got = 0; };   // block read ahead of the parsers
   std::future<Ahead> ahead_; bool exhausted_ = false;
+  std::vector<char> blocks_[2]; int next_buf_ = 0;   // two block buffers in turn: their pages are touched once, not once per block
   LineSource *src_; PackOptions opt_;
   // order check across blocks
   bool have_prev_ = false; std::string prev_chrom_; char prev_strand_ = '+'; long prev_start_ = 0;
