@@ -213,3 +213,9 @@ def test_cli_reader_rules_match_oracle(tmp_path):
     for args in (["-kmin", "1", "-S", "n", "-p", "50", "-h"], ["-kmin", "1", "-kmax", "10", "-S", "sum", "-p", "64", "-d"]):
         a, b = run_both(args + [str(f)], seed=4)
         assert a.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 10
+
+
+def test_cli_no_category_passes_the_support_filter():
+    a, b = run_both(["-kmin", "100000", "-S", "sum", "-p", "10", "-h", os.path.join(GOLD, "perm_go.txt")], seed=1)
+    assert a.returncode == 0 and b.returncode == 0
+    assert a.stdout == b.stdout == b"CATEGORY\tCATEGORY-SIZE\tQ-VALUE\tP-VALUE\tSTATISTIC\n"
