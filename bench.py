@@ -59,6 +59,29 @@ def make_reads_on_device(n, chrom_ids, seed, device):
     return out
 
 
+# RCCL prints a version banner on the process's stdout when its first communicator comes up; the contract is ONE
+# JSON line there.  Multi-rank runs therefore point fd 1 at stderr for their whole life and write the line to the
+# saved descriptor.
+_REAL_STDOUT = None
+
+
+def guard_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, line)
+
+
 def bench_scans(args, eng, reads, n, rank, world, device, rehearse):
     """BASELINE config 4: sliding-window read counts (1 kb windows) over the reads of this rank's chromosomes;
     the per-window vectors of the ranks are disjoint by chromosome and are combined with one all-reduce(sum)."""
@@ -112,7 +135,7 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse):
     if rank == 0:
         n_micro = int((synth.CHROM_LEN // step_bp).sum())
         alg = 12.0 * n + 4.0 * n_micro
-        print(json.dumps({
+        emit(({
             "metric": "window-counted reads/sec, genomic_scans counts 1 kb windows (BASELINE config 4)",
             "value": world * n * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -189,7 +212,7 @@ def bench_perm(args, rank, world, local, device, rehearse):
     if rank == 0:
         alg = 4.0 * nnz * P                                               # gathered: one 4-byte slab element per (membership, shuffle)
         unique = 4.0 * n_rows * P + 4.0 * nnz + 8.0 * n_cols              # slab read once + membership lists + offsets
-        print(json.dumps({
+        emit(({
             "metric": "category-member sums/sec, permutation_test -S sum, 10k shuffles (BASELINE config 5)",
             "value": world * nnz * P * args.steps / elapsed, "unit": "member-sums/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -245,6 +268,14 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    # GTX_BENCH_FORCE_DIST=1: run the N>1 code (process group, pipelined RCCL all-reduce) with a single rank -- a
+    # self-test of that path on a one-GPU box, never a reported configuration
+    force_dist = world == 1 and os.environ.get("GTX_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
+        guard_stdout()
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
@@ -265,7 +296,7 @@ def main():
     # two count vectors in ping-pong: the all-reduce of step i (RCCL's own stream) overlaps the kernels of step i+1
     hits_pp = [hits, torch.zeros_like(hits)]
     pending = [None, None]
-    pipelined = world > 1 and os.environ.get("GTX_BENCH_SYNC_REDUCE") != "1"
+    pipelined = (world > 1 or force_dist) and os.environ.get("GTX_BENCH_SYNC_REDUCE") != "1"
     step_no = [0]
 
     eng = gtx.Engine(local)
@@ -300,7 +331,7 @@ def main():
                 pending[b].wait()
                 pending[b] = None
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -417,8 +448,8 @@ def main():
         }
         if two_streams:
             line["two_streams"] = two_streams
-        print(json.dumps(line))
-    if world > 1:
+        emit(line)
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
