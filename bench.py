@@ -63,6 +63,7 @@ def make_reads_on_device(n, chrom_ids, seed, device):
 # JSON line there.  Multi-rank runs therefore point fd 1 at stderr for their whole life and write the line to the
 # saved descriptor.
 _REAL_STDOUT = None
+DIST_ON = False          # a process group exists (N > 1, or the single-rank self-test GTX_BENCH_FORCE_DIST=1)
 
 
 def guard_stdout():
@@ -92,7 +93,7 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse):
 
     def step():
         eng.scan_device(reads.data_ptr(), n, synth.CHROM_LEN, step_bp, size_bp, out.data_ptr())
-        if world > 1:
+        if DIST_ON:
             if rehearse:
                 h = out.cpu(); dist.all_reduce(h, op=dist.ReduceOp.SUM); out.copy_(h)
             else:
@@ -100,7 +101,7 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if DIST_ON:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -114,7 +115,7 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse):
     fence()
     elapsed = time.perf_counter() - t0
     k_ms = float(np.mean([eng.profile_last(b)[0] for b in range(min(args.steps, 64))]))
-    if world > 1:
+    if DIST_ON:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -146,7 +147,7 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse):
                          "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "scan_hist_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes": alg},
             "cpu_baseline": cpu}))
-    if world > 1:
+    if DIST_ON:
         dist.destroy_process_group()
 
 
@@ -166,14 +167,14 @@ def bench_perm(args, rank, world, local, device, rehearse):
     def step():
         c = e.count_ge("sum", Y, 2024, rank * P, P)                      # this rank's shuffles: [rank*P, (rank+1)*P)
         ms.append(e.last_ms())
-        if world > 1:
+        if DIST_ON:
             acc.copy_(torch.from_numpy(c.view(np.int64)))
             dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         return c
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if DIST_ON:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -186,7 +187,7 @@ def bench_perm(args, rank, world, local, device, rehearse):
         counts = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if DIST_ON:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -233,7 +234,7 @@ def bench_perm(args, rank, world, local, device, rehearse):
                                  "(hit rate 0.69); traffic = L2->fabric bytes of the committed PMC pass, includes Infinity-Cache hits"},
             "cpu_baseline": cpu}))
     e.close()
-    if world > 1:
+    if DIST_ON:
         dist.destroy_process_group()
 
 
@@ -271,7 +272,9 @@ def main():
     # GTX_BENCH_FORCE_DIST=1: run the N>1 code (process group, pipelined RCCL all-reduce) with a single rank -- a
     # self-test of that path on a one-GPU box, never a reported configuration
     force_dist = world == 1 and os.environ.get("GTX_BENCH_FORCE_DIST") == "1"
-    if world > 1 or force_dist:
+    global DIST_ON
+    DIST_ON = world > 1 or force_dist
+    if DIST_ON:
         guard_stdout()
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
