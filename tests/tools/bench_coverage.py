@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """genomic_overlaps coverage on the GPU: 100M reads resident in HBM x 1M refs (BASELINE config 3 shape)."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "ibm-cbc-genomic-tools_amd")); sys.path.insert(0, R)
 import numpy as np, torch, gtx
 from gtx import synth

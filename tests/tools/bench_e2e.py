@@ -5,7 +5,7 @@
         (single thread, the restated reference algorithms incl. text parsing)
 Usage: bench_e2e.py [n_reads] [n_refs]"""
 import os, subprocess, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "ibm-cbc-genomic-tools_amd")); sys.path.insert(0, R)
 import numpy as np, pandas as pd
 import gtx

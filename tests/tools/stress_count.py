@@ -2,7 +2,7 @@
 """Randomised stress of the count / coverage / scan paths at sizes between the unit tests and the bench
 (10^5..3x10^6 reads, up to 3x10^5 regions, 1..400 classes, several orders and shapes) against the CPU oracle."""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "ibm-cbc-genomic-tools_amd")); sys.path.insert(0, R)
 import numpy as np, gtx
 from oracle import orc
