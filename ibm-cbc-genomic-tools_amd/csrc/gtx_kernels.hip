@@ -614,35 +614,65 @@ __device__ __forceinline__ bool cov_step4_ok(const WIN &X, const int (&k)[4], in
   return __ballot(bad) == 0;
 }
 
+// One step of 4 x 64 ordered keys against one window, all boundaries of the window AT ONCE: the 256 keys and the
+// exclusive prefix sums of their (relative) values go to a wave-private piece of LDS; lane L, which holds boundary
+// base-1+L, finds by a fixed-depth binary search how many keys lie at or below it (cnt) and reads the prefix sum at
+// that position (sum); slot L-1 then receives cnt[L] - cnt[L-1] keys and sum[L] - sum[L-1] of key value (DPP lane
+// differences).  The cost does not depend on how many boundaries the step crosses -- the per-boundary loop this
+// replaces cost ~60 instructions per crossing.  A step that runs past the window publishes it, slides and repeats.
 template <class WIN>
-__device__ __forceinline__ void cov_step4_run(WIN &X, const Seg &sg, const int (&k)[4], int lane, bool &valid)
+__device__ __forceinline__ void cov_step4_run(WIN &X, const Seg &sg, const int (&k)[4], int lane, bool &valid, int *ldsK, int *ldsP)
 {
   const int kbase = rdlane(k[0], 0);
-  int q[4], tot[4];                                             // exclusive in-register prefix of the relative keys; register totals
+  if (WIN::below(rdlane(k[3], 63), X.curW)) {                    // the whole step stays in the current slot
+    const int t = (k[0] - kbase) + (k[1] - kbase) + (k[2] - kbase) + (k[3] - kbase);
+    X.pend += 256;
+    X.pend2 += (i64)kbase * 256 + rdlane(wave_scan_add(t), 63);
+    return;
+  }
+  int run = 0;                                                   // sum of the relative keys of the registers below
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { const int rel = k[r] - kbase; const int p = wave_scan_add(rel); q[r] = p - rel; tot[r] = rdlane(p, 63); }
-  const int cum1 = tot[0], cum2 = cum1 + tot[1], cum3 = cum2 + tot[2], cum4 = cum3 + tot[3];
-  int cprev = 0, sprev = 0, adv = 0;
+  for (int r = 0; r < 4; ++r) {
+    const int rel = k[r] - kbase, p = wave_scan_add(rel);
+    ldsK[64 * r + lane] = k[r];
+    ldsP[64 * r + lane] = run + p - rel;                         // exclusive prefix over all keys before this one
+    run += rdlane(p, 63);
+  }
+  if (lane == 0) ldsP[256] = run;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  X.deposit(lane);                                               // what is pending belongs to the slot we are about to leave
+  int adv = 0;
   for (;;) {
-    int c = 0;
+    const int bnd = X.W;
+    int cnt = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c += __popcll(__ballot(WIN::below(k[r], X.curW)));
-    // the keys are ordered, so the c keys at or below the boundary are registers 0 .. c/64-1 entirely + the first c%64 lanes of the next
-    const int rc = c >> 6, lc = c & 63;
-    const int qsel = rc == 0 ? q[0] : rc == 1 ? q[1] : rc == 2 ? q[2] : q[3];
-    const int below = rc == 0 ? 0 : rc == 1 ? cum1 : rc == 2 ? cum2 : rc == 3 ? cum3 : cum4;
-    const int srel = below + (rc < 4 ? rdlane(qsel, lc) : 0);
-    const int dc = c - cprev;
-    X.pend += dc;
-    X.pend2 += (i64)kbase * dc + (srel - sprev);
-    cprev = c; sprev = srel;
-    if (c == 256) return;
-    if (X.fwd(sg, lane) && ++adv > 2) {
-      X.flush(sg, lane); valid = false;
+    for (int half = 128; half >= 1; half >>= 1) cnt += WIN::below(ldsK[cnt + half - 1], bnd) ? half : 0;
+    cnt += WIN::below(ldsK[cnt], bnd) ? 1 : 0;                   // 0..256 keys at or below this lane's boundary
+    const int sum = ldsP[cnt];
+    const int dc = cnt - lane_prev(cnt), ds = sum - lane_prev(sum);     // lane 0 differs from itself: 0
+    X.acc += dc;
+    X.acc2 += (i64)kbase * dc + ds;
+    const int top = rdlane(cnt, 63);
+    if (top == 256) {
+      // every key is placed; the slot of the last key is the one below the first boundary that has them all
+      const int first = __ffsll((unsigned long long)__ballot(cnt == 256)) - 1;
+      X.j = first - 1; X.prevW = rdlane(X.W, first - 1); X.curW = rdlane(X.W, first);
+      return;
+    }
+    // keys beyond the window: publish it and slide (lane 0 of the new window holds the old lane 63, so its count
+    // is `top` and the differences above keep working)
+    if (__ballot(X.acc != 0 || X.acc2 != 0)) X.flush_acc(sg, lane);
+    X.base += kSlots; X.j = 0;
+    X.W = X.Wn; X.Wn = X.load_window(sg, X.base + kSlots, lane);
+    X.prevW = rdlane(X.W, 0); X.curW = rdlane(X.W, 1);
+    if (++adv > 2) {
+      valid = false;                                             // acc is empty and nothing is pending
 #pragma unroll 1
-      for (int r = 0; r < 4; ++r) {                             // the reads not yet placed add themselves
+      for (int r = 0; r < 4; ++r) {                              // the keys not yet placed add themselves
         const int kr = r == 0 ? k[0] : r == 1 ? k[1] : r == 2 ? k[2] : k[3];
-        const u64 m = __ballot(64 * r + lane >= c);
+        const u64 m = __ballot(64 * r + lane >= top);
         if (m) X.lanes_add(sg, kr, 1, m, lane);
       }
       return;
@@ -714,6 +744,8 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
   i64 cnt = n - first; if (cnt > (i64)a.chunksPerWave * 64) cnt = (i64)a.chunksPerWave * 64;
   const int nMine = (int)cnt;
 
+  __shared__ int ldsK[4][256], ldsP[4][264];                     // per wave: the keys of a step and their prefix sums
+  const int wid = rfl(threadIdx.x >> 6);
   CovState<WEIGHTED, STRICT> st;
   constexpr int h0 = STRICT ? 4 : 0;                              // histograms 0..3 belong to the ends array, 4..7 to the starts array
   st.Ws.arr = st.We.arr = STRICT ? a.sortedS : a.sortedE;
@@ -745,8 +777,8 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
         if (st.sg.start == st.sg.end) { at += 256; continue; }    // a class without reference regions
         const int ks[4] = {t[0].s, t[1].s, t[2].s, t[3].s}, ke[4] = {t[0].e, t[1].e, t[2].e, t[3].e};
         if (cov_step4_ok(st.Ws, ks, lane, st.vs) && cov_step4_ok(st.We, ke, lane, st.ve)) {
-          cov_step4_run(st.Ws, st.sg, ks, lane, st.vs);
-          cov_step4_run(st.We, st.sg, ke, lane, st.ve);
+          cov_step4_run(st.Ws, st.sg, ks, lane, st.vs, ldsK[wid], ldsP[wid]);
+          cov_step4_run(st.We, st.sg, ke, lane, st.ve, ldsK[wid], ldsP[wid]);
           at += 256;
           continue;
         }
