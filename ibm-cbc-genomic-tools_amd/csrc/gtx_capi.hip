@@ -293,6 +293,9 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
   a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0; a.prefetch = c->prefetch;
   a.zeroLenOk = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   a.sampE = c->d_sampE; a.sampS = c->d_sampS; a.sampShift = c->sampShift; a.nSamp = c->nSamp;
+  // dense references (>= 4 boundaries per 256 reads and array): all boundaries of a window at once instead of the
+  // per-boundary loop (100 M reads x 4 M regions: 0.41 -> 0.28 ms; at 1 M regions the loop is 3 % faster).  GTX_FLIP=0|1 forces.
+  { static const char *fl = getenv("GTX_FLIP"); a.flip = fl ? atoi(fl) : (c->nValid * 256 >= 4 * std::max<int64_t>(nReads, 1)); }
   return a;
 }
 

@@ -31,6 +31,7 @@ struct CountArgs {
   const int *sampE;              // every (1 << sampShift)-th element of sortedE / sortedS: the
   const int *sampS;              //   search kernel keeps them in LDS as the top level of its searches
   int sampShift, nSamp;
+  int flip;                      // streaming kernel: meet all boundaries of a window at once (dense references)
 };
 
 // coverage: 8 histograms / tile-sum arrays in the order

@@ -440,6 +440,60 @@ __device__ __forceinline__ void walk_fast(WIN &X, const Seg &sg, const int (&k)[
   }
 }
 
+__device__ __forceinline__ int max_of4(const int (&k)[4]) { int m = k[0]; m = k[1] > m ? k[1] : m; m = k[2] > m ? k[2] : m; return k[3] > m ? k[3] : m; }
+
+// All boundaries of the window at once (see cov_step4_run; chosen by the host when the references are dense): for ordered keys, lane L counts the keys at or below its
+// boundary by binary search in a wave-private LDS copy of the step's 256 keys; slots receive the lane differences.
+// Returns false (nothing touched) when the keys are not in order.
+template <class WIN>
+__device__ __forceinline__ bool walk_flip4(WIN &X, const Seg &sg, const int (&k)[4], int lane, bool &valid, int *ldsK)
+{
+  if (__ballot(WIN::below(max_of4(k), X.curW)) == ~0ull) { X.pend += 256u; return true; }   // no boundary crossed
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int prev = lane_prev(k[r]);
+    if (r > 0) { const int last = rdlane(k[r - 1], 63); prev = lane == 0 ? last : prev; }
+    bad |= k[r] < prev;
+  }
+  if (__ballot(bad)) return false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ldsK[64 * r + lane] = k[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (X.pend != 0) { X.acc += (lane == X.j + 1) ? X.pend : 0u; X.pend = 0; }
+  int adv = 0;
+  for (;;) {
+    const int bnd = X.W;
+    int cnt = 0;
+#pragma unroll
+    for (int half = 128; half >= 1; half >>= 1) cnt += WIN::below(ldsK[cnt + half - 1], bnd) ? half : 0;
+    cnt += WIN::below(ldsK[cnt], bnd) ? 1 : 0;
+    X.acc += (unsigned)(cnt - lane_prev(cnt));
+    const int top = rdlane(cnt, 63);
+    if (top == 256) {
+      const int first = __ffsll((unsigned long long)__ballot(cnt == 256)) - 1;
+      X.j = first - 1; X.prevW = rdlane(X.W, first - 1); X.curW = rdlane(X.W, first);
+      return true;
+    }
+    if (__ballot(X.acc != 0)) X.flush_acc(sg, lane);
+    X.base += kSlots; X.j = 0;
+    X.W = X.Wn; X.Wn = X.load_window(sg, X.base + kSlots, lane);
+    X.prevW = rdlane(X.W, 0); X.curW = rdlane(X.W, 1);
+    if (++adv > 2) {
+      valid = false;
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) {
+        const int kr = r == 0 ? k[0] : r == 1 ? k[1] : r == 2 ? k[2] : k[3];
+        const u64 m = __ballot(64 * r + lane >= top);
+        if (m) X.lanes_add(sg, kr, 1, m, lane);
+      }
+      return true;
+    }
+  }
+}
+
 template <int R>
 __device__ __forceinline__ int min_of(const int (&k)[R]) { int m = k[0];
 #pragma unroll
@@ -462,6 +516,8 @@ template <bool WEIGHTED, int R>
 __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n,
                                                          CountArgs a)
 {
+  __shared__ int ldsK[8][256];                                 // per wave: the keys of a step (walk_flip4)
+  const int wid = rfl(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + rfl(threadIdx.x >> 6);
   const i64 first = wave * (i64)a.chunksPerWave * 64;          // first read of this wave's span
@@ -509,7 +565,15 @@ __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__
         // dg < 0 in some lane <=> some read has start > end (+zl)
         const int kmin = min_of<R>(ks), emin = min_of<R>(ke);
         if (__ballot((odd != 0) | (dg < 0) | (kmin <= st.A.prevW) | (emin < st.B.prevW))) break;
-        if constexpr (!WEIGHTED) {
+        if constexpr (!WEIGHTED && R == 4) {
+          if (a.flip) {
+            if (!walk_flip4(st.A, st.sg, ks, lane, st.validA, ldsK[wid])) walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
+            if (!walk_flip4(st.B, st.sg, ke, lane, st.validB, ldsK[wid])) walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
+          } else {
+            walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
+            walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
+          }
+        } else if constexpr (!WEIGHTED) {
           walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
           walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
         }
