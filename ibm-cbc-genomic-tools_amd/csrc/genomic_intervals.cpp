@@ -145,7 +145,7 @@ GenomicRegionSet::GenomicRegionSet(char *file, unsigned long int buffer_size, bo
   this->from_stdin = file == NULL;
   this->load_in_memory = from_stdin ? false : load_in_memory;
   this->hide_header = hide_header;
-  this->src = NULL; this->R = NULL; this->n_regions = 0; this->r_index = 0;
+  this->src = NULL; this->packed = NULL; this->R = NULL; this->n_regions = 0; this->r_index = 0;
   Init();
 }
 
@@ -153,6 +153,7 @@ GenomicRegionSet::~GenomicRegionSet()
 {
   delete[] file;
   delete src;
+  delete packed;
   if (R) {
     long int n = load_in_memory ? n_regions : 1;
     for (long int k = 0; k < n; k++) delete R[k];
@@ -193,6 +194,23 @@ void GenomicRegionSet::Init()
   if (getenv("GTX_NO_WARMUP") == NULL) GtxWarmUp();
   Mark(load_in_memory ? "GenomicRegionSet (in memory): open" : "GenomicRegionSet (stream): open");
   std::string err;
+  if (gtxhost::GtxView::IsGtx(file)) {
+    // a packed region file: no text to tokenise; regions are made from its records on demand
+    packed = gtxhost::GtxView::Open(file, &err);
+    if (!packed) { fprintf(stderr, "%s\n", err.c_str()); exit(1); }
+    format = packed->n ? "GTX" : "EMPTY";
+    r_index = 0;
+    if (load_in_memory) {
+      n_regions = (long int)packed->n;
+      R = n_regions > 0 ? new GenomicRegion *[n_regions] : NULL;
+      for (long int k = 0; k < n_regions; k++) R[k] = PackedRegion(k);
+    } else if (packed->n) {
+      n_regions = 1;
+      R = new GenomicRegion *[1];
+      R[0] = PackedRegion(0);
+    }
+    return;
+  }
   src = LineSource::Open(file, &err);
   if (!src) { fprintf(stderr, "%s\n", err.c_str()); exit(1); }
   char *line = src->Next();
@@ -233,6 +251,7 @@ void GenomicRegionSet::Reset()
   if (load_in_memory) { r_index = 0; return; }
   if (R) { delete R[0]; delete[] R; R = NULL; }
   delete src; src = NULL;
+  delete packed; packed = NULL;
   Init();
 }
 
@@ -242,9 +261,26 @@ GenomicRegion *GenomicRegionSet::Get()
   return !load_in_memory ? R[0] : (r_index >= n_regions ? NULL : R[r_index]);
 }
 
+GenomicRegion *GenomicRegionSet::PackedRegion(long int k)
+{
+  const gtxhost::GtxView &g = *packed;
+  char line[512];
+  const char strand = (g.minus[k >> 3] >> (k & 7)) & 1 ? '-' : '+';
+  if (g.label) snprintf(line, sizeof line, "%s\t%ld\t%ld\t%ld\t0\t%c", g.chrom[g.chrom_idx[k]].c_str(), (long)g.start[k] - 1, (long)g.stop[k], (long)g.label[k], strand);
+  else snprintf(line, sizeof line, "%s\t%ld\t%ld\t_\t0\t%c", g.chrom[g.chrom_idx[k]].c_str(), (long)g.start[k] - 1, (long)g.stop[k], strand);
+  return new GenomicRegionBED(line, k + 1);
+}
+
 GenomicRegion *GenomicRegionSet::Next(bool retain_current)
 {
   if (load_in_memory) { ++r_index; return r_index >= n_regions ? NULL : R[r_index]; }
+  if (packed) {
+    if (n_regions == 0) return NULL;
+    if (r_index + 1 >= (long int)packed->n) return NULL;
+    if (R[0] && !retain_current) delete R[0];
+    R[0] = PackedRegion(++r_index);
+    return R[0];
+  }
   if (n_regions == 0 || !src) return NULL;
   char *line = src->Next();
   if (!line) return NULL;
@@ -266,6 +302,15 @@ GenomicRegion *GenomicRegionSet::Next(bool sorted_by_strand, bool retain_current
     if (r == NULL) { R[0] = NULL; n_regions = 0; }            // end of the stream: Get() answers NULL from now on
   }
   return r;
+}
+
+const gtxhost::GtxView *GenomicRegionSet::DetachPacked(long int *current_record)
+{
+  if (load_in_memory || !packed) PrintError("[DetachPacked] not a streamed packed region file!");
+  *current_record = n_regions > 0 ? r_index : (long int)packed->n;
+  if (n_regions > 0) { delete R[0]; R[0] = NULL; }
+  n_regions = 0;
+  return packed;
 }
 
 LineSource *GenomicRegionSet::DetachStream(std::string *current_line, long int *current_line_no)
@@ -322,6 +367,19 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
 {
   const size_t batch_reads = 24u << 20;
   PackedBatch batch; PackError err;
+  if (!set->load_in_memory && set->format == "GTX") {
+    long int at = 0;
+    const gtxhost::GtxView *view = set->DetachPacked(&at);
+    BedPacker packer(view, opt);
+    packer.SkipRecords((uint64_t)at);
+    for (;;) {
+      bool more = packer.NextBatch(&batch, batch_reads, &err);
+      if (err.set) DiePack(err);
+      if (!batch.tri.empty()) sink(batch);
+      if (!more) break;
+    }
+    return;
+  }
   if (!set->load_in_memory) {
     std::string first; long int first_no = 0;
     LineSource *src = set->DetachStream(&first, &first_no);
@@ -344,7 +402,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
     snprintf(buf, sizeof buf, "%ld\t%ld\t", i->START - 1, i->STOP); text += buf;
     text += r->LABEL; text += "\t0\t"; text += i->STRAND; text += '\n';
   }
-  BedPacker packer(NULL, opt);
+  BedPacker packer((LineSource *)NULL, opt);
   packer.PrimeBlock(text, 1);
   for (;;) {
     bool more = packer.NextBatch(&batch, batch_reads, &err);

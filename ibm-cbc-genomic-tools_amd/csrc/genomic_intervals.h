@@ -23,7 +23,7 @@
 #include <string>
 #include <vector>
 
-namespace gtxhost { class LineSource; }
+namespace gtxhost { class LineSource; struct GtxView; }
 
 typedef std::map<std::string, long int> StringLIntMap;          // genomic_intervals.h:41
 
@@ -89,18 +89,22 @@ class GenomicRegionSet
   // MI355X path: hands the not yet consumed part of a streaming set (the current region's raw
   // line first) to the bulk packer.  After this call Get()/Next() report the end of the set.
   gtxhost::LineSource *DetachStream(std::string *current_line, long int *current_line_no);
+  // the same for a packed region file (format "GTX"): the view and the index of the current record
+  const gtxhost::GtxView *DetachPacked(long int *current_record);
 
   char *file;
   unsigned long int buffer_size;
   bool verbose, load_in_memory, from_stdin, hide_header;
   long int n_regions;
-  std::string format;                                              // "BED" or "EMPTY"
+  std::string format;                                              // "BED", "EMPTY" or "GTX" (a packed region file, gtx_bed.h)
   GenomicRegion **R;
 
  private:
   void Init();
   void DetectFormat(const char *first_line);
   gtxhost::LineSource *src;
+  gtxhost::GtxView *packed;                                        // format "GTX"
+  GenomicRegion *PackedRegion(long int record);                    // region object of one record of the packed file
   std::string cur_raw;                                             // unparsed copy of the current line (streaming mode)
   long int r_index;
 };

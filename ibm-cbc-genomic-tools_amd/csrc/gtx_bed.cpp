@@ -4,6 +4,7 @@
 #include <fcntl.h>
 #include <limits.h>
 #include <stdlib.h>
+#include <sys/mman.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -234,6 +235,109 @@ static inline char *ParseTabbedLine(char *line, char *end, BedFields *o)
   return p + 1;
 }
 
+static inline void SetErrPublic(PackError *e, long line, const std::string &msg, bool no_prefix)
+{
+  if (!e->set) { e->set = true; e->line = line; e->msg = msg; e->no_prefix = no_prefix; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// packed region files
+// ---------------------------------------------------------------------------------------------------
+static const char kGtxMagic[8] = {'G', 'T', 'X', 'P', 1, 0, 0, 0};
+static inline size_t Pad8(size_t x) { return (x + 7) & ~(size_t)7; }
+
+bool GtxView::IsGtx(const char *path)
+{
+  if (!path) return false;
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  char m[8]; const bool ok = fread(m, 1, 8, f) == 8 && memcmp(m, kGtxMagic, 8) == 0;
+  fclose(f);
+  return ok;
+}
+
+GtxView *GtxView::Open(const char *path, std::string *err)
+{
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) { *err = std::string("Error: cannot open file '") + path + "'!"; return nullptr; }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || st.st_size < 24) { close(fd); *err = std::string("Error: '") + path + "' is not a packed region file!"; return nullptr; }
+  void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) { *err = std::string("Error: cannot map file '") + path + "'!"; return nullptr; }
+  const char *b = (const char *)m, *e = b + st.st_size;
+  GtxView *g = new GtxView; g->map_ = m; g->map_len_ = (size_t)st.st_size;
+  auto bad = [&]() { *err = std::string("Error: '") + path + "' is not a valid packed region file!"; delete g; return (GtxView *)nullptr; };
+  if (memcmp(b, kGtxMagic, 8) != 0) return bad();
+  uint32_t n_chrom; memcpy(&n_chrom, b + 8, 4); memcpy(&g->flags, b + 12, 4); memcpy(&g->n, b + 16, 8);
+  const char *p = b + 24;
+  for (uint32_t c = 0; c < n_chrom; c++) {
+    if (p + 2 > e) return bad();
+    uint16_t len; memcpy(&len, p, 2); p += 2;
+    if (p + len > e) return bad();
+    g->chrom.emplace_back(p, len); p += len;
+  }
+  size_t off = Pad8((size_t)(p - b));
+  auto take = [&](size_t bytes) -> const char * { const char *q = b + off; off = Pad8(off + bytes); return off <= (size_t)(e - b) + 7 && q + bytes <= e ? q : nullptr; };
+  g->chrom_idx = (const uint16_t *)take(2 * g->n);
+  g->start = (const int32_t *)take(4 * g->n);
+  g->stop = (const int32_t *)take(4 * g->n);
+  g->minus = (const uint8_t *)take((g->n + 7) / 8);
+  g->label = (g->flags & 1) ? (const int32_t *)take(4 * g->n) : nullptr;
+  if (!g->chrom_idx || !g->start || !g->stop || !g->minus || ((g->flags & 1) && !g->label)) return bad();
+  for (uint64_t i = 0; i < g->n; i++) if (g->chrom_idx[i] >= n_chrom) return bad();
+  return g;
+}
+
+GtxView::~GtxView() { if (map_) munmap(map_, map_len_); }
+
+bool WriteGtx(LineSource *src, const char *out_path, PackError *err)
+{
+  std::vector<std::string> names; std::vector<uint16_t> cidx; std::vector<int32_t> st, en, lab; std::vector<uint8_t> minus;
+  std::string last; int last_id = -1;
+  bool any_label = false, top = true;
+  uint64_t n = 0;
+  for (char *line = src->Next(); line; line = src->Next()) {
+    if (top && (strncmp(line, "browser ", 8) == 0 || strncmp(line, "track ", 6) == 0)) continue;   // genomic_intervals.cpp:3713-3720
+    top = false;
+    BedFields f; char *bad = nullptr;
+    const BedStatus s = ParseBedLine(line, &f, &bad);
+    if (s == BED_TOO_FEW_TOKENS) { SetErrPublic(err, src->line_no(), "number of tokens should be at least 3 for BED format!", false); return false; }
+    if (s == BED_BAD_STRAND) { SetErrPublic(err, src->line_no(), std::string("Error: invalid strand '") + bad + "'!", true); return false; }
+    if (f.n_tokens == 12) { SetErrPublic(err, src->line_no(), "multi-interval (BED12) regions are outside the MI355X counting path!", false); return false; }
+    const long v = f.label ? FastAtol(f.label) : 0;
+    if (f.start >= INT_MAX - 1 || f.stop >= INT_MAX - 1 || f.start <= INT_MIN + 1 || f.stop <= INT_MIN + 1 || v > INT_MAX || v < INT_MIN) {
+      SetErrPublic(err, src->line_no(), "coordinate or label value does not fit the packed 32-bit representation of the MI355X path!", false); return false;
+    }
+    if (last_id < 0 || last != f.chrom) {
+      last = f.chrom; last_id = -1;
+      for (size_t c = 0; c < names.size(); c++) if (names[c] == last) { last_id = (int)c; break; }
+      if (last_id < 0) {
+        if (names.size() >= 65535 || last.size() > 65535) { SetErrPublic(err, src->line_no(), "too many chromosomes for a packed region file!", false); return false; }
+        names.push_back(last); last_id = (int)names.size() - 1;
+      }
+    }
+    cidx.push_back((uint16_t)last_id); st.push_back((int32_t)f.start); en.push_back((int32_t)f.stop); lab.push_back((int32_t)v);
+    if ((n & 7) == 0) minus.push_back(0);
+    if (f.strand == '-') minus.back() |= (uint8_t)(1u << (n & 7));
+    any_label |= f.label != nullptr;
+    n++;
+  }
+  FILE *o = fopen(out_path, "wb");
+  if (!o) { SetErrPublic(err, 0, std::string("Error: cannot create file '") + out_path + "'!", true); return false; }
+  const uint32_t n_chrom = (uint32_t)names.size(), flags = any_label ? 1u : 0u;
+  size_t off = 0;
+  auto put = [&](const void *p, size_t bytes) { if (bytes) fwrite(p, 1, bytes, o); off += bytes; };
+  auto pad = [&]() { static const char z[8] = {0}; const size_t k = Pad8(off) - off; if (k) put(z, k); };
+  put(kGtxMagic, 8); put(&n_chrom, 4); put(&flags, 4); put(&n, 8);
+  for (const std::string &nm : names) { const uint16_t len = (uint16_t)nm.size(); put(&len, 2); put(nm.data(), len); }
+  pad(); put(cidx.data(), 2 * n); pad(); put(st.data(), 4 * n); pad(); put(en.data(), 4 * n); pad(); put(minus.data(), minus.size()); pad();
+  if (any_label) { put(lab.data(), 4 * n); pad(); }
+  const bool ok = fclose(o) == 0;
+  if (!ok) SetErrPublic(err, 0, std::string("Error: cannot write file '") + out_path + "'!", true);
+  return ok;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // ChromTable
 // ---------------------------------------------------------------------------------------------------
@@ -269,6 +373,7 @@ namespace {
 
 struct Piece {                       // one thread's share of a block
   char *begin = nullptr, *end = nullptr;
+  const GtxView *gtx = nullptr; uint64_t rec0 = 0, rec1 = 0;   // ... or of a packed file: records [rec0, rec1)
   long first_line = 0; long n_lines = 0;
   std::vector<int32_t> tri, w, zero_len;
   std::vector<int32_t> tri_minus, w_minus;   // strand-aware runs: '-' reads are grouped behind the '+' reads of the batch
@@ -304,14 +409,84 @@ const char *NotSortedMsg(const PackOptions &o)
   return o.sorted_by_strand ? "input regions are not sorted (sorted-by-strand = true)!" : "input regions are not sorted (sorted-by-strand = false)!";
 }
 
-void ParsePiece(Piece *p, const PackOptions &o)
+// What happens to one parsed region (the same for a text line and for a record of a packed file): order check,
+// chromosome lookup, the mode's validity rules, output.  Returns false when an error was recorded.
+struct ChromCache { std::string name; int id = -2; };
+static inline bool HandleRecord(Piece *p, const PackOptions &o, const BedFields &f, long label_value, long line_no, ChromCache &cc)
 {
   const bool sorted_mode = o.mode == PACK_OVERLAPS_SORTED || o.mode == PACK_SCAN_SORTED;
   const bool weighted = o.max_label_value > 1;
   const int n_chrom = o.chroms->size();
-  // last chromosome looked up (sorted input repeats it millions of times)
-  std::string cache_name; int cache_id = -2;
+    if (sorted_mode) {
+      if (p->any && SortsBefore(f.chrom, f.strand, f.start, p->last_chrom.c_str(), p->last_strand, p->last_start, o.sorted_by_strand)) {
+        SetErr(&p->err, line_no, NotSortedMsg(o)); return false;
+      }
+      if (!p->any) { p->first_chrom = f.chrom; p->first_strand = f.strand; p->first_start = f.start; p->first_region_line = line_no; }
+      if (p->last_chrom != f.chrom) p->last_chrom = f.chrom;
+      p->last_strand = f.strand; p->last_start = f.start; p->any = true;
+    }
+    if (cc.id == -2 || cc.name != f.chrom) { cc.name = f.chrom; cc.id = o.chroms->Find(f.chrom); }
+    const int id = cc.id;
+    bool zero_len = false;
+    long wv = 1;                                                         // GetLabelValue (genomic_intervals.cpp:1081-1085)
+    if (weighted) { const long v = label_value; wv = v < o.max_label_value ? v : o.max_label_value; }
+    p->label_sum += wv;
+    switch (o.mode) {
+      case PACK_OVERLAPS_UNSORTED:
+        if (id < 0) return true;                                            // unknown chromosome: never validated
+        if (f.stop <= 0) { SetErr(&p->err, line_no, "stop position must be positive!"); break; }
+        if (f.start > f.stop) { SetErr(&p->err, line_no, "start position cannot be greater than stop position!"); break; }
+        break;
+      case PACK_OVERLAPS_SORTED:
+        if (id < 0) return true;
+        if (f.start > f.stop + 1) { SetErr(&p->err, line_no, "inverted interval (end < start) is outside the MI355X counting path!"); break; }
+        zero_len = f.start == f.stop + 1;
+        break;
+      case PACK_SCAN_UNSORTED:
+        if (f.start > f.stop || f.stop <= 0) return true;
+        if (id < 0) return true;
+        break;
+      case PACK_SCAN_SORTED:
+        if (id < 0) return true;
+        break;
+    }
+    if (p->err.set) return false;
+    const bool minus = o.strand_aware && f.strand == '-';
+    const int32_t cls = (int32_t)(id + (minus ? n_chrom : 0));
+    if (p->dtri) {
+      int32_t *d = p->dtri + 3 * p->nd;
+      d[0] = cls; d[1] = (int32_t)f.start; d[2] = (int32_t)f.stop;
+      if (weighted) p->dw[p->nd] = (int32_t)wv;
+      p->nd++;
+    } else {
+      std::vector<int32_t> &dst = minus ? p->tri_minus : p->tri;
+      dst.push_back(cls); dst.push_back((int32_t)f.start); dst.push_back((int32_t)f.stop);
+      if (weighted) (minus ? p->w_minus : p->w).push_back((int32_t)wv);
+    }
+    if (zero_len && o.collect_zero_length) { p->zero_len.push_back(cls); p->zero_len.push_back((int32_t)f.start); p->zero_len.push_back((int32_t)wv); }
+  return true;
+}
+
+void ParsePiece(Piece *p, const PackOptions &o)
+{
+  const bool weighted = o.max_label_value > 1;
+  ChromCache cc;                                             // last chromosome looked up (sorted input repeats it millions of times)
   long line_no = p->first_line - 1;
+  if (p->gtx) {                                              // records of a packed file: already tokenised, numbers already read
+    const GtxView &g = *p->gtx;
+    if (!p->dtri) { p->tri.reserve((size_t)(p->rec1 - p->rec0) * 3); if (weighted) p->w.reserve((size_t)(p->rec1 - p->rec0)); }
+    for (uint64_t r = p->rec0; r < p->rec1; r++) {
+      line_no++;
+      BedFields f;
+      f.chrom = (char *)g.chrom[g.chrom_idx[r]].c_str(); f.label = nullptr;
+      f.start = g.start[r]; f.stop = g.stop[r];
+      f.strand = (g.minus[r >> 3] >> (r & 7)) & 1 ? '-' : '+';
+      f.n_tokens = 6;
+      if (!HandleRecord(p, o, f, g.label ? g.label[r] : 0, line_no, cc)) break;
+    }
+    p->n_lines = line_no - (p->first_line - 1);
+    return;
+  }
   char *cur = p->begin;
   size_t est = (size_t)(p->end - p->begin) / 20 + 16;
   if (!p->dtri) { p->tri.reserve(est * 3); if (weighted) p->w.reserve(est); }
@@ -336,53 +511,7 @@ void ParsePiece(Piece *p, const PackOptions &o)
     if (f.start >= INT_MAX - 1 || f.stop >= INT_MAX - 1 || f.start <= INT_MIN + 1 || f.stop <= INT_MIN + 1) {
       SetErr(&p->err, line_no, "coordinate does not fit the packed 32-bit representation of the MI355X path!"); break;
     }
-    if (sorted_mode) {
-      if (p->any && SortsBefore(f.chrom, f.strand, f.start, p->last_chrom.c_str(), p->last_strand, p->last_start, o.sorted_by_strand)) {
-        SetErr(&p->err, line_no, NotSortedMsg(o)); break;
-      }
-      if (!p->any) { p->first_chrom = f.chrom; p->first_strand = f.strand; p->first_start = f.start; p->first_region_line = line_no; }
-      if (p->last_chrom != f.chrom) p->last_chrom = f.chrom;
-      p->last_strand = f.strand; p->last_start = f.start; p->any = true;
-    }
-    if (cache_id == -2 || cache_name != f.chrom) { cache_name = f.chrom; cache_id = o.chroms->Find(f.chrom); }
-    const int id = cache_id;
-    bool zero_len = false;
-    long wv = 1;                                                         // GetLabelValue (genomic_intervals.cpp:1081-1085)
-    if (weighted) { long v = f.label ? FastAtol(f.label) : 0; wv = v < o.max_label_value ? v : o.max_label_value; }
-    p->label_sum += wv;
-    switch (o.mode) {
-      case PACK_OVERLAPS_UNSORTED:
-        if (id < 0) continue;                                            // unknown chromosome: never validated
-        if (f.stop <= 0) { SetErr(&p->err, line_no, "stop position must be positive!"); break; }
-        if (f.start > f.stop) { SetErr(&p->err, line_no, "start position cannot be greater than stop position!"); break; }
-        break;
-      case PACK_OVERLAPS_SORTED:
-        if (id < 0) continue;
-        if (f.start > f.stop + 1) { SetErr(&p->err, line_no, "inverted interval (end < start) is outside the MI355X counting path!"); break; }
-        zero_len = f.start == f.stop + 1;
-        break;
-      case PACK_SCAN_UNSORTED:
-        if (f.start > f.stop || f.stop <= 0) continue;
-        if (id < 0) continue;
-        break;
-      case PACK_SCAN_SORTED:
-        if (id < 0) continue;
-        break;
-    }
-    if (p->err.set) break;
-    const bool minus = o.strand_aware && f.strand == '-';
-    const int32_t cls = (int32_t)(id + (minus ? n_chrom : 0));
-    if (p->dtri) {
-      int32_t *d = p->dtri + 3 * p->nd;
-      d[0] = cls; d[1] = (int32_t)f.start; d[2] = (int32_t)f.stop;
-      if (weighted) p->dw[p->nd] = (int32_t)wv;
-      p->nd++;
-    } else {
-      std::vector<int32_t> &dst = minus ? p->tri_minus : p->tri;
-      dst.push_back(cls); dst.push_back((int32_t)f.start); dst.push_back((int32_t)f.stop);
-      if (weighted) (minus ? p->w_minus : p->w).push_back((int32_t)wv);
-    }
-    if (zero_len && o.collect_zero_length) { p->zero_len.push_back(cls); p->zero_len.push_back((int32_t)f.start); p->zero_len.push_back((int32_t)wv); }
+    if (!HandleRecord(p, o, f, f.label ? FastAtol(f.label) : 0, line_no, cc)) break;
   }
   p->n_lines = line_no - (p->first_line - 1);
 }
@@ -401,6 +530,12 @@ BedPacker::BedPacker(LineSource *src, const PackOptions &opt) : src_(src), opt_(
   if (opt_.threads <= 0) { unsigned hc = std::thread::hardware_concurrency(); opt_.threads = hc ? (int)std::min(hc, 64u) : 4; }
 }
 
+BedPacker::BedPacker(const GtxView *packed, const PackOptions &opt) : src_(nullptr), opt_(opt)
+{
+  if (opt_.threads <= 0) { unsigned hc = std::thread::hardware_concurrency(); opt_.threads = hc ? (int)std::min(hc, 64u) : 4; }
+  gtx_ = packed;
+}
+
 void BedPacker::Prime(const std::string &line, long line_no)
 {
   primed_.assign(line.begin(), line.end()); primed_.push_back('\n');
@@ -416,7 +551,6 @@ void BedPacker::PrimeBlock(const std::string &lines, long first_line)
 // parse one block of complete lines with the thread pool and append the result to *out
 bool BedPacker::PackBlock(char *block, size_t got, long first_line, PackedBatch *out, PackError *err)
 {
-  const bool sorted_mode = opt_.mode == PACK_OVERLAPS_SORTED || opt_.mode == PACK_SCAN_SORTED;
   // cut the block into pieces at line ends
   int T = (int)std::min<size_t>((size_t)opt_.threads, got / (256u << 10) + 1);
   std::vector<Piece> pieces(T);
@@ -433,6 +567,15 @@ bool BedPacker::PackBlock(char *block, size_t got, long first_line, PackedBatch 
     pieces[0].n_lines = CountLines(pieces[0].begin, pieces[0].end);
     for (auto &x : th) x.join();
   }
+  return PackPieces(&pieces, first_line, out, err);
+}
+
+// pieces with their line counts known -> parsed in parallel, checked at the seams, appended to *out
+bool BedPacker::PackPieces(void *pieces_ptr, long first_line, PackedBatch *out, PackError *err)
+{
+  std::vector<Piece> &pieces = *(std::vector<Piece> *)pieces_ptr;
+  const int T = (int)pieces.size();
+  const bool sorted_mode = opt_.mode == PACK_OVERLAPS_SORTED || opt_.mode == PACK_SCAN_SORTED;
   long ln = first_line;
   for (int t = 0; t < T; t++) { pieces[t].first_line = ln; ln += pieces[t].n_lines; }
   const bool direct = !opt_.strand_aware;
@@ -520,6 +663,22 @@ bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
   if (primed_set_) {
     primed_set_ = false;
     if (!PackBlock(primed_.data(), primed_.size(), primed_first_line_, out, err)) return false;
+  }
+  if (gtx_) {
+    // records of a packed file: cut the next target_reads of them into one range per thread
+    const uint64_t left = gtx_->n - gtx_pos_;
+    if (left == 0) return false;
+    const uint64_t take = std::min<uint64_t>(left, target_reads);
+    const int T = (int)std::min<uint64_t>((uint64_t)opt_.threads, take / 65536 + 1);
+    std::vector<Piece> pieces(T);
+    for (int t = 0; t < T; t++) {
+      pieces[t].gtx = gtx_;
+      pieces[t].rec0 = gtx_pos_ + take * (uint64_t)t / T; pieces[t].rec1 = gtx_pos_ + take * (uint64_t)(t + 1) / T;
+      pieces[t].n_lines = (long)(pieces[t].rec1 - pieces[t].rec0);
+    }
+    const bool ok = PackPieces(&pieces, (long)gtx_pos_ + 1, out, err);
+    gtx_pos_ += take;
+    return ok && gtx_pos_ < gtx_->n;
   }
   if (!src_ || exhausted_) return false;
   // the next block is read (and inflated, for .gz) while the current one is parsed

@@ -80,6 +80,24 @@ class ChromTable {
   bool frozen_ = false;
 };
 
+// ---- packed region files (.gtx): a BED file after tokenising, column by column ------------------------
+// Layout (little endian): "GTXP" u32 version=1 | u32 n_chrom | u32 flags (1 = label values present) | u64 n |
+// n_chrom x (u16 length, bytes) | padding to 8 | u16 chrom_idx[n] | pad | i32 start[n] (1-based) | pad | i32 stop[n] |
+// pad | u8 minus[(n+7)/8] (strand bits) | pad | i32 label_value[n] (atol of column 4; present if flags & 1).
+// Record i stands for line i+1 of the text it was made from (header lines not counted).  Labels themselves are not
+// kept: a packed file can be the streamed TEST set of genomic_overlaps / the input of genomic_scans, not a
+// reference set whose labels are printed.  Not a format of the reference: a cache that skips the text parse on re-runs.
+struct GtxView {
+  uint64_t n = 0; uint32_t flags = 0;
+  std::vector<std::string> chrom;
+  const uint16_t *chrom_idx = nullptr; const int32_t *start = nullptr, *stop = nullptr, *label = nullptr; const uint8_t *minus = nullptr;
+  static bool IsGtx(const char *path);                              // regular file starting with the magic
+  static GtxView *Open(const char *path, std::string *err);         // mmap; NULL + message on failure
+  ~GtxView();
+ private:
+  void *map_ = nullptr; size_t map_len_ = 0;
+};
+
 // ---- bulk packing ---------------------------------------------------------------------------------
 enum PackMode {
   PACK_OVERLAPS_UNSORTED,   // UnsortedGenomicRegionSetOverlaps query rules (genomic_intervals.cpp:5717-5764)
@@ -122,12 +140,17 @@ struct PackedBatch {
   int64_t label_sum = 0;             // sum of GetLabelValue(max_label_value) over ALL regions seen (CountGenomicRegions, genomic_intervals.cpp:6206-6214)
 };
 
+// text -> packed file; lines are validated like GenomicRegionBED (token count, strand); returns false with *err set
+bool WriteGtx(LineSource *src, const char *out_path, PackError *err);
+
 // Packs blocks of lines from `src` until about `target_reads` reads are in `out` or the input ends.
 // Returns false when the input is exhausted (out may still hold reads).  The first error in file
 // order, if any, is left in *err and packing stops there.
 class BedPacker {
  public:
   BedPacker(LineSource *src /* may be NULL: primed text only */, const PackOptions &opt);
+  BedPacker(const GtxView *packed, const PackOptions &opt);           // the records of a packed file instead of text
+  void SkipRecords(uint64_t n) { gtx_pos_ = n; }                     // packed file: start at record n
   // text to be packed before anything is read from the source: one line without its '\n' (a
   // region the caller had already pulled from the stream), or a block of '\n'-terminated lines
   void Prime(const std::string &line, long line_no);
@@ -135,6 +158,8 @@ class BedPacker {
   bool NextBatch(PackedBatch *out, size_t target_reads, PackError *err);
  private:
   bool PackBlock(char *block, size_t got, long first_line, PackedBatch *out, PackError *err);
+  bool PackPieces(void *pieces, long first_line, PackedBatch *out, PackError *err);
+  const GtxView *gtx_ = nullptr; uint64_t gtx_pos_ = 0;
   std::vector<char> primed_; long primed_first_line_ = 0; bool primed_set_ = false;
   struct Ahead { int buf = 0; char *view = nullptr; size_t got = 0; };   // block read ahead of the parsers
   std::future<Ahead> ahead_; bool exhausted_ = false;

@@ -23,6 +23,20 @@ int main(int argc, char **argv)
   if (argc < 2) { fprintf(stderr, "usage: gtx_packtool ou|os|su|ss [-t N] [-s] [-a] [-l MAX] -c chr1,chr2,... [FILE]\n"); return 2; }
   PackOptions opt;
   std::string m = argv[1];
+  if (m == "pack") {
+    // gtx_packtool pack IN.bed[.gz] OUT.gtx : tokenise once, keep the columns (gtx_bed.h, "packed region files")
+    if (argc != 4) { fprintf(stderr, "usage: gtx_packtool pack IN.bed OUT.gtx\n"); return 2; }
+    std::string err;
+    LineSource *src = LineSource::Open(argv[2], &err);
+    if (!src) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    PackError e;
+    if (!WriteGtx(src, argv[3], &e)) {
+      if (e.no_prefix) fprintf(stderr, "%s\n", e.msg.c_str()); else fprintf(stderr, "\nError: Line %ld: %s\n", e.line, e.msg.c_str());
+      return 1;
+    }
+    delete src;
+    return 0;
+  }
   if (m == "stats") {
     // the host-side tail probabilities of `genomic_scans peaks` (gtx_stats.h), one "b K P N" / "p K MU" / "g X" query per stdin line
     char kind; double x, y, z;
@@ -59,9 +73,11 @@ int main(int argc, char **argv)
   chroms.Freeze();
   opt.chroms = &chroms;
   std::string err;
-  LineSource *src = LineSource::Open(file, &err);
-  if (!src) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
-  BedPacker packer(src, opt);
+  LineSource *src = nullptr; GtxView *packed = nullptr;
+  if (GtxView::IsGtx(file)) { packed = GtxView::Open(file, &err); if (!packed) { fprintf(stderr, "%s\n", err.c_str()); return 1; } }
+  else { src = LineSource::Open(file, &err); if (!src) { fprintf(stderr, "%s\n", err.c_str()); return 1; } }
+  BedPacker packer_text(src, opt), packer_packed(packed, opt);
+  BedPacker &packer = packed ? packer_packed : packer_text;
   PackedBatch b; PackError e; int64_t lines = 0;
   for (;;) {
     bool more = packer.NextBatch(&b, batch, &e);
@@ -81,6 +97,6 @@ int main(int argc, char **argv)
   }
   if (quiet) printf("# reads=%lld checksum=%lld\n", n_reads, checksum);
   printf("# lines=%ld\n", (long)lines);
-  delete src;
+  delete src; delete packed;
   return 0;
 }

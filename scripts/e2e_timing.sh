@@ -14,3 +14,8 @@ PY
 GTX_TIMING=1 ./ibm-cbc-genomic-tools_amd/csrc/genomic_overlaps count -S -i /tmp/t_refs.bed /tmp/t_reads.bed 2>&1 >/dev/null | grep gtx
 # whole-process wall time, output to a file (three runs)
 for i in 1 2 3; do s=$(date +%s%N); ./ibm-cbc-genomic-tools_amd/csrc/genomic_overlaps count -S -i /tmp/t_refs.bed /tmp/t_reads.bed > /tmp/t_out.txt; e=$(date +%s%N); echo "wall $(( (e - s) / 1000000 )) ms, $(wc -l < /tmp/t_out.txt) lines"; done
+# the same query set as a packed region file (tokenised once)
+s=$(date +%s%N); ./ibm-cbc-genomic-tools_amd/csrc/gtx_packtool pack /tmp/t_reads.bed /tmp/t_reads.gtx; e=$(date +%s%N); echo "pack: $(( (e - s) / 1000000 )) ms, $(stat -c %s /tmp/t_reads.gtx) bytes"
+GTX_TIMING=1 ./ibm-cbc-genomic-tools_amd/csrc/genomic_overlaps count -S -i /tmp/t_refs.bed /tmp/t_reads.gtx 2>&1 >/tmp/t_out2.txt | grep "gtx " | tail -4
+cmp /tmp/t_out.txt /tmp/t_out2.txt && echo "same output"
+for i in 1 2 3; do s=$(date +%s%N); ./ibm-cbc-genomic-tools_amd/csrc/genomic_overlaps count -S -i /tmp/t_refs.bed /tmp/t_reads.gtx > /tmp/t_out2.txt; e=$(date +%s%N); echo "wall (packed input) $(( (e - s) / 1000000 )) ms"; done

@@ -353,3 +353,51 @@ def test_peaks_without_control_runs(beds):
     assert r.returncode == 0 and len(r.stdout.decode().splitlines()) > 50
     r2 = subprocess.run([TOOLS["scans"], "peaks", "-i", "-g", "genome.bed", "peaks_signal.bed"], capture_output=True, cwd=beds, env=env)
     assert r.stdout == r2.stdout                       # GTX_SEED fixes the background draws
+
+
+# ---- packed region files (.gtx) as the streamed input: same output as the text they were made from -------------
+PACKTOOL = os.path.join(BIN, "gtx_packtool")
+
+
+@pytest.fixture(scope="module")
+def packed(beds):
+    for name in ("reads_pos", "reads_strand", "scan_pos", "scan_strand", "peaks_signal", "peaks_control"):
+        r = subprocess.run([PACKTOOL, "pack", name + ".bed", name + ".gtx"], capture_output=True, cwd=beds)
+        assert r.returncode == 0, r.stderr.decode()
+    r = subprocess.run([PACKTOOL, "pack", "reads_shuffled.bed.gz", "reads_shuffled.gtx"], capture_output=True, cwd=beds)
+    assert r.returncode == 0, r.stderr.decode()
+    return beds
+
+
+PACKED_RUNS = [
+    ("overlaps", ["count", "-S", "-i", "refs.bed", "reads_pos"]),
+    ("overlaps", ["count", "refs.bed", "reads_pos"]),
+    ("overlaps", ["count", "-S", "-s", "refs_strand.bed", "reads_strand"]),
+    ("overlaps", ["count", "-i", "--max-label-value", "4", "refs.bed", "reads_shuffled"]),
+    ("overlaps", ["coverage", "-S", "-i", "refs.bed", "reads_pos"]),
+    ("overlaps", ["rpkm", "-i", "refs.bed", "reads_pos"]),
+    ("overlaps", ["count", "-S", "-i", "refs.bed", "reads_shuffled"]),        # not sorted: the same error either way
+    ("scans", ["counts", "-i", "-g", "genome.bed", "-w", "1000", "-d", "1000", "-min", "1", "scan_pos"]),
+    ("scans", ["counts", "-S", "-g", "genome.bed", "-w", "500", "-d", "25", "-min", "3", "scan_strand"]),
+    ("scans", ["counts", "-i", "-g", "genome.bed", "-r", "scan_refs.bed", "-w", "1000", "-d", "500", "-min", "1", "scan_pos"]),
+]
+
+
+@pytest.mark.parametrize("tool,args", PACKED_RUNS, ids=[" ".join(a) for _, a in PACKED_RUNS])
+def test_packed_input_equals_text_input(packed, tool, args):
+    last = args[-1]
+    text = product(tool, args[:-1] + [last + (".bed.gz" if last == "reads_shuffled" else ".bed")], cwd=packed)
+    pk = product(tool, args[:-1] + [last + ".gtx"], cwd=packed)
+    assert pk[0] == text[0] and pk[1] == text[1]
+    if text[0] != 0:
+        assert pk[2].strip() == text[2].strip()
+    else:
+        assert len(pk[1]) > 100
+
+
+def test_packed_inputs_for_peaks(packed):
+    base = ["peaks", "-i", "-g", "genome.bed", "-cmp"]
+    text = product("scans", base + ["peaks_signal.bed", "peaks_control.bed"], cwd=packed)
+    pk = product("scans", base + ["peaks_signal.gtx", "peaks_control.gtx"], cwd=packed)
+    assert pk[0] == text[0] == 0 and pk[1] == text[1] and len(pk[1]) > 100
+    assert pk[2].replace(".gtx", ".bed") == text[2]

@@ -160,3 +160,67 @@ def test_one_pass_tab_parser_agrees_with_the_general_tokenizer(tmp_path, mode, e
         fast = subprocess.run([TOOL] + args, capture_output=True)
         slow = subprocess.run([TOOL] + args, capture_output=True, env=dict(os.environ, GTX_NO_FAST_PARSE="1"))
         assert (fast.returncode, fast.stdout, fast.stderr) == (slow.returncode, slow.stdout, slow.stderr), lines
+
+
+# ---- packed region files (.gtx): the text parse done once --------------------------------------------------
+def _pack(src, dst):
+    r = subprocess.run([TOOL, "pack", str(src), str(dst)], capture_output=True)
+    return r.returncode, r.stderr.decode()
+
+
+@pytest.mark.parametrize("mode,extra", [("ou", []), ("ou", ["-a"]), ("os", ["-z"]), ("os", ["-a", "-s", "-z"]), ("su", ["-a", "-l", "4"]),
+                                        ("ss", []), ("ou", ["-l", "3"])])
+def test_packed_file_gives_the_same_batches_as_its_text(tmp_path, mode, extra):
+    rng = np.random.default_rng(17)
+    names = ["chr1", "chr10", "chr2", "chrX", "chrUn_1"]
+    n = 30000
+    c = np.sort(rng.integers(0, len(names), size=n))
+    s = np.concatenate([np.sort(rng.integers(0, 200000, size=int((c == k).sum()))) for k in range(len(names))])
+    ln = rng.choice([0, 1, 36, 500], size=n)
+    strand = rng.choice(["+", "-", "."], size=n)
+    label = rng.choice(["5", "2", "abc", "-3", "0", "17"], size=n)
+    order = np.lexsort((s, [names[k] for k in c]))                      # strcmp order of the names, then start
+    f = tmp_path / "reads.bed"
+    with open(f, "w") as h:
+        h.write("track name=x\n")
+        for i in order:
+            h.write("%s\t%d\t%d\t%s\t0\t%s\n" % (names[c[i]], s[i], s[i] + ln[i], label[i], strand[i]))
+    g = tmp_path / "reads.gtx"
+    assert _pack(f, g) == (0, "")
+    # the text path sees the header line only through GenomicRegionSet (which skips it): give the tool the body
+    body = tmp_path / "body.bed"
+    body.write_text("".join(open(f).readlines()[1:]))
+    args = [mode] + extra + ["-t", "3", "-b", "7000", "-c", "chr1,chr10,chr2,chrX"]
+    a = subprocess.run([TOOL] + args + [str(body)], capture_output=True)
+    b = subprocess.run([TOOL] + args + [str(g)], capture_output=True)
+    assert (a.returncode, a.stderr) == (b.returncode, b.stderr)
+    # batches end at different places (text: blocks of lines, packed: record counts), so the per-batch "# zero" notes
+    # interleave differently with the triples; the triples in order and the notes as a set must agree
+    rows = lambda r: [l for l in r.stdout.decode().splitlines() if not l.startswith("#")]
+    notes = lambda r: sorted(l for l in r.stdout.decode().splitlines() if l.startswith("#"))
+    if "-a" in extra:                                    # strand-aware batches put their '-' reads behind their '+' reads
+        assert sorted(rows(a)) == sorted(rows(b)) and notes(a) == notes(b)
+    else:
+        assert rows(a) == rows(b) and notes(a) == notes(b)
+    assert len(a.stdout) > 1000 or a.returncode != 0
+
+
+def test_packed_file_errors_and_order_checks(tmp_path):
+    f = tmp_path / "u.bed"
+    f.write_text("chr1\t10\t20\tx\t0\t+\nchr1\t5\t8\ty\t0\t-\nchr2\t1\t0\tz\t0\t+\n")
+    g = tmp_path / "u.gtx"
+    assert _pack(f, g) == (0, "")
+    for mode, extra in (("os", []), ("ss", ["-a", "-s"]), ("ou", []), ("os", ["-s"])):
+        a = subprocess.run([TOOL, mode] + extra + ["-c", "chr1,chr2", str(f)], capture_output=True)
+        b = subprocess.run([TOOL, mode] + extra + ["-c", "chr1,chr2", str(g)], capture_output=True)
+        assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr), (mode, extra)
+    bad = tmp_path / "bad.bed"
+    bad.write_text("chr1\t10\t20\tx\t0\t+\nchr1\t5\n")
+    rc, err = _pack(bad, tmp_path / "bad.gtx")
+    assert rc == 1 and err == "\nError: Line 2: number of tokens should be at least 3 for BED format!\n"
+    bad.write_text("chr1\t10\t20\tx\t0\t?\n")
+    rc, err = _pack(bad, tmp_path / "bad.gtx")
+    assert rc == 1 and err == "Error: invalid strand '?'!\n"
+    (tmp_path / "junk.gtx").write_bytes(b"GTXP\x01\x00\x00\x00" + b"\xff" * 40)
+    r = subprocess.run([TOOL, "ou", "-c", "chr1", str(tmp_path / "junk.gtx")], capture_output=True)
+    assert r.returncode == 1 and b"not a valid packed region file" in r.stderr
