@@ -512,11 +512,10 @@ __device__ __forceinline__ int max_of(const int (&k)[R]) { int m = k[0];
 // and leaves -- before touching any state -- as soon as a step needs anything else (another class,
 // a degenerate read, a key behind a window, an unplaced window, the partial last step), and the
 // outer loop that gives exactly that step to the general per-chunk code and re-enters.
-template <bool WEIGHTED, int R>
-__global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n,
-                                                         CountArgs a)
+template <bool WEIGHTED, int R, bool FLIP>
+__device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, const CountArgs &a)
 {
-  __shared__ int ldsK[8][256];                                 // per wave: the keys of a step (walk_flip4)
+  __shared__ int ldsK[FLIP ? 8 : 1][FLIP ? 256 : 1];           // per wave: the keys of a step (walk_flip4)
   const int wid = rfl(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + rfl(threadIdx.x >> 6);
@@ -565,13 +564,10 @@ __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__
         // dg < 0 in some lane <=> some read has start > end (+zl)
         const int kmin = min_of<R>(ks), emin = min_of<R>(ke);
         if (__ballot((odd != 0) | (dg < 0) | (kmin <= st.A.prevW) | (emin < st.B.prevW))) break;
-        if constexpr (!WEIGHTED && R == 4) {
-          if (a.flip) {
+        if constexpr (!WEIGHTED && R == 4 && FLIP) {
+          {
             if (!walk_flip4(st.A, st.sg, ks, lane, st.validA, ldsK[wid])) walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
             if (!walk_flip4(st.B, st.sg, ke, lane, st.validB, ldsK[wid])) walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
-          } else {
-            walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
-            walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
           }
         } else if constexpr (!WEIGHTED) {
           walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
@@ -614,6 +610,20 @@ __global__ __launch_bounds__(256) void count_walk_kernel(const Tri *__restrict__
     if (st.nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)st.nDegen); atomicMin((i64 *)&a.info->first_degenerate, st.firstDegen); }
     if (st.firstUnsorted != INT64_MAX) atomicMin((i64 *)&a.info->first_unsorted, st.firstUnsorted);
   }
+}
+
+// Residency is set by the scalar registers: 256-thread blocks are admitted per CU by floor(800 / (ceil(sgpr/16)*16 + 16)) --
+// 8 blocks (8 waves per SIMD) up to 80 SGPRs, 7 up to 96, 6 above (MI355X_MICROARCH.md, "Residency").  Left alone the
+// compiler takes 96-106; capped, it parks ~20 rarely used scalars in the lanes of one VGPR.  100 M x 1 M: 6 -> 8 waves
+// per SIMD, 0.240 -> 0.22 ms.  The all-boundaries-at-once variant needs 72 VGPRs (7 waves), so it gets the 96 cap.
+template <bool WEIGHTED, int R>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void count_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
+{
+  count_walk_body<WEIGHTED, R, false>(reads, weights, n, a);
+}
+__global__ __launch_bounds__(256, 7) __attribute__((amdgpu_num_sgpr(96))) void count_walk_kernel_flip(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
+{
+  count_walk_body<false, 4, true>(reads, weights, n, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1224,6 +1234,7 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
     else if (a.prefetch <= 1) count_walk_kernel<false, 1><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.prefetch == 2) count_walk_kernel<false, 2><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.prefetch == 3) count_walk_kernel<false, 3><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (a.flip) count_walk_kernel_flip<<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else count_walk_kernel<false, 4><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   } else {
     // one 1024-thread block per CU (the LDS top level fills most of the CU's 160 KB)
