@@ -130,18 +130,39 @@ struct Win {
     if (SUMKEY) { if (pend2 != 0) { if (lane == j + 1) acc2 += pend2; pend2 = 0; } }
   }
 
-  // publish the window's accumulators: one contiguous 64-lane atomic add into the histogram, and
-  // the same amounts into the (at most two) tile sums the window touches
+  // publish per-lane accumulators `a` of the window whose slot 0 has rank b: one contiguous 64-lane atomic add into
+  // the histogram, and the same amounts into the (at most two) tile sums the window touches
+  __device__ __forceinline__ void flush_at(const Seg &sg, int lane, int b, acc_t a)
+  {
+    const i64 idx0 = (i64)b - 1 + sg.cls;                    // wave-uniform: histogram index of lane 0
+    const i64 idx = idx0 + lane;
+    if (a != 0) atomicAdd(&hist[idx], (u64)(i64)a);
+    if constexpr (sizeof(acc_t) == 4) {
+      // a wave streams at most 128 x 64 reads, so the lane sums fit 32 bits: one DPP scan, and the tile border
+      // (at most one inside 64 consecutive slots) splits the total by a v_readlane
+      const int p = wave_scan_add((int)a);
+      const int total = rdlane(p, 63);
+      const int t0 = (int)((idx0 + 1) >> kTileShift);        // tile of lane 1 (lane 0 never holds a count)
+      const i64 border = ((i64)(t0 + 1) << kTileShift) - idx0;   // first lane of the next tile
+      const int s0 = border < 64 ? rdlane(p, (int)border - 1) : total;
+      const int s1 = total - s0;
+      if (lane == 0) { if (s0 != 0) atomicAdd(&part[t0], (u64)(unsigned)s0); if (s1 != 0) atomicAdd(&part[t0 + 1], (u64)(unsigned)s1); }
+    } else {
+      const int tile = (int)(idx >> kTileShift);
+      const int t0 = rdlane(tile, 1);                        // lane 0 never holds a count
+      const i64 s0 = wave_sum(tile == t0 ? (i64)a : 0), s1 = wave_sum(tile != t0 ? (i64)a : 0);
+      if (lane == 0) { if (s0 != 0) atomicAdd(&part[t0], (u64)s0); if (s1 != 0) atomicAdd(&part[t0 + 1], (u64)s1); }
+    }
+  }
+
   __device__ __forceinline__ void flush_acc(const Seg &sg, int lane)
   {
-    const i64 idx = (i64)base - 1 + lane + sg.cls;
-    if (acc != 0) atomicAdd(&hist[idx], (u64)(i64)acc);
-    const int tile = (int)(idx >> kTileShift);
-    const int t0 = rdlane(tile, 1);                        // lane 0 never holds a count
-    const i64 s0 = wave_sum(tile == t0 ? (i64)acc : 0), s1 = wave_sum(tile != t0 ? (i64)acc : 0);
-    if (lane == 0) { if (s0 != 0) atomicAdd(&part[t0], (u64)s0); if (s1 != 0) atomicAdd(&part[t0 + 1], (u64)s1); }
+    flush_at(sg, lane, base, acc);
     acc = 0;
     if (SUMKEY) {
+      const i64 idx = (i64)base - 1 + lane + sg.cls;
+      const int tile = (int)(idx >> kTileShift);
+      const int t0 = rdlane(tile, 1);
       if (acc2 != 0) atomicAdd(&hist2[idx], (u64)acc2);
       const i64 q0 = wave_sum(tile == t0 ? acc2 : 0), q1 = wave_sum(tile != t0 ? acc2 : 0);
       if (lane == 0) { if (q0 != 0) atomicAdd(&part2[t0], (u64)q0); if (q1 != 0) atomicAdd(&part2[t0 + 1], (u64)q1); }
@@ -348,10 +369,15 @@ __device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountA
 // behind the current slot (the caller has checked all that).  k[r] are the keys.
 // The boundary-crossing loop inside one register window, hand-scheduled (gfx950 ISA): hipcc turns
 // the C++ form of this multi-exit loop into a state machine of ~50 instructions per boundary; this
-// is 27.  Per boundary: 4 compares against the wave-uniform boundary + 4 scalar popcounts give the
-// number of keys at or below it; the difference to the previous boundary is the slot's count, which
-// is handed to the lane that owns the slot; then the next boundary is fetched with v_readlane.
-// Leaves with status 0 when every key is accounted for, 1 when the window is exhausted (j == 63).
+// is 24.  The loop is entered knowing that some key lies above the boundary W.  Per boundary: 4 compares
+// against the wave-uniform W + 4 scalar popcounts give c = the number of keys at or below it; the slot
+// below W is then complete and receives q + c (q = what was pending for it minus the keys counted by
+// earlier boundaries of this step) in the lane that owns it (a one-lane exec mask around a v_add), q = -c;
+// the next boundary is fetched with v_readlane and one compare of the per-lane maximum tells whether
+// any key is still above it.  Leaves with status 0 when no key is above W (the open slot has q + 64 R
+// pending), 1 when the window is exhausted (j == 63).  The wave issues one instruction per turn and the
+// scalar pipe is the busiest one (PMC), so the instruction count of this loop is what the kernel's
+// distance to the load-only ceiling is made of.
 // CMP is "v_cmp_ge_i32" (key <= W) for the ends array, "v_cmp_gt_i32" (key < W) for the starts array.
 #define GTX_CROSS_LOOP4(CMP)                                                                        \
   asm volatile(                                                                                     \
@@ -366,33 +392,30 @@ __device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountA
       "s_add_i32 %[c], %[c], %[t]\n\t"                                                              \
       CMP " vcc, %[cw], %[k3]\n\t"                                                                  \
       "s_bcnt1_i32_b64 %[t], vcc\n\t"                                                               \
-      "s_add_i32 %[c], %[c], %[t]\n\t"                                                              \
-      "s_sub_i32 %[t], %[c], %[cp]\n\t"                                                             \
-      "s_add_i32 %[pend], %[pend], %[t]\n\t"                                                        \
-      "s_mov_b32 %[cp], %[c]\n\t"                                                                   \
-      "s_mov_b32 %[st], 0\n\t"                                                                      \
-      "s_cmpk_eq_i32 %[c], 0x100\n\t"                                                               \
-      "s_cbranch_scc1 2f\n\t"                                                                       \
       "s_add_i32 %[j], %[j], 1\n\t"                /* lane j+1 owns the slot that is now complete */ \
-      "s_add_i32 %[t], %[j], 1\n\t"                /* lane of the next upper boundary             */ \
-      "v_cmp_eq_u32 vcc, %[j], %[lane]\n\t"                                                         \
-      "v_mov_b32 %[tv], %[pend]\n\t"                                                                \
-      "v_cndmask_b32 %[tv], 0, %[tv], vcc\n\t"                                                      \
-      "v_add_u32 %[acc], %[acc], %[tv]\n\t"                                                         \
-      "s_mov_b32 %[pend], 0\n\t"                                                                    \
-      "s_mov_b32 %[st], 1\n\t"                                                                      \
+      "s_add_i32 %[c], %[c], %[t]\n\t"                                                              \
+      "s_add_i32 %[t1], %[j], 1\n\t"               /* lane of the next upper boundary             */ \
+      "s_lshl_b64 exec, 1, %[j]\n\t"                                                                \
+      "s_add_i32 %[t], %[q], %[c]\n\t"                                                              \
+      "s_sub_i32 %[q], 0, %[c]\n\t"                                                                 \
+      "v_add_u32 %[acc], %[t], %[acc]\n\t"                                                          \
+      "s_mov_b64 exec, -1\n\t"                                                                      \
       "s_cmpk_eq_i32 %[j], 63\n\t"                                                                  \
       "s_cbranch_scc1 2f\n\t"                                                                       \
-      "v_readlane_b32 %[cw], %[w], %[t]\n\t"       /* >= 4 instructions after the s_add of t      */ \
-      "s_branch 1b\n\t"                                                                             \
+      "v_readlane_b32 %[cw], %[w], %[t1]\n\t"                                                       \
+      "s_nop 0\n\t"                                                                                 \
+      CMP " vcc, %[cw], %[km]\n\t"                                                                  \
+      "s_cmp_eq_u64 vcc, -1\n\t"                                                                    \
+      "s_cbranch_scc0 1b\n\t"                                                                       \
+      "s_mov_b32 %[st], 0\n\t"                                                                      \
       "2:\n\t"                                                                                      \
-      : [c] "=&s"(c), [t] "=&s"(t), [st] "=&s"(status), [tv] "=&v"(tv), [cw] "+s"(curW), [j] "+s"(j),  \
-        [pend] "+s"(pend), [cp] "+s"(cprev), [acc] "+v"(X.acc)                                      \
-      : [k0] "v"(k[0]), [k1] "v"(k[1]), [k2] "v"(k[2]), [k3] "v"(k[3]), [w] "v"(X.W), [lane] "v"(lane) \
+      : [c] "=&s"(c), [t] "=&s"(t), [t1] "=&s"(t1), [st] "+s"(status), [cw] "+s"(curW), [j] "+s"(j), \
+        [q] "+s"(q), [acc] "+v"(X.acc)                                                              \
+      : [k0] "v"(k[0]), [k1] "v"(k[1]), [k2] "v"(k[2]), [k3] "v"(k[3]), [km] "v"(kmax), [w] "v"(X.W) \
       : "vcc", "scc")
 
 // Fast path for R x 64 reads of the current class, all valid, unweighted, window placed and no key
-// behind the current slot (the caller has checked all that).  k[r] are the keys.
+// behind the current slot (the caller has checked all that).  k[r] are the keys, kmax their per-lane maximum.
 template <int R, class WIN>
 __device__ __forceinline__ void walk_fast(WIN &X, const Seg &sg, const int (&k)[R], int kmax, int lane, bool &valid)
 {
@@ -404,10 +427,13 @@ __device__ __forceinline__ void walk_fast(WIN &X, const Seg &sg, const int (&k)[
   for (;;) {
     int status;
     if constexpr (R == 4 && sizeof(X.acc) == 4) {
-      unsigned c, t, tv;
+      unsigned c, t, t1, q = pend - cprev;
+      status = 1;
       if (WIN::kStrict) GTX_CROSS_LOOP4("v_cmp_gt_i32"); else GTX_CROSS_LOOP4("v_cmp_ge_i32");
       // asm results count as divergent for the compiler; they are SGPRs: tell it so
-      status = rfl(status); j = rfl(j); curW = rfl(curW); pend = (unsigned)rfl((int)pend); cprev = (unsigned)rfl((int)cprev);
+      status = rfl(status); j = rfl(j); curW = rfl(curW); q = (unsigned)rfl((int)q);
+      if (status == 0) { pend = q + 64u * R; }
+      else { pend = 0; cprev = 0u - q; }                     // window exhausted right after a deposit: q = -c
     } else {
       status = 1;
       for (;;) {                                             // inside one register window
@@ -436,6 +462,10 @@ __device__ __forceinline__ void walk_fast(WIN &X, const Seg &sg, const int (&k)[
       X.j = 0; X.prevW = passed; X.curW = curW; X.pend = 0;
       valid = false;                                         // acc is 0 and nothing is pending: nothing to flush
       return;
+    }
+    if constexpr (R == 4 && sizeof(X.acc) == 4) {
+      // the asm loop is entered only with some key above curW
+      if (__ballot(WIN::below(kmax, curW)) == ~0ull) { X.j = 0; X.prevW = rdlane(X.W, 0); X.curW = curW; X.pend = 64u * R - cprev; return; }
     }
   }
 }
