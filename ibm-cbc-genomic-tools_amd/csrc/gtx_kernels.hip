@@ -577,33 +577,39 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
     Tri t[R];
     bool have = false;                                         // t holds step s (loaded by the fast loop)
     // ---------------- fast loop ----------------
-    // No software prefetch: a second register buffer costs 48 VGPRs (8 -> 4 waves per SIMD) and
-    // measured no gain; the 7-8 resident waves per SIMD overlap each other's load latency instead.
+    // No software prefetch: a second register set (two-step ping-pong) takes the kernel from 58 to 91 VGPRs
+    // (8 -> 5 waves per SIMD) and measured 0.243 against 0.222 ms; the 8 resident waves per SIMD overlap each
+    // other's load latency instead.
     if (fastOk && st.validA && st.validB) {
-      while (s < nFull) {
-        const char *p = base + (size_t)s * (768 * R) + loff;
-#pragma unroll
-        for (int r = 0; r < R; ++r) t[r] = load_tri(p + 768 * r);
-        have = true;
+      // one step of the fast path on registers tt; false (nothing touched) when the step needs the general path
+      auto fast_step = [&](const Tri (&tt)[R]) -> bool {
         int odd = 0, dg = 0, ks[R], ke[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          odd |= t[r].c ^ st.sg.cls; ks[r] = t[r].s; ke[r] = t[r].e;
-          dg |= __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(t[r].e, zl), t[r].s);   // saturating: the sign is exact for any int32
+          odd |= tt[r].c ^ st.sg.cls; ks[r] = tt[r].s; ke[r] = tt[r].e;
+          dg |= __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(tt[r].e, zl), tt[r].s);   // saturating: the sign is exact for any int32
         }
         // dg < 0 in some lane <=> some read has start > end (+zl)
         const int kmin = min_of<R>(ks), emin = min_of<R>(ke);
-        if (__ballot((odd != 0) | (dg < 0) | (kmin <= st.A.prevW) | (emin < st.B.prevW))) break;
+        if (__ballot((odd != 0) | (dg < 0) | (kmin <= st.A.prevW) | (emin < st.B.prevW))) return false;
         if constexpr (!WEIGHTED && R == 4 && FLIP) {
-          {
-            if (!walk_flip4(st.A, st.sg, ks, lane, st.validA, ldsK[wid])) walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
-            if (!walk_flip4(st.B, st.sg, ke, lane, st.validB, ldsK[wid])) walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
-          }
+          if (!walk_flip4(st.A, st.sg, ks, lane, st.validA, ldsK[wid])) walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
+          if (!walk_flip4(st.B, st.sg, ke, lane, st.validB, ldsK[wid])) walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
         } else if constexpr (!WEIGHTED) {
           walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
           walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
         }
-        ++s; have = false;
+        return true;
+      };
+      auto load_step = [&](Tri (&tt)[R], int step) {
+        const char *p = base + (size_t)step * (768 * R) + loff;
+#pragma unroll
+        for (int r = 0; r < R; ++r) tt[r] = load_tri(p + 768 * r);
+      };
+      while (s < nFull) {
+        load_step(t, s);
+        if (!fast_step(t)) { have = true; break; }
+        ++s;
         if (!(st.validA && st.validB)) break;
       }
       if (s >= nSteps) break;
@@ -644,14 +650,14 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
 
 // Residency is set by the scalar registers: 256-thread blocks are admitted per CU by floor(800 / (ceil(sgpr/16)*16 + 16)) --
 // 8 blocks (8 waves per SIMD) up to 80 SGPRs, 7 up to 96, 6 above (MI355X_MICROARCH.md, "Residency").  Left alone the
-// compiler takes 96-106; capped, it parks ~20 rarely used scalars in the lanes of one VGPR.  100 M x 1 M: 6 -> 8 waves
-// per SIMD, 0.240 -> 0.22 ms.  The all-boundaries-at-once variant needs 72 VGPRs (7 waves), so it gets the 96 cap.
+// compiler takes 96-106 for this kernel; capped, it parks a dozen rarely used scalars in the lanes of one VGPR.
+// 100 M x 1 M: 6 -> 8 waves per SIMD, 0.240 -> 0.222 ms.
 template <bool WEIGHTED, int R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void count_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
 {
   count_walk_body<WEIGHTED, R, false>(reads, weights, n, a);
 }
-__global__ __launch_bounds__(256, 7) __attribute__((amdgpu_num_sgpr(96))) void count_walk_kernel_flip(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void count_walk_kernel_flip(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
 {
   count_walk_body<false, 4, true>(reads, weights, n, a);
 }
