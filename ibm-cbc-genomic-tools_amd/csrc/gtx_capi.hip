@@ -30,6 +30,7 @@ struct gtx_ctx {
   int nClasses = 0;
   int *d_sortedE = nullptr, *d_sortedS = nullptr, *d_segStart = nullptr;
   int *d_sampE = nullptr, *d_sampS = nullptr; int sampShift = 6, nSamp = 0;   // top level of the search kernel
+  int *d_topE = nullptr, *d_topS = nullptr;   // every 256th boundary: first hop of the streaming kernel's start-of-span search
   // unsorted reads, bucket path (gtx_bucket.hip): table built with the references, scratch sized by the largest call
   int *d_bkt = nullptr; int nB = 0;                  // posHi | eLo | eHi | sLo | sHi | cls (nB each) | clsStart (nClasses+1)
   unsigned *d_bktCnt = nullptr;                      // count | offset (nB+1) | cursor
@@ -121,7 +122,7 @@ void gtx_destroy(gtx_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
-  dfree(c->d_bktIds); dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_bkt); dfree(c->d_bktCnt);
+  dfree(c->d_bktIds); dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_bktCnt);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   dfree(c->d_reads); dfree(c->d_weights); dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
   for (auto &p : c->d_cov) dfree(p);
@@ -198,7 +199,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   }
 
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
-  dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_bkt); dfree(c->d_bktCnt);
+  dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_bktCnt);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB);
   c->nRefs = -1;
   const int64_t histLen = nv + nClasses;
@@ -233,6 +234,13 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
     HIPCHK(c, hipMalloc(&c->d_sampS, sizeof(int32_t) * (c->nSamp + 1)));
     HIPCHK(c, hipMemcpy(c->d_sampE, sampE.data(), sizeof(int32_t) * (c->nSamp + 1), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_sampS, sampS.data(), sizeof(int32_t) * (c->nSamp + 1), hipMemcpyHostToDevice));
+    const int64_t nTop = (nv + 255) >> 8;
+    std::vector<int32_t> topE(nTop + 1), topS(nTop + 1);
+    for (int64_t i = 0; i < nTop; i++) { topE[i] = sortedE[i << 8]; topS[i] = sortedS[i << 8]; }
+    HIPCHK(c, hipMalloc(&c->d_topE, sizeof(int32_t) * (nTop + 1)));
+    HIPCHK(c, hipMalloc(&c->d_topS, sizeof(int32_t) * (nTop + 1)));
+    HIPCHK(c, hipMemcpy(c->d_topE, topE.data(), sizeof(int32_t) * (nTop + 1), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_topS, topS.data(), sizeof(int32_t) * (nTop + 1), hipMemcpyHostToDevice));
   }
   {
     // bucket table of the unsorted path: cuts of the ends array every bucket_e_size() boundaries, never across classes
@@ -294,6 +302,7 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
   a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0; a.prefetch = c->prefetch;
   a.zeroLenOk = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   a.sampE = c->d_sampE; a.sampS = c->d_sampS; a.sampShift = c->sampShift; a.nSamp = c->nSamp;
+  a.topE = c->d_topE; a.topS = c->d_topS;
   // dense references (>= 4 boundaries per 256 reads and array): all boundaries of a window at once instead of the
   // per-boundary loop (100 M reads x 4 M regions: 0.41 -> 0.28 ms; at 1 M regions the loop is 3 % faster).  GTX_FLIP=0|1 forces.
   { static const char *fl = getenv("GTX_FLIP"); a.flip = fl ? atoi(fl) : (c->nValid * 256 >= 4 * std::max<int64_t>(nReads, 1)); }

@@ -31,6 +31,8 @@ struct CountArgs {
   const int *sampE;              // every (1 << sampShift)-th element of sortedE / sortedS: the
   const int *sampS;              //   search kernel keeps them in LDS as the top level of its searches
   int sampShift, nSamp;
+  const int *topE;               // every 256th element of sortedE / sortedS (index i << 8): first hop of the streaming
+  const int *topS;               //   kernel's start-of-span search (rank_pair)
   int flip;                      // streaming kernel: meet all boundaries of a window at once (dense references)
 };
 

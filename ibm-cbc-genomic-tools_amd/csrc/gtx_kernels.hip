@@ -535,6 +535,74 @@ __device__ __forceinline__ int max_of(const int (&k)[R]) { int m = k[0];
   for (int r = 1; r < R; ++r) m = k[r] > m ? k[r] : m;
   return m; }
 
+// Start of a wave's span: the ranks of its first keys in both boundary arrays, found together.  What a wave pays before
+// it streams is a chain of dependent memory round trips (~2 us each under load) and the cache lines its probes touch:
+// one 64-ary search after the other (Win::seek: three levels of 64 scattered lines each for 40 k boundaries per class)
+// plus the two window placements made that chain nine round trips and ~400 lines long -- ~30 us of the 215 us a
+// 100 M-read launch takes, three waves per slot.  Here both searches go in lockstep through two CONTIGUOUS hops: the
+// class's piece of the every-256th-boundary arrays (topE / topS, <= 256 entries up to 65 k boundaries per class; larger
+// classes narrow it first with 256 strided probes per level), then the <= 255 boundaries between two samples.
+// Reads, samples, boundaries, windows = four round trips, ~70 lines.
+//   rank = sg.start + #{v in arr[sg.start..sg.end) : before(v, key)}   (as Win::rank_of)
+template <class WA, class WB>
+__device__ __forceinline__ void rank_pair(const Seg &sg, const WA &A, const int *__restrict__ topA, int keyA, const WB &B,
+                                          const int *__restrict__ topB, int keyB, int lane, int &pA, int &pB)
+{
+  // samples of the class: indices t0 .. t1-1 of the top arrays (boundary t << 8 lies in [sg.start, sg.end))
+  const int t0 = (sg.start + 255) >> 8, t1 = ((sg.end - 1) >> 8) + 1;
+  int loA = t0, hiA = t1 > t0 ? t1 : t0, loB = loA, hiB = hiA;
+  while (hiA - loA > 256 || hiB - loB > 256) {
+    const int stA = (hiA - loA + 255) >> 8, stB = (hiB - loB + 255) >> 8;
+    int vA[4], vB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const i64 ia = (i64)loA + (i64)(64 * i + lane) * stA, ib = (i64)loB + (i64)(64 * i + lane) * stB;
+      vA[i] = ia < hiA ? topA[ia] : kHi;
+      vB[i] = ib < hiB ? topB[ib] : kHi;
+    }
+    int nA = 0, nB = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const i64 ia = (i64)loA + (i64)(64 * i + lane) * stA, ib = (i64)loB + (i64)(64 * i + lane) * stB;
+      nA += __popcll(__ballot(ia < hiA && WA::before(vA[i], keyA)));
+      nB += __popcll(__ballot(ib < hiB && WB::before(vB[i], keyB)));
+    }
+    // the probes are in array order, so nX of them before the key means: the rank lies behind probe nX-1 and at or before probe nX
+    if (nA == 0) hiA = loA; else { const i64 nh = (i64)loA + (i64)nA * stA; loA = loA + (nA - 1) * stA + 1; if (nh < hiA) hiA = (int)nh; }
+    if (nB == 0) hiB = loB; else { const i64 nh = (i64)loB + (i64)nB * stB; loB = loB + (nB - 1) * stB + 1; if (nh < hiB) hiB = (int)nh; }
+  }
+  int vA[4], vB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ia = loA + 64 * i + lane, ib = loB + 64 * i + lane;
+    vA[i] = ia < hiA ? topA[ia] : kHi;
+    vB[i] = ib < hiB ? topB[ib] : kHi;
+  }
+  int sA = loA, sB = loB;                                    // first sample that is not before the key
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ia = loA + 64 * i + lane, ib = loB + 64 * i + lane;
+    sA += __popcll(__ballot(ia < hiA && WA::before(vA[i], keyA)));
+    sB += __popcll(__ballot(ib < hiB && WB::before(vB[i], keyB)));
+  }
+  // the boundaries behind the last sample before the key, up to the first sample that is not: < 256 of them
+  const int eLoA = sA > t0 ? ((sA - 1) << 8) + 1 : sg.start, eHiA = sA < t1 ? (sA << 8) : sg.end;
+  const int eLoB = sB > t0 ? ((sB - 1) << 8) + 1 : sg.start, eHiB = sB < t1 ? (sB << 8) : sg.end;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ia = eLoA + 64 * i + lane, ib = eLoB + 64 * i + lane;
+    vA[i] = ia < eHiA ? A.arr[ia] : kHi;
+    vB[i] = ib < eHiB ? B.arr[ib] : kHi;
+  }
+  pA = eLoA; pB = eLoB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ia = eLoA + 64 * i + lane, ib = eLoB + 64 * i + lane;
+    pA += __popcll(__ballot(ia < eHiA && WA::before(vA[i], keyA)));
+    pB += __popcll(__ballot(ib < eHiB && WB::before(vB[i], keyB)));
+  }
+}
+
 // One wave owns chunksPerWave*64 consecutive reads and takes them in steps of R x 64 (register r of
 // lane l holds read 64 r + l of the step: R coalesced 768-byte requests).  The scalar work per step
 // (loop control, class / validity test, two "did anything cross a boundary" tests) is amortised over
@@ -573,9 +641,31 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
   const int zl = a.zeroLenOk;
 
   int s = 0;
+  Tri t[R];
+  bool have = false;                                           // t holds step s
+  if (fastOk && nFull > 0) {
+    // the common start: the first step is all of one class with reference regions -- place both windows at once
+#pragma unroll
+    for (int r = 0; r < R; ++r) t[r] = load_tri(base + 768 * r + loff);
+    have = true;
+    const int c0 = rdlane(t[0].c, 0);
+    int odd = 0, dg = 0, ks[R], ke[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      odd |= t[r].c ^ c0; ks[r] = t[r].s; ke[r] = t[r].e;
+      dg |= __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(t[r].e, zl), t[r].s);
+    }
+    if ((unsigned)c0 < (unsigned)a.nClasses && !__ballot((odd != 0) | (dg < 0))) {
+      st.sg.start = rfl(a.segStart[c0]); st.sg.end = rfl(a.segStart[c0 + 1]); st.sg.cls = c0;
+      if (st.sg.start != st.sg.end) {
+        int pA, pB;
+        rank_pair(st.sg, st.A, a.topE, wave_min(min_of<R>(ks)), st.B, a.topS, wave_min(min_of<R>(ke)), lane, pA, pB);
+        st.A.place(st.sg, pA, lane); st.B.place(st.sg, pB, lane);
+        st.validA = st.validB = true;
+      }
+    }
+  }
   while (s < nSteps) {
-    Tri t[R];
-    bool have = false;                                         // t holds step s (loaded by the fast loop)
     // ---------------- fast loop ----------------
     // No software prefetch: a second register set (two-step ping-pong) takes the kernel from 58 to 91 VGPRs
     // (8 -> 5 waves per SIMD) and measured 0.243 against 0.222 ms; the 8 resident waves per SIMD overlap each
@@ -607,9 +697,10 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
         for (int r = 0; r < R; ++r) tt[r] = load_tri(p + 768 * r);
       };
       while (s < nFull) {
-        load_step(t, s);
-        if (!fast_step(t)) { have = true; break; }
-        ++s;
+        if (!have) load_step(t, s);
+        have = true;
+        if (!fast_step(t)) break;
+        ++s; have = false;
         if (!(st.validA && st.validB)) break;
       }
       if (s >= nSteps) break;
@@ -637,7 +728,7 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
       const u64 active = left >= 64 ? ~0ull : ((1ull << left) - 1);
       walk_chunk<WEIGHTED>(st, a, tt, ww, active, first + at + 64 * r, lane);
     }
-    ++s;
+    ++s; have = false;
   }
   if (st.validA) st.A.flush(st.sg, lane);
   if (st.validB) st.B.flush(st.sg, lane);
