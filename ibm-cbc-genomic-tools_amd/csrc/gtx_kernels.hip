@@ -101,7 +101,7 @@ struct Win {
   typedef typename std::conditional<WEIGHTED || SUMKEY, i64, unsigned>::type acc_t;
   const int *arr;       // sorted boundaries of all classes
   u64 *hist;            // rank histogram, index = rank + class id
-  u64 *part;            // per-tile (kTile slots) sums of hist, kept up to date for the finalize scan
+  u64 *part;            // per-tile (kTile slots) sums of hist, kept up to date for the finalize scan (nullptr: not kept)
   u64 *hist2, *part2;   // SUMKEY only
   i64 acc2, pend2;      // SUMKEY only
   int base;             // global rank of slot 0
@@ -137,6 +137,7 @@ struct Win {
     const i64 idx0 = (i64)b - 1 + sg.cls;                    // wave-uniform: histogram index of lane 0
     const i64 idx = idx0 + lane;
     if (a != 0) atomicAdd(&hist[idx], (u64)(i64)a);
+    if (!part) return;                                       // few tiles: the finalize step rebuilds their sums (see count_args)
     if constexpr (sizeof(acc_t) == 4) {
       // a wave streams at most 128 x 64 reads, so the lane sums fit 32 bits: one DPP scan, and the tile border
       // (at most one inside 64 consecutive slots) splits the total by a v_readlane
@@ -250,7 +251,7 @@ struct Win {
       if (SUMKEY) atomicAdd(&hist2[idx], (u64)(w * key));
       tile = (int)(idx >> kTileShift);
     }
-    u64 rem = m;
+    u64 rem = part ? m : 0;                                  // part == nullptr: the finalize step rebuilds the tile sums
     while (rem) {
       const int t0 = rdlane(tile, __ffsll((unsigned long long)rem) - 1);
       const u64 g = __ballot(tile == t0) & rem;
