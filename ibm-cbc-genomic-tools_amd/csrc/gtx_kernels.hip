@@ -69,6 +69,18 @@ __device__ __forceinline__ int wave_scan_add(int v)
   return v;
 }
 
+// the same for 64-bit values: both halves travel by DPP, the add carries
+__device__ __forceinline__ u64 wave_scan_add64(u64 v)
+{
+#define GTX_DPP64(ctrl, rmask, bc)                                                                                  \
+  v += ((u64)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(v >> 32), ctrl, rmask, 0xf, bc) << 32) |                \
+       (u64)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, ctrl, rmask, 0xf, bc)
+  GTX_DPP64(0x111, 0xf, true); GTX_DPP64(0x112, 0xf, true); GTX_DPP64(0x114, 0xf, true); GTX_DPP64(0x118, 0xf, true);
+  GTX_DPP64(0x142, 0xa, false); GTX_DPP64(0x143, 0xc, false);
+#undef GTX_DPP64
+  return v;
+}
+
 __device__ __forceinline__ int wave_min(int v)
 {
 #pragma unroll
@@ -1092,15 +1104,19 @@ __device__ __forceinline__ u64 block_sum(u64 v, u64 *lds)
 __global__ __launch_bounds__(256) void tile_sums_kernel(const u64 *__restrict__ ha, const u64 *__restrict__ hb, i64 len,
                                                         u64 *__restrict__ pa, u64 *__restrict__ pb)
 {
+  // grid (tiles, 2): blockIdx.y picks the histogram; thread t owns 4 consecutive slots (two 16-byte loads)
   __shared__ u64 lds[4];
-  const i64 b0 = (i64)blockIdx.x * kTile;
-  u64 sa = 0, sb = 0;
-  for (int k = 0; k < kTile / 256; k++) {
-    i64 i = b0 + (i64)k * 256 + threadIdx.x;
-    if (i < len) { sa += ha[i]; sb += hb[i]; }
+  const u64 *__restrict__ h = blockIdx.y ? hb : ha;
+  const i64 i0 = (i64)blockIdx.x * kTile + (i64)threadIdx.x * 4;
+  u64 s = 0;
+  if (i0 + 4 <= len) {
+    const ulonglong2 x = *(const ulonglong2 *)(h + i0), y = *(const ulonglong2 *)(h + i0 + 2);
+    s = x.x + x.y + y.x + y.y;
+  } else {
+    for (int k = 0; k < 4; k++) if (i0 + k < len) s += h[i0 + k];
   }
-  sa = block_sum(sa, lds); sb = block_sum(sb, lds);
-  if (threadIdx.x == 0) { pa[blockIdx.x] = sa; pb[blockIdx.x] = sb; }
+  s = block_sum(s, lds);
+  if (threadIdx.x == 0) (blockIdx.y ? pb : pa)[blockIdx.x] = s;
 }
 
 // grid (tiles, 2): blockIdx.y picks the histogram (A or B) -- twice the blocks, half the work per block
@@ -1117,24 +1133,35 @@ __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha
   const int tile = blockIdx.x;
   // thread t owns 4 consecutive slots (two 16-byte loads); issued first, used last
   const i64 i0 = (i64)tile * kTile + (i64)threadIdx.x * 4;
+  const bool full = i0 + 4 <= len;                   // (32-byte aligned: the histograms come from hipMalloc, i0 is a multiple of 4)
   u64 v[4];
+  if (full) {
+    const ulonglong2 x = *(const ulonglong2 *)(h + i0), y = *(const ulonglong2 *)(h + i0 + 2);
+    v[0] = x.x; v[1] = x.y; v[2] = y.x; v[3] = y.y;
+  } else {
 #pragma unroll
-  for (int k = 0; k < 4; k++) v[k] = i0 + k < len ? h[i0 + k] : 0;
+    for (int k = 0; k < 4; k++) v[k] = i0 + k < len ? h[i0 + k] : 0;
+  }
   // offset of this tile: sum of the tile sums below it
   u64 o = 0;
   for (int t = threadIdx.x; t < tile; t += 256) o += ts[t];
   o = block_sum(o, lds);
   v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
-  u64 x = v[3];                                    // inclusive scan of the thread totals across the wave
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { u64 y = __shfl_up(x, d); if (lane >= d) x += y; }
+  const u64 x = wave_scan_add64(v[3]);             // inclusive scan of the thread totals across the wave (DPP)
   if (lane == 63) wsum[wv] = x;
   __syncthreads();
   o += x - v[3];
   for (int k = 0; k < wv; k++) o += wsum[k];
+  if (full) {
+    *(ulonglong2 *)(p + i0) = make_ulonglong2(v[0] + o, v[1] + o);
+    *(ulonglong2 *)(p + i0 + 2) = make_ulonglong2(v[2] + o, v[3] + o);
+    *(ulonglong2 *)(h + i0) = make_ulonglong2(0, 0);
+    *(ulonglong2 *)(h + i0 + 2) = make_ulonglong2(0, 0);
+  } else {
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (i0 + k < len) { p[i0 + k] = v[k] + o; h[i0 + k] = 0; }
+    for (int k = 0; k < 4; k++)
+      if (i0 + k < len) { p[i0 + k] = v[k] + o; h[i0 + k] = 0; }
+  }
 }
 
 __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict__ pa, const u64 *__restrict__ pb,
@@ -1386,7 +1413,7 @@ hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 
 {
   const int nb = scan_tiles(histLen);
   if (nb > 0) {
-    if (!tileSumsValid) tile_sums_kernel<<<nb, 256, 0, st>>>(histA, histB, histLen, tileA, tileB);
+    if (!tileSumsValid) tile_sums_kernel<<<dim3(nb, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB);
     finalize_scan_kernel<<<dim3(nb, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB);
   }
   const i64 work = (m > nb ? m : nb) > 0 ? (m > nb ? m : nb) : 1;
