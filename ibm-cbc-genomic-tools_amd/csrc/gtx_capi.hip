@@ -62,6 +62,7 @@ struct gtx_ctx {
   // measurement
   static constexpr int kProfSlots = 64;   // ring: the last 64 profiled calls can be read back
   bool prof = false; long long profCalls = 0;
+  int profEvery = 1; long long profSeq = 0; bool profThis = false;   // gtx_profile_enable(N >= 2): kernel-only events on every N-th call
   hipEvent_t evRing[kProfSlots][4] = {};
   hipEvent_t *ev = evRing[0];
 
@@ -372,13 +373,14 @@ int gtx_count_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int
   if (n < 0 || (n > 0 && !d_reads) || (c->nRefs > 0 && !d_hits)) return fail(c, GTX_E_ARG, "gtx_count_device: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   int rc = count_begin(c); if (rc) return rc;
-  if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
+  c->profThis = c->prof && (c->profEvery <= 1 || (c->profSeq++ % c->profEvery) == 0);
+  if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
   if (!(flags & GTX_READS_SORTED)) c->tileSumsValid = false;
   if (flags & GTX_READS_SORTED) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), true, c->stream));
   else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n)); if (rc) return rc; }
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   rc = count_end(c, d_hits); if (rc) return rc;
-  if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
+  if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   return GTX_OK;
 }
 
@@ -561,11 +563,12 @@ int gtx_coverage_device(gtx_ctx *c, const void *d_reads, const void *d_weights, 
   if (n < 0 || (n > 0 && !d_reads) || (c->nRefs > 0 && !d_cov)) return fail(c, GTX_E_ARG, "gtx_coverage_device: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
   int rc = cover_begin(c); if (rc) return rc;
-  if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
+  c->profThis = c->prof && (c->profEvery <= 1 || (c->profSeq++ % c->profEvery) == 0);
+  if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
   HIPCHK(c, gtx::launch_coverage(d_reads, d_weights, n, cover_args(c, n), c->stream));
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   rc = cover_end(c, d_cov); if (rc) return rc;
-  if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
+  if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   return GTX_OK;
 }
 
@@ -688,11 +691,12 @@ int gtx_scan_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int6
   if (c->scanTotalWindows > 0 && !d_out) return fail(c, GTX_E_ARG, "gtx_scan_device: null output");
   const bool micro64 = d_weights != nullptr;
   if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (micro64 ? 8 : 4), c->stream));
-  if (c->prof) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
+  c->profThis = c->prof && (c->profEvery <= 1 || (c->profSeq++ % c->profEvery) == 0);
+  if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
   HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream));
-  if (c->prof) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, (u64 *)d_out, c->stream));
-  if (c->prof) { HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
+  if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   return GTX_OK;
 }
 
@@ -733,7 +737,12 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
 // ---------------------------------------------------------------------------------------------
 // measurement
 // ---------------------------------------------------------------------------------------------
-int gtx_profile_enable(gtx_ctx *c, int on) { if (!c) return GTX_E_ARG; c->prof = on != 0; c->profCalls = 0; return GTX_OK; }
+int gtx_profile_enable(gtx_ctx *c, int on)
+{
+  if (!c || on < 0) return GTX_E_ARG;
+  c->prof = on != 0; c->profEvery = on > 1 ? on : 1; c->profCalls = 0; c->profSeq = 0; c->profThis = false;
+  return GTX_OK;
+}
 
 int gtx_profile_read(gtx_ctx *c, int back, float *msKernel, float *msTotal)
 {
@@ -741,15 +750,18 @@ int gtx_profile_read(gtx_ctx *c, int back, float *msKernel, float *msTotal)
   if (back < 0 || back >= gtx_ctx::kProfSlots || back >= c->profCalls) return fail(c, GTX_E_STATE, "gtx_profile_read: no such profiled call");
   HIPCHK(c, hipSetDevice(c->device));
   hipEvent_t *ev = c->evRing[(c->profCalls - 1 - back) % gtx_ctx::kProfSlots];
-  HIPCHK(c, hipEventSynchronize(ev[3]));
+  const bool kernelOnly = c->profEvery > 1;
+  HIPCHK(c, hipEventSynchronize(ev[kernelOnly ? 2 : 3]));
   float a = 0, b = 0;
   HIPCHK(c, hipEventElapsedTime(&a, ev[1], ev[2]));
-  HIPCHK(c, hipEventElapsedTime(&b, ev[1], ev[3]));
+  if (kernelOnly) b = a; else HIPCHK(c, hipEventElapsedTime(&b, ev[1], ev[3]));
   if (msKernel) *msKernel = a;
   if (msTotal) *msTotal = b;
   return GTX_OK;
 }
 
 int gtx_profile_last(gtx_ctx *c, float *msKernel, float *msTotal) { return gtx_profile_read(c, 0, msKernel, msTotal); }
+
+int gtx_profile_count(gtx_ctx *c) { return c ? (int)std::min<long long>(c->profCalls, gtx_ctx::kProfSlots) : 0; }
 
 } // extern "C"

@@ -67,6 +67,7 @@ ABI = {
                                        ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gtx_profile_last": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_profile_count": (ctypes.c_int, [ctypes.c_void_p]),
     "gtx_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
@@ -211,7 +212,11 @@ class Engine:
         return off, tot
 
     def profile(self, on=True):
-        self._chk(self.lib.gtx_profile_enable(self.ctx, 1 if on else 0))
+        """True/1: events around every call; N >= 2: kernel-only events on every N-th call; False/0: off (gtx.h)."""
+        self._chk(self.lib.gtx_profile_enable(self.ctx, int(on)))
+
+    def profiled_calls(self):
+        return int(self.lib.gtx_profile_count(self.ctx))
 
     def profile_last(self, back=0):
         """(ms of the streaming kernel, ms of the whole call) of the call `back` calls before the last profiled one."""

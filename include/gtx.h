@@ -178,8 +178,11 @@ int gtx_scan_device(gtx_ctx *ctx, const void *d_read_triples, const void *d_weig
 
 /* ---- measurement ------------------------------------------------------------------------ */
 
-/* When enabled, every *_device call brackets its dominant kernel (and the whole call) with
- * HIP events on the context's stream. */
+/* on = 1: every *_device call brackets its dominant kernel and the whole call with HIP events on the
+ * context's stream (three records, ~5 us of stream bubble each on this platform).
+ * on = N >= 2: only every N-th call is profiled and only its dominant kernel is bracketed (two records;
+ * ms_total then repeats ms_stream_kernel) -- for timing loops that should not be stretched by their own
+ * instrumentation.  on = 0: off.  Resets the ring of profiled calls. */
 int gtx_profile_enable(gtx_ctx *ctx, int on);
 /* Elapsed ms of the last profiled call: the streaming kernel alone, and the whole enqueue
  * (memsets + stream kernel + finalize kernels).  Waits for that call to finish. */
@@ -187,6 +190,8 @@ int gtx_profile_last(gtx_ctx *ctx, float *ms_stream_kernel, float *ms_total);
 /* Same for the call `back` calls before the last one (0 = last); the last 64 profiled calls
  * are kept, so a timed loop can be read back after it ends without synchronising inside it. */
 int gtx_profile_read(gtx_ctx *ctx, int back, float *ms_stream_kernel, float *ms_total);
+/* How many profiled calls gtx_profile_read can reach (<= 64) since the last gtx_profile_enable. */
+int gtx_profile_count(gtx_ctx *ctx);
 
 /* Library/ABI version, e.g. 100 = 1.0.0 */
 int gtx_version(void);

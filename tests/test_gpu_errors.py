@@ -108,3 +108,32 @@ def test_permutation_tables_can_be_replaced():
         assert np.array_equal(Y.view(np.uint64), porc.statistic(t, "sum").view(np.uint64))
         np.testing.assert_array_equal(e.count_ge("sum", Y, 5, 0, 130), porc.count_ge(t, "sum", Y, 5, 0, 130))
     e.close()
+
+
+def test_profile_modes(engine):
+    """gtx_profile_enable: 1 = events around every device call (kernel + whole call), N >= 2 = kernel-only events on
+    every N-th call; the counts are the same with and without the instrumentation."""
+    import torch
+    refs = synth.genome_intervals(20_000, 5, 50, 2000)
+    reads = synth.genome_intervals(300_000, 6, 50, 51)
+    engine.set_refs(refs, 24)
+    want = orc.count(refs, reads, algo=orc.SORTED_MERGE)
+    d_reads = torch.from_numpy(reads).cuda()
+    d_hits = torch.zeros(len(refs), dtype=torch.int64, device="cuda")
+    engine.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for mode, calls, expect in ((1, 5, 5), (4, 9, 3), (0, 2, 0)):
+            engine.profile(mode)
+            for _ in range(calls):
+                engine.count_device(d_reads.data_ptr(), len(reads), d_hits.data_ptr())
+            engine.sync()
+            np.testing.assert_array_equal(d_hits.cpu().numpy().view(np.uint64), want)
+            assert engine.profiled_calls() == expect
+            for b in range(expect):
+                k, tot = engine.profile_last(b)
+                assert 0 < k <= tot if mode == 1 else (k > 0 and tot == k)
+            with pytest.raises(gtx.GtxError):
+                engine.profile_last(expect)
+    finally:
+        engine.profile(False)
+        engine.set_stream(0)
