@@ -1213,10 +1213,12 @@ __global__ __launch_bounds__(256) void gather_coverage_kernel(CoverGather g, i64
 // ---------------------------------------------------------------------------------------------
 // previous lane's value (lane 0 keeps its own): DPP wave_shr:1, no LDS traffic
 // micro-window (class, index) of one read, or (-1,-1) when it does not count
-__device__ __forceinline__ void scan_slot(const Tri &t, bool in_range, const ScanArgs &a, int &cls, int &mw)
+// clsU >= 0: the caller knows that every read of the step has class clsU (valid) and passes its micro-window count nmU --
+// a scalar instead of a per-lane table lookup, i.e. no memory round trip between the arrival of the reads and their use
+__device__ __forceinline__ void scan_slot(const Tri &t, bool in_range, const ScanArgs &a, int &cls, int &mw, int clsU = -1, i64 nmU = 0)
 {
   cls = -1; mw = -1;
-  if (in_range && (unsigned)t.c < (unsigned)a.nClasses && (a.sortedRule || (t.s <= t.e && t.e > 0))) {
+  if (in_range && (clsU >= 0 || (unsigned)t.c < (unsigned)a.nClasses) && (a.sortedRule || (t.s <= t.e && t.e > 0))) {
     i64 pos = a.center ? (i64)t.s + ((i64)t.e - t.s) / 2 : (i64)t.s;
     if (a.sortedRule && pos < 1) pos = 1;           // the sorted scanner takes START <= stop of the first window
     if (pos >= 1) {
@@ -1226,7 +1228,7 @@ __device__ __forceinline__ void scan_slot(const Tri &t, bool in_range, const Sca
       unsigned r = x - q * d;
       if (r >= d) { q++; r -= d; }
       if (r >= d) q++;
-      if ((i64)q < a.nMicro[t.c]) { cls = t.c; mw = (int)q; }
+      if ((i64)q < (clsU >= 0 ? nmU : a.nMicro[t.c])) { cls = t.c; mw = (int)q; }
     }
   }
 }
@@ -1254,10 +1256,10 @@ __device__ __forceinline__ void scan_tile_flush(ScanTile &T, const ScanArgs &a, 
 }
 
 template <bool WEIGHTED>
-__device__ __forceinline__ void scan_add64(const Tri &t, int w, bool in_range, const ScanArgs &a, ScanTile &T, int lane)
+__device__ __forceinline__ void scan_add64(const Tri &t, int w, bool in_range, const ScanArgs &a, ScanTile &T, int lane, int clsU = -1, i64 nmU = 0)
 {
   int cls, mw;
-  scan_slot(t, in_range, a, cls, mw);
+  scan_slot(t, in_range, a, cls, mw, clsU, nmU);
   const u64 valid = __ballot(mw >= 0);
   if (valid == 0) return;
   if (WEIGHTED) {                                  // weighted: one atomic per read
@@ -1301,6 +1303,7 @@ __global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ 
   i64 s0 = wave * per, s1 = s0 + per; if (s1 > nSteps) s1 = nSteps;
   ScanTile T; T.lds = tiles[wv]; T.cls = -1; T.base = 0; T.used = false;
   if (!WEIGHTED) for (int k = lane; k < kScanTile; k += 64) T.lds[k] = 0;
+  int cachedCls = -1; i64 cachedNm = 0;
   for (i64 s = s0; s < s1; ++s) {
     const i64 at = s * 64 * R;
     Tri t[R]; int w[R];
@@ -1308,8 +1311,18 @@ __global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ 
       const char *p = (const char *)(reads + at) + (unsigned)lane * 12u;
 #pragma unroll
       for (int r = 0; r < R; ++r) { t[r] = load_tri(p + 768 * r); w[r] = WEIGHTED ? weights[at + 64 * r + lane] : 1; }
+      // one class for the whole step (the rule on sorted reads): its micro-window count comes from a scalar load
+      const int c0 = rdlane(t[0].c, 0);
+      int odd = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) scan_add64<WEIGHTED>(t[r], w[r], true, a, T, lane);
+      for (int r = 0; r < R; ++r) odd |= t[r].c ^ c0;
+      int clsU = -1; i64 nmU = 0;
+      if ((unsigned)c0 < (unsigned)a.nClasses && __ballot(odd != 0) == 0) {
+        if (c0 != cachedCls) { cachedCls = c0; cachedNm = a.nMicro[c0]; }
+        clsU = c0; nmU = cachedNm;
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) scan_add64<WEIGHTED>(t[r], w[r], true, a, T, lane, clsU, nmU);
     } else {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
