@@ -300,11 +300,12 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
   // (10 k regions: 0.28 -> 0.19 ms).  Small batches keep the sums (no extra launch).  GTX_PART_MAX_HIST=0 restores them.
   { static const char *mx = getenv("GTX_PART_MAX_HIST"); const int64_t lim = mx ? atoll(mx) : INT64_MAX;
     if (c->histLen <= lim && nReads >= (1 << 20)) { a.partA = nullptr; a.partB = nullptr; c->tileSumsValid = false; } }
-  // span of one wave: long enough to amortise the two window seeks at its start, short enough that
-  // the grid has ~3 rounds of the 8192 wave slots of the chip (256 CUs x 32 waves; measured flat from 48 to 80
-  // chunks at 100 M reads, 3 % slower at 96)
+  // span of one wave: long enough to amortise the window placement at its start, short enough that the grid has >= 3
+  // rounds of the 8192 wave slots of the chip (256 CUs x 32 waves) and that the waves resident at one time read a
+  // compact piece of the stream (100 M reads: flat from 48 to 64 chunks, +3 % at 96, +12 % at 192 = one round;
+  // 1 G reads: 1.74 ms at 48, 1.76 at 64-96, 1.82 at 128; the bare load pattern behaves the same, scripts/membench.hip)
   int cpw = c->chunksPerWave;
-  if (cpw <= 0) { int64_t nChunks = (nReads + 63) >> 6; cpw = (int)std::min<int64_t>(128, std::max<int64_t>(8, nChunks / 24576)); }
+  if (cpw <= 0) { int64_t nChunks = (nReads + 63) >> 6; cpw = (int)std::min<int64_t>(56, std::max<int64_t>(8, nChunks / 24576)); }
   const int r = std::max(1, std::min(4, c->prefetch));
   a.chunksPerWave = (cpw + r - 1) / r * r;
   a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0; a.prefetch = c->prefetch;
