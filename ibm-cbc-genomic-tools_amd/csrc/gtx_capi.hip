@@ -522,11 +522,11 @@ static int cover_prepare(gtx_ctx *c)
 static gtx::CoverArgs cover_args(gtx_ctx *c, int64_t nReads)
 {
   gtx::CoverArgs a;
-  a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart;
+  a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart; a.topE = c->d_topE; a.topS = c->d_topS;
   for (int q = 0; q < 8; q++) { a.hist[q] = c->d_cov[q]; a.part[q] = c->d_cov[8 + q]; }
   a.info = c->d_info + c->infoCur; a.nClasses = c->nClasses;
   int64_t nChunks = (nReads + 63) >> 6;
-  a.chunksPerWave = (int)std::min<int64_t>(128, std::max<int64_t>(8, nChunks / 16384));
+  a.chunksPerWave = c->chunksPerWave > 0 ? c->chunksPerWave : (int)std::min<int64_t>(56, std::max<int64_t>(8, nChunks / 24576));   // as count_args
   return a;
 }
 

@@ -41,6 +41,7 @@ struct CountArgs {
 //   4 (S-array, key s, w)  5 (S-array, key s, w*s)  6 (S-array, key e, w)  7 (S-array, key e, w*e)
 struct CoverArgs {
   const int *sortedE, *sortedS, *segStart;
+  const int *topE, *topS;          // every 256th boundary (as CountArgs)
   unsigned long long *hist[8], *part[8];
   DevInfo *info;
   int nClasses, chunksPerWave;

@@ -948,6 +948,7 @@ __device__ __forceinline__ void cov_chunk(CovState<WEIGHTED, STRICT> &st, const 
   }
 }
 
+// (5 waves per SIMD at 90 VGPRs; forcing 6-8 with launch bounds + an SGPR cap spills and measured 3-8 % slower)
 template <bool WEIGHTED, bool STRICT>
 __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CoverArgs a)
 {
@@ -978,6 +979,28 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
   // The general code exists once (it is large; two copies of it would not share the instruction cache well).
   const char *base = (const char *)(reads + first) + (size_t)lane * 12;
   int at = 0;
+  if (!WEIGHTED && nMine >= 256) {
+    // the common start (as in count_walk_body): the first step is all of one class with reference regions -- both
+    // windows placed by one paired search instead of two 64-ary searches in a row through the general code
+    Tri t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = load_tri(base + 768 * r);
+    const int c0 = rdlane(t[0].c, 0);
+    bool odd = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) odd |= t[r].c != c0 || t[r].s > t[r].e;
+    if ((unsigned)c0 < (unsigned)a.nClasses && __ballot(odd) == 0) {
+      st.sg.start = rfl(a.segStart[c0]); st.sg.end = rfl(a.segStart[c0 + 1]); st.sg.cls = c0;
+      if (st.sg.start != st.sg.end) {
+        const int ks[4] = {t[0].s, t[1].s, t[2].s, t[3].s}, ke[4] = {t[0].e, t[1].e, t[2].e, t[3].e};
+        const int *top = STRICT ? a.topS : a.topE;
+        int ps, pe;
+        rank_pair(st.sg, st.Ws, top, wave_min(min_of<4>(ks)), st.We, top, wave_min(min_of<4>(ke)), lane, ps, pe);
+        st.Ws.place(st.sg, ps, lane); st.We.place(st.sg, pe, lane);
+        st.vs = st.ve = true;
+      }
+    }
+  }
   while (at < nMine) {
     if (!WEIGHTED && at + 256 <= nMine && st.sg.cls >= 0) {
       Tri t[4];
