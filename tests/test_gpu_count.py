@@ -286,3 +286,29 @@ def test_linearity_at_large_scale(engine):
     rsel = np.nonzero(refs[:, 0] == c)[0]
     want = orc.count(refs[rsel], sub, algo=orc.SORTED_MERGE)
     np.testing.assert_array_equal(whole.cpu().numpy().view(np.uint64)[rsel], want)
+
+
+def test_span_starts_among_equal_boundaries(engine):
+    """Every wave places its two windows with the paired two-hop search (rank_pair) through the every-256th-boundary arrays:
+    long runs of equal boundaries (ties across many samples), a class above 65 k boundaries (strided first hop) and
+    classes smaller than one sample distance must all give the ranks of the plain searches."""
+    rng = np.random.default_rng(17)
+    parts = []
+    for cls, m in ((0, 150_000), (1, 90), (2, 300), (3, 20_000)):
+        s = np.sort(rng.integers(1, 4_000_000, size=m))
+        parts.append(np.stack([np.full(m, cls), s, s + rng.integers(0, 1500, size=m)], axis=1))
+    dup = np.stack([np.zeros(70_000), np.full(70_000, 2_000_000), np.full(70_000, 2_000_010)], axis=1)       # 70 k identical regions
+    dup2 = np.stack([np.full(40_000, 3), np.full(40_000, 1_000_000), 1_000_000 + rng.integers(0, 3, size=40_000)], axis=1)
+    refs = np.concatenate(parts + [dup, dup2]).astype(np.int32)
+    refs = refs[rng.permutation(len(refs))]                                  # file order is not sorted order
+    n = 400_000
+    reads = np.stack([np.sort(rng.integers(0, 4, size=n)), rng.integers(1, 4_000_000, size=n), np.zeros(n, dtype=np.int64)], axis=1)
+    order = np.lexsort((reads[:, 1], reads[:, 0]))
+    reads = reads[order]
+    reads[:, 2] = reads[:, 1] + 49
+    reads = reads.astype(np.int32)
+    engine.set_refs(refs, 4)
+    hits, info = engine.count(reads, None, gtx.READS_SORTED)
+    np.testing.assert_array_equal(hits, orc.count(refs, reads, algo=orc.BIN_INDEX))
+    cov, _ = engine.coverage(reads)
+    np.testing.assert_array_equal(cov, orc.coverage(refs, reads, algo=orc.BIN_INDEX))
