@@ -304,6 +304,7 @@ def main():
     hits_pp = [hits, torch.zeros_like(hits)]
     pending = [None, None]
     pipelined = (world > 1 or force_dist) and os.environ.get("GTX_BENCH_SYNC_REDUCE") != "1"
+    use_allreduce = os.environ.get("GTX_BENCH_ALLREDUCE") == "1"
     step_no = [0]
 
     eng = gtx.Engine(local)
@@ -321,7 +322,12 @@ def main():
             if pending[b] is not None:
                 pending[b].wait()                                          # stream-side wait: buffer b is free again
             eng.count_device(reads.data_ptr(), n, hits_pp[b].data_ptr(), None, flags)
-            pending[b] = dist.all_reduce(hits_pp[b], op=dist.ReduceOp.SUM, async_op=True)
+            # north_star: "an RCCL reduce over xGMI of the per-region count vector" -- rank 0 (the one that would print) gets the
+            # sum; a reduce moves half the bytes of an all-reduce over the ring (GTX_BENCH_ALLREDUCE=1: every rank gets it)
+            if use_allreduce:
+                pending[b] = dist.all_reduce(hits_pp[b], op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                pending[b] = dist.reduce(hits_pp[b], dst=0, op=dist.ReduceOp.SUM, async_op=True)
             return
         eng.count_device(reads.data_ptr(), n, hits.data_ptr(), None, flags)
         if world > 1:
@@ -446,8 +452,9 @@ def main():
             "config": {"workload": "BASELINE config 3: %d 50bp reads/GPU sorted by (chrom,start) x %d ref intervals over 24 hg38 "
                                    "chromosomes, strand ignored (genomic_overlaps count -S -i); reads resident in HBM" % (n, len(refs)),
                        "reads_per_gpu": n, "refs": len(refs),
-                       "parallelism": "chromosome shards (LPT) x%d, all-reduce(sum) of the uint64 count vector%s"
-                                      % (world, " overlapped with the next step" if pipelined else "")},
+                       "parallelism": "chromosome shards (LPT) x%d, RCCL %s of the uint64 count vector%s"
+                                      % (world, "reduce(sum) to rank 0" if pipelined and not use_allreduce else "all-reduce(sum)",
+                                         " overlapped with the next step" if pipelined else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "count_walk_kernel", "kernel_ms": kernel_ms, "kernel_samples": len(k_ms), "algorithmic_bytes": alg_bytes},
