@@ -8,6 +8,10 @@ for a, b in (("bench_line", "bench_line"), ("bench_scans_line", "bench_scans_lin
              ("bench_line_under_rocprof", "bench_line_under_rocprof"), ("bench_line_two_streams", "bench_line_two_streams")):
     shutil.copy(src + a + ".json", R + "profiles/%s_%s.json" % (rnd, b))
 shutil.copy(glob.glob(src + "stats/*/*kernel_stats.csv")[0], R + "profiles/%s_bench_kernel_stats.csv" % rnd)
+for w in ("scans", "perm"):
+    g = glob.glob(src + "stats_%s/*/*kernel_stats.csv" % w)
+    if g:
+        shutil.copy(g[0], R + "profiles/%s_bench_%s_kernel_stats.csv" % (rnd, w))
 lines, keep = [], False
 for l in open(src + "pmc_summary.txt"):
     if l.startswith("=="):
