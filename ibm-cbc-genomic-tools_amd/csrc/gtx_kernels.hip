@@ -537,6 +537,65 @@ __device__ __forceinline__ bool walk_flip4(WIN &X, const Seg &sg, const int (&k)
   }
 }
 
+// Weighted reads (label values): the all-boundaries-at-once step with the weights' exclusive prefix sums next to the keys
+// (as cov_step4_run does for the key sums).  The caller has checked that the keys are non-decreasing over the 256 reads and
+// that |weight| < 2^22 (so the prefix sums of a step fit 32 bits), and has stored the prefix sums in ldsP[0..256].
+__device__ __forceinline__ bool keys_ordered4(const int (&k)[4], int lane)
+{
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int prev = lane_prev(k[r]);
+    if (r > 0) { const int last = rdlane(k[r - 1], 63); prev = lane == 0 ? last : prev; }
+    bad |= k[r] < prev;
+  }
+  return __ballot(bad) == 0;
+}
+
+template <class WIN>
+__device__ __forceinline__ void walk_flipw4(WIN &X, const Seg &sg, const int (&k)[4], int total, int lane, bool &valid,
+                                            int *ldsK, const int *ldsP)
+{
+  if (__ballot(WIN::below(max_of4(k), X.curW)) == ~0ull) { X.pend += total; return; }   // no boundary crossed
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ldsK[64 * r + lane] = k[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  X.deposit(lane);                                               // what is pending belongs to the slot we are about to leave
+  int adv = 0;
+  for (;;) {
+    const int bnd = X.W;
+    int cnt = 0;
+#pragma unroll
+    for (int half = 128; half >= 1; half >>= 1) cnt += WIN::below(ldsK[cnt + half - 1], bnd) ? half : 0;
+    cnt += WIN::below(ldsK[cnt], bnd) ? 1 : 0;                   // 0..256 keys at or below this lane's boundary
+    const int sum = ldsP[cnt];                                   // their weight
+    X.acc += sum - lane_prev(sum);                               // lane 0 differs from itself: 0
+    const int top = rdlane(cnt, 63);
+    if (top == 256) {
+      const int first = __ffsll((unsigned long long)__ballot(cnt == 256)) - 1;
+      X.j = first - 1; X.prevW = rdlane(X.W, first - 1); X.curW = rdlane(X.W, first);
+      return;
+    }
+    // keys beyond the window: publish it and slide (lane 0 of the new window holds the old lane 63, so the differences keep working)
+    if (__ballot(X.acc != 0)) X.flush_acc(sg, lane);
+    X.base += kSlots; X.j = 0;
+    X.W = X.Wn; X.Wn = X.load_window(sg, X.base + kSlots, lane);
+    X.prevW = rdlane(X.W, 0); X.curW = rdlane(X.W, 1);
+    if (++adv > 2) {
+      valid = false;                                             // acc is empty and nothing is pending
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) {                              // the keys not yet placed add themselves (key and weight back from LDS)
+        const int e = 64 * r + lane, kr = ldsK[e], wr = ldsP[e + 1] - ldsP[e];
+        const u64 m = __ballot(e >= top);
+        if (m) X.lanes_add(sg, kr, wr, m, lane);
+      }
+      return;
+    }
+  }
+}
+
 template <int R>
 __device__ __forceinline__ int min_of(const int (&k)[R]) { int m = k[0];
 #pragma unroll
@@ -627,6 +686,7 @@ template <bool WEIGHTED, int R, bool FLIP>
 __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, const CountArgs &a)
 {
   __shared__ int ldsK[FLIP ? 8 : 1][FLIP ? 256 : 1];           // per wave: the keys of a step (walk_flip4)
+  __shared__ int ldsP[(FLIP && WEIGHTED) ? 8 : 1][(FLIP && WEIGHTED) ? 264 : 1];   // and the prefix sums of their weights (walk_flipw4)
   const int wid = rfl(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + rfl(threadIdx.x >> 6);
@@ -650,16 +710,17 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
   const char *base = (const char *)(reads + first);            // wave-uniform
   const int *wbase = WEIGHTED ? weights + first : nullptr;
   const unsigned loff = (unsigned)lane * 12u;
-  const bool fastOk = !WEIGHTED && !a.checkSorted;
+  const bool fastOk = !a.checkSorted && (!WEIGHTED || (R == 4 && FLIP));
   const int zl = a.zeroLenOk;
 
   int s = 0;
   Tri t[R];
-  bool have = false;                                           // t holds step s
+  int tw[WEIGHTED ? R : 1];                                    // the weights of step s (weighted fast path)
+  bool have = false;                                           // t (and tw) hold step s
   if (fastOk && nFull > 0) {
     // the common start: the first step is all of one class with reference regions -- place both windows at once
 #pragma unroll
-    for (int r = 0; r < R; ++r) t[r] = load_tri(base + 768 * r + loff);
+    for (int r = 0; r < R; ++r) { t[r] = load_tri(base + 768 * r + loff); if constexpr (WEIGHTED) tw[r] = wbase[64 * r + lane]; }
     have = true;
     const int c0 = rdlane(t[0].c, 0);
     int odd = 0, dg = 0, ks[R], ke[R];
@@ -695,7 +756,19 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
         // dg < 0 in some lane <=> some read has start > end (+zl)
         const int kmin = min_of<R>(ks), emin = min_of<R>(ke);
         if (__ballot((odd != 0) | (dg < 0) | (kmin <= st.A.prevW) | (emin < st.B.prevW))) return false;
-        if constexpr (!WEIGHTED && R == 4 && FLIP) {
+        if constexpr (WEIGHTED && R == 4 && FLIP) {
+          // weighted step: ordered keys and small weights, else the general path takes it
+          bool big = false;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) big |= (unsigned)(tw[r] + (1 << 22)) >= (1u << 23);
+          if (__ballot(big) || !keys_ordered4(ks, lane) || !keys_ordered4(ke, lane)) return false;
+          int run = 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int p = wave_scan_add(tw[r]); ldsP[wid][64 * r + lane] = run + p - tw[r]; run += rdlane(p, 63); }
+          if (lane == 0) ldsP[wid][256] = run;
+          walk_flipw4(st.A, st.sg, ks, run, lane, st.validA, ldsK[wid], ldsP[wid]);
+          walk_flipw4(st.B, st.sg, ke, run, lane, st.validB, ldsK[wid], ldsP[wid]);
+        } else if constexpr (!WEIGHTED && R == 4 && FLIP) {
           if (!walk_flip4(st.A, st.sg, ks, lane, st.validA, ldsK[wid])) walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
           if (!walk_flip4(st.B, st.sg, ke, lane, st.validB, ldsK[wid])) walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
         } else if constexpr (!WEIGHTED) {
@@ -707,7 +780,7 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
       auto load_step = [&](Tri (&tt)[R], int step) {
         const char *p = base + (size_t)step * (768 * R) + loff;
 #pragma unroll
-        for (int r = 0; r < R; ++r) tt[r] = load_tri(p + 768 * r);
+        for (int r = 0; r < R; ++r) { tt[r] = load_tri(p + 768 * r); if constexpr (WEIGHTED) tw[r] = wbase[(size_t)step * (64 * R) + 64 * r + lane]; }
       };
       while (s < nFull) {
         if (!have) load_step(t, s);
@@ -760,6 +833,11 @@ template <bool WEIGHTED, int R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void count_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
 {
   count_walk_body<WEIGHTED, R, false>(reads, weights, n, a);
+}
+// weighted reads: steps of 4 x 64 with the weights' prefix sums in LDS (walk_flipw4); the general code takes what does not qualify
+__global__ __launch_bounds__(256) void count_walk_kernel_weighted(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
+{
+  count_walk_body<true, 4, true>(reads, weights, n, a);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void count_walk_kernel_flip(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
 {
@@ -1421,7 +1499,9 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
     const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
     const unsigned bs = 64u * wpb;
     // a.prefetch = reads per lane per step (R)
-    if (weights) count_walk_kernel<true, 2><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    static const bool wfast = !(getenv("GTX_WEIGHTED_FAST") && atoi(getenv("GTX_WEIGHTED_FAST")) == 0);
+    if (weights && wfast && a.chunksPerWave % 4 == 0) count_walk_kernel_weighted<<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (weights) count_walk_kernel<true, 2><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.prefetch <= 1) count_walk_kernel<false, 1><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.prefetch == 2) count_walk_kernel<false, 2><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.prefetch == 3) count_walk_kernel<false, 3><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);

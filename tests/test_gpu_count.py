@@ -312,3 +312,25 @@ def test_span_starts_among_equal_boundaries(engine):
     np.testing.assert_array_equal(hits, orc.count(refs, reads, algo=orc.BIN_INDEX))
     cov, _ = engine.coverage(reads)
     np.testing.assert_array_equal(cov, orc.coverage(refs, reads, algo=orc.BIN_INDEX))
+
+
+def test_weighted_fast_path_and_its_fallbacks(engine):
+    """Weighted sorted reads go in steps of 256 with the weights' prefix sums in LDS when the keys are ordered and the
+    weights are small; anything else (huge label values, read ends out of order, class changes) takes the general code.
+    All mixes must give the oracle's counts; dense references make a step cross many boundaries and whole windows."""
+    rng = np.random.default_rng(23)
+    for m, lens, wkind in ((40_000, (50, 51), "small"), (600_000, (50, 51), "small"), (40_000, (20, 3000), "small"),
+                           (40_000, (50, 51), "mixed"), (600_000, (30, 400), "signed")):
+        refs = synth.genome_intervals(m, 31 + m % 5, 50, 2000)
+        reads = synth.genome_intervals(500_000, 32, lens[0], lens[1])
+        n = len(reads)
+        if wkind == "small":
+            w = rng.integers(0, 100, size=n)
+        elif wkind == "signed":
+            w = rng.integers(-1000, 1000, size=n)
+        else:
+            w = rng.integers(0, 50, size=n)
+            big = rng.integers(0, n, size=200)
+            w[big] = rng.integers(1 << 22, (1 << 31) - 1, size=200)            # steps holding one of these fall back
+            w[rng.integers(0, n, size=50)] = -(1 << 30)
+        check(engine, refs, reads, w.astype(np.int32), n_classes=synth.n_classes())
