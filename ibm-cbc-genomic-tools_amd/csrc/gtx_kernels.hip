@@ -710,7 +710,7 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
   const char *base = (const char *)(reads + first);            // wave-uniform
   const int *wbase = WEIGHTED ? weights + first : nullptr;
   const unsigned loff = (unsigned)lane * 12u;
-  const bool fastOk = !a.checkSorted && (!WEIGHTED || (R == 4 && FLIP));
+  const bool fastOk = (!a.checkSorted || R == 4) && (!WEIGHTED || (R == 4 && FLIP));
   const int zl = a.zeroLenOk;
 
   int s = 0;
@@ -756,6 +756,14 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
         // dg < 0 in some lane <=> some read has start > end (+zl)
         const int kmin = min_of<R>(ks), emin = min_of<R>(ke);
         if (__ballot((odd != 0) | (dg < 0) | (kmin <= st.A.prevW) | (emin < st.B.prevW))) return false;
+        if constexpr (R == 4) {
+          if (a.checkSorted) {
+            // GTX_CHECK_SORTED: a step in (class, start) order behind the previous read is consumed here; the first
+            // violation is found -- and reported with its index -- by the general code
+            const int cc = st.sg.cls >> a.sortClassShift, k0 = rdlane(ks[0], 0);
+            if (cc < st.pc || (cc == st.pc && k0 < st.ps) || !keys_ordered4(ks, lane)) return false;
+          }
+        }
         if constexpr (WEIGHTED && R == 4 && FLIP) {
           // weighted step: ordered keys and small weights, else the general path takes it
           bool big = false;
@@ -774,6 +782,9 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
         } else if constexpr (!WEIGHTED) {
           walk_fast<R>(st.A, st.sg, ks, max_of<R>(ks), lane, st.validA);
           walk_fast<R>(st.B, st.sg, ke, max_of<R>(ke), lane, st.validB);
+        }
+        if constexpr (R == 4) {
+          if (a.checkSorted) { st.pc = st.sg.cls >> a.sortClassShift; st.ps = rdlane(ks[3], 63); }   // the step is consumed: it is the previous read now
         }
         return true;
       };

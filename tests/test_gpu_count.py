@@ -179,6 +179,20 @@ def test_sort_check(engine):
         bad[7001, 1] -= 1
     _, info = engine.count(bad, None, gtx.READS_SORTED | gtx.CHECK_SORTED)
     assert info["first_unsorted"] == 7001
+    # the streaming fast path checks whole steps of 256 reads: violations inside a step, at a step seam, at a seam between
+    # two waves' spans (512 reads each at this size) and in the partial last step, with and without weights
+    w = np.ones(len(reads), dtype=np.int32)
+    for at in (1, 100, 255, 256, 511, 512, 513, 4095, 4096, 9990, 9999):
+        bad = reads.copy()
+        bad[[at - 1, at]] = bad[[at, at - 1]]
+        if bad[at - 1, 1] == bad[at, 1]:
+            bad[at, 1] -= 1
+        for ww in (None, w):
+            hits, info = engine.count(bad, ww, gtx.READS_SORTED | gtx.CHECK_SORTED)
+            assert info["first_unsorted"] == at
+            np.testing.assert_array_equal(hits, orc.count(refs, bad, algo=orc.BIN_INDEX))
+        hits, info = engine.count(reads, w, gtx.READS_SORTED | gtx.CHECK_SORTED)
+        assert info["first_unsorted"] == -1
 
 
 def test_device_entry_matches_host_entry(engine):
