@@ -1351,16 +1351,19 @@ __device__ __forceinline__ void scan_slot(const Tri &t, bool in_range, const Sca
 // i.e. whole 64-byte requests at the memory side instead of one request per read.
 static constexpr int kScanTile = 1024;
 
-struct ScanTile { unsigned *lds; int cls, base; bool used; };
-
 // (unweighted scans count in 32 bits -- at most n_reads < 2^32 per micro-window -- which halves the
-//  atomic, memset and window-sum traffic; weighted scans keep the reference's 64-bit counters)
-__device__ __forceinline__ void scan_tile_flush(ScanTile &T, const ScanArgs &a, int lane)
+//  atomic, memset and window-sum traffic; weighted scans keep the reference's 64-bit counters, in the tile too)
+template <bool WEIGHTED>
+struct ScanTile { typedef typename std::conditional<WEIGHTED, u64, unsigned>::type ct; ct *lds; int cls, base; bool used; };
+
+template <bool WEIGHTED>
+__device__ __forceinline__ void scan_tile_flush(ScanTile<WEIGHTED> &T, const ScanArgs &a, int lane)
 {
+  typedef typename ScanTile<WEIGHTED>::ct ct;
   if (!T.used) return;
-  unsigned *dst = (unsigned *)a.micro + a.microOff[T.cls] + T.base;
+  ct *dst = (ct *)a.micro + a.microOff[T.cls] + T.base;
   for (int k = 0; k < kScanTile; k += 64) {
-    unsigned v = T.lds[k + lane];
+    ct v = T.lds[k + lane];
     if (__ballot(v != 0) == 0) continue;
     if (v != 0) { atomicAdd(&dst[k + lane], v); T.lds[k + lane] = 0; }
   }
@@ -1368,16 +1371,12 @@ __device__ __forceinline__ void scan_tile_flush(ScanTile &T, const ScanArgs &a, 
 }
 
 template <bool WEIGHTED>
-__device__ __forceinline__ void scan_add64(const Tri &t, int w, bool in_range, const ScanArgs &a, ScanTile &T, int lane, int clsU = -1, i64 nmU = 0)
+__device__ __forceinline__ void scan_add64(const Tri &t, int w, bool in_range, const ScanArgs &a, ScanTile<WEIGHTED> &T, int lane, int clsU = -1, i64 nmU = 0)
 {
   int cls, mw;
   scan_slot(t, in_range, a, cls, mw, clsU, nmU);
   const u64 valid = __ballot(mw >= 0);
   if (valid == 0) return;
-  if (WEIGHTED) {                                  // weighted: one atomic per read
-    if (mw >= 0) atomicAdd(&a.micro[a.microOff[cls] + mw], (u64)(i64)w);
-    return;
-  }
   // keep the tile where the reads are: if the first counting read of this register is outside, move the tile there
   const int f = __ffsll((unsigned long long)valid) - 1;
   const int fc = rdlane(cls, f), fm = rdlane(mw, f);
@@ -1386,6 +1385,12 @@ __device__ __forceinline__ void scan_add64(const Tri &t, int w, bool in_range, c
     T.cls = fc; T.base = fm; T.used = true;
   }
   const bool inTile = mw >= 0 && cls == T.cls && (unsigned)(mw - T.base) < (unsigned)kScanTile;
+  if constexpr (WEIGHTED) {
+    // weighted: every read adds its weight -- to the tile (64-bit LDS atomic) or, outside it, straight to HBM
+    if (inTile) atomicAdd(&T.lds[mw - T.base], (u64)(i64)w);
+    else if (mw >= 0) atomicAdd(&a.micro[a.microOff[cls] + mw], (u64)(i64)w);
+    return;
+  }
   // runs of equal slots in neighbouring lanes: the first lane of a run adds the run length
   const int key = inTile ? mw : -1 - lane;         // lanes outside the tile never join a run
   const int pk = lane_prev(key);                   // (all lanes active here: DPP must not run under a partial exec mask)
@@ -1405,7 +1410,7 @@ template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, ScanArgs a)
 {
   constexpr int R = 4;
-  __shared__ unsigned tiles[4][kScanTile];
+  __shared__ typename ScanTile<WEIGHTED>::ct tiles[4][kScanTile];
   const int lane = threadIdx.x & 63;
   const int wv = rfl(threadIdx.x >> 6);
   const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + wv;
@@ -1413,8 +1418,8 @@ __global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ 
   const i64 nSteps = (n + 64 * R - 1) / (64 * R);
   const i64 per = (nSteps + nWaves - 1) / nWaves;
   i64 s0 = wave * per, s1 = s0 + per; if (s1 > nSteps) s1 = nSteps;
-  ScanTile T; T.lds = tiles[wv]; T.cls = -1; T.base = 0; T.used = false;
-  if (!WEIGHTED) for (int k = lane; k < kScanTile; k += 64) T.lds[k] = 0;
+  ScanTile<WEIGHTED> T; T.lds = tiles[wv]; T.cls = -1; T.base = 0; T.used = false;
+  for (int k = lane; k < kScanTile; k += 64) T.lds[k] = 0;
   int cachedCls = -1; i64 cachedNm = 0;
   for (i64 s = s0; s < s1; ++s) {
     const i64 at = s * 64 * R;

@@ -46,6 +46,20 @@ def test_scan_unsorted_input_and_weights(engine):
     np.testing.assert_array_equal(got, want)
 
 
+def test_scan_sorted_weighted_uses_the_lds_tile(engine):
+    """Weighted sorted reads: the 64-bit per-wave LDS tile follows the reads; large and negative label values wrap in 64 bits
+    like the reference's unsigned long; fine and coarse window steps; reads of several classes."""
+    rng = np.random.default_rng(47)
+    reads = reads_scaled(300000, 47)
+    reads = reads[np.lexsort((reads[:, 1], reads[:, 0]))]
+    for w in (rng.integers(0, 5, size=len(reads)), rng.integers(-(1 << 31), (1 << 31) - 1, size=len(reads))):
+        w = w.astype(np.int32)
+        for step, size, prep in ((200, 1000, "1"), (25, 500, "c"), (5000, 5000, "1")):
+            got, _ = engine.scan(reads, LENS, step, size, prep, weights=w)
+            want, _ = orc.scan(reads, LENS, step, size, prep, weights=w, algo=0)
+            np.testing.assert_array_equal(got, want)
+
+
 def test_scan_edges(engine):
     # reads beyond the last whole micro-window, class without windows, unknown class, invalid reads
     lens = np.array([10000, 2500, 700], dtype=np.int32)
