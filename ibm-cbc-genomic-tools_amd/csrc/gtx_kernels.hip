@@ -14,22 +14,24 @@
 // and  hits[k] = prefix(HA)[posE(k)] - prefix(HB)[posS(k)].  Integer adds commute, so any
 // execution order is bit-exact.
 //
-// The streaming kernel (count_walk_kernel) is wave-autonomous -- no LDS, no barriers: a wave64 owns
-// a contiguous span of reads and takes them 4 x 64 at a time (register r of lane l = read 64r+l of
-// the step: four coalesced non-temporal 768-byte requests).  The sorted boundaries of the class it is
-// in live in a 63-slot window in ONE VGPR across the wave (next window prefetched).  For a boundary W
-// (wave-uniform, v_readlane) the number of keys of the step at or below it is
-// popcount(ballot(key <= W)): per boundary crossed a handful of compares and scalar popcounts (a
-// hand-scheduled 27-instruction loop), nothing per read; a step that crosses no boundary costs two
-// compares per array.  Sorted input crosses ~2M/(N/256) boundaries per step, so the kernel is bound by
-// the HBM read of the triples first and by scalar-ALU issue second.  Any input
-// order is handled exactly (backward walk, re-seek by wave-cooperative 64-ary search, lanes that add
-// themselves by binary search); only the speed depends on the order.
+// The streaming kernel (count_walk_kernel) is wave-autonomous -- no barriers, LDS only in the variants named below: a
+// wave64 owns a contiguous span of reads (<= 56 x 64) and takes them 4 x 64 at a time (register r of lane l = read
+// 64r+l of the step: four coalesced non-temporal 768-byte requests).  The sorted boundaries of the class it is in live
+// in a 63-slot window in ONE VGPR across the wave (next window prefetched).  For a boundary W (wave-uniform,
+// v_readlane) the number of keys of the step at or below it is popcount(ballot(key <= W)): per boundary crossed a
+// handful of compares and scalar popcounts (a hand-scheduled 24-instruction loop), nothing per read; a step that
+// crosses no boundary costs two compares per array.  A span starts with ONE paired search for both windows through the
+// every-256th-boundary arrays (rank_pair).  80 SGPRs / 58 VGPRs: 8 waves per SIMD.  The kernel is bound by the HBM
+// read of the triples (DESIGN.md section 7 lists what else was in the way).  Any input order is handled exactly
+// (backward walk, re-seek by wave-cooperative 64-ary search, lanes that add themselves by binary search); only the
+// speed depends on the order.  Variants: count_walk_kernel_flip (dense references: all boundaries of a window at once,
+// the keys of a step in wave-private LDS), count_walk_kernel_weighted (label weights: the same with the weights'
+// prefix sums next to the keys).
 // No MFMA anywhere: this is integer indexing, not a contraction.
 //
-// Kernels in this file: count_walk_kernel (dominant), count_search_kernel (order-agnostic, small batches; large
-// unsorted batches take the bucket path of gtx_bucket.hip), coverage_walk_kernel (CalcIndexCoverage, one launch
-// per boundary array), tile_sums/finalize_scan/gather_hits/gather_coverage (prefix + gather), scan_hist_kernel +
+// Kernels in this file: count_walk_kernel (dominant) and its two variants, count_search_kernel (order-agnostic, small
+// batches; large unsorted batches take the bucket path of gtx_bucket.hip), coverage_walk_kernel (CalcIndexCoverage, one
+// launch per boundary array), tile_sums/finalize_scan/gather_hits/gather_coverage (prefix + gather), scan_hist_kernel +
 // scan_window_kernel (genomic_scans counts).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
