@@ -525,6 +525,7 @@ static gtx::CoverArgs cover_args(gtx_ctx *c, int64_t nReads)
   a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart; a.topE = c->d_topE; a.topS = c->d_topS;
   for (int q = 0; q < 8; q++) { a.hist[q] = c->d_cov[q]; a.part[q] = c->d_cov[8 + q]; }
   a.info = c->d_info + c->infoCur; a.nClasses = c->nClasses;
+  { static const bool wf = !(getenv("GTX_WEIGHTED_FAST") && atoi(getenv("GTX_WEIGHTED_FAST")) == 0); a.wfast = wf ? 1 : 0; }
   int64_t nChunks = (nReads + 63) >> 6;
   a.chunksPerWave = c->chunksPerWave > 0 ? c->chunksPerWave : (int)std::min<int64_t>(56, std::max<int64_t>(8, nChunks / 24576));   // as count_args
   return a;

@@ -45,6 +45,7 @@ struct CoverArgs {
   unsigned long long *hist[8], *part[8];
   DevInfo *info;
   int nClasses, chunksPerWave;
+  int wfast;                       // weighted reads: steps of 4 x 64 with prefix sums in LDS (0: general per-chunk code only)
 };
 
 struct CoverGather {

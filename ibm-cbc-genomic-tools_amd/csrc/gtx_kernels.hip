@@ -925,6 +925,69 @@ __device__ __forceinline__ bool cov_step4_ok(const WIN &X, const int (&k)[4], in
 // that position (sum); slot L-1 then receives cnt[L] - cnt[L-1] keys and sum[L] - sum[L-1] of key value (DPP lane
 // differences).  The cost does not depend on how many boundaries the step crosses -- the per-boundary loop this
 // replaces cost ~60 instructions per crossing.  A step that runs past the window publishes it, slides and repeats.
+__device__ __forceinline__ i64 rd64(i64 v, int l) { return (i64)(((u64)(unsigned)rdlane((int)((u64)v >> 32), l) << 32) | (unsigned)rdlane((int)(unsigned)(u64)v, l)); }
+__device__ __forceinline__ i64 prev64(i64 v) { return (i64)(((u64)(unsigned)lane_prev((int)((u64)v >> 32)) << 32) | (unsigned)lane_prev((int)(unsigned)(u64)v)); }
+
+// The same step for weighted reads: what a slot receives is the weight and the weight x key of its keys, so the LDS holds the
+// exclusive prefix sums of w (ldsW, stored once per step by the caller: both windows of a launch share it) and of
+// w x (key - kbase) (ldsWK, per window), in 64 bits -- no bound on the label values.
+template <class WIN>
+__device__ __forceinline__ void cov_step4_run_w(WIN &X, const Seg &sg, const int (&k)[4], const int (&w)[4], i64 totalW, int lane, bool &valid,
+                                                int *ldsK, const i64 *ldsW, i64 *ldsWK)
+{
+  const int kbase = rdlane(k[0], 0);
+  i64 run = 0;                                                   // sum of w x relative key of the registers below
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const i64 v = (i64)w[r] * (k[r] - kbase), p = (i64)wave_scan_add64((u64)v);
+    ldsK[64 * r + lane] = k[r];
+    ldsWK[64 * r + lane] = run + p - v;                          // exclusive prefix over all reads before this one
+    run += rd64(p, 63);
+  }
+  if (WIN::below(rdlane(k[3], 63), X.curW)) {                    // the whole step stays in the current slot
+    X.pend += totalW;
+    X.pend2 += (i64)kbase * totalW + run;
+    return;
+  }
+  if (lane == 0) ldsWK[256] = run;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  X.deposit(lane);                                               // what is pending belongs to the slot we are about to leave
+  int adv = 0;
+  for (;;) {
+    const int bnd = X.W;
+    int cnt = 0;
+#pragma unroll
+    for (int half = 128; half >= 1; half >>= 1) cnt += WIN::below(ldsK[cnt + half - 1], bnd) ? half : 0;
+    cnt += WIN::below(ldsK[cnt], bnd) ? 1 : 0;                   // 0..256 keys at or below this lane's boundary
+    const i64 sw = ldsW[cnt], swk = ldsWK[cnt];
+    const i64 dw = sw - prev64(sw), dwk = swk - prev64(swk);     // lane 0 differs from itself: 0
+    X.acc += dw;
+    X.acc2 += (i64)kbase * dw + dwk;
+    const int top = rdlane(cnt, 63);
+    if (top == 256) {
+      const int first = __ffsll((unsigned long long)__ballot(cnt == 256)) - 1;
+      X.j = first - 1; X.prevW = rdlane(X.W, first - 1); X.curW = rdlane(X.W, first);
+      return;
+    }
+    if (__ballot(X.acc != 0 || X.acc2 != 0)) X.flush_acc(sg, lane);
+    X.base += kSlots; X.j = 0;
+    X.W = X.Wn; X.Wn = X.load_window(sg, X.base + kSlots, lane);
+    X.prevW = rdlane(X.W, 0); X.curW = rdlane(X.W, 1);
+    if (++adv > 2) {
+      valid = false;                                             // acc is empty and nothing is pending
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) {                              // the keys not yet placed add themselves (key and weight back from LDS)
+        const int e = 64 * r + lane, kr = ldsK[e], wr = (int)(ldsW[e + 1] - ldsW[e]);
+        const u64 m = __ballot(e >= top);
+        if (m) X.lanes_add(sg, kr, wr, m, lane);
+      }
+      return;
+    }
+  }
+}
+
 template <class WIN>
 __device__ __forceinline__ void cov_step4_run(WIN &X, const Seg &sg, const int (&k)[4], int lane, bool &valid, int *ldsK, int *ldsP)
 {
@@ -1050,7 +1113,8 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
   i64 cnt = n - first; if (cnt > (i64)a.chunksPerWave * 64) cnt = (i64)a.chunksPerWave * 64;
   const int nMine = (int)cnt;
 
-  __shared__ int ldsK[4][256], ldsP[4][264];                     // per wave: the keys of a step and their prefix sums
+  __shared__ int ldsK[4][256], ldsP[WEIGHTED ? 1 : 4][WEIGHTED ? 1 : 264];   // per wave: the keys of a step and their prefix sums
+  __shared__ i64 ldsW[WEIGHTED ? 4 : 1][WEIGHTED ? 264 : 1], ldsWK[WEIGHTED ? 4 : 1][WEIGHTED ? 264 : 1];   // weighted: prefix sums of w and of w x key
   const int wid = rfl(threadIdx.x >> 6);
   CovState<WEIGHTED, STRICT> st;
   constexpr int h0 = STRICT ? 4 : 0;                              // histograms 0..3 belong to the ends array, 4..7 to the starts array
@@ -1070,7 +1134,7 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
   // The general code exists once (it is large; two copies of it would not share the instruction cache well).
   const char *base = (const char *)(reads + first) + (size_t)lane * 12;
   int at = 0;
-  if (!WEIGHTED && nMine >= 256) {
+  if ((!WEIGHTED || a.wfast) && nMine >= 256) {
     // the common start (as in count_walk_body): the first step is all of one class with reference regions -- both
     // windows placed by one paired search instead of two 64-ary searches in a row through the general code
     Tri t[4];
@@ -1093,11 +1157,11 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
     }
   }
   while (at < nMine) {
-    if (!WEIGHTED && at + 256 <= nMine && st.sg.cls >= 0) {
-      Tri t[4];
+    if ((!WEIGHTED || a.wfast) && at + 256 <= nMine && st.sg.cls >= 0) {
+      Tri t[4]; int w4[4];
       const char *p = base + (size_t)at * 12;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) t[r] = load_tri(p + 768 * r);
+      for (int r = 0; r < 4; ++r) { t[r] = load_tri(p + 768 * r); w4[r] = WEIGHTED ? weights[first + at + 64 * r + lane] : 1; }
       bool odd = false;
 #pragma unroll
       for (int r = 0; r < 4; ++r) odd |= t[r].c != st.sg.cls || t[r].s > t[r].e;
@@ -1105,8 +1169,17 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
         if (st.sg.start == st.sg.end) { at += 256; continue; }    // a class without reference regions
         const int ks[4] = {t[0].s, t[1].s, t[2].s, t[3].s}, ke[4] = {t[0].e, t[1].e, t[2].e, t[3].e};
         if (cov_step4_ok(st.Ws, ks, lane, st.vs) && cov_step4_ok(st.We, ke, lane, st.ve)) {
-          cov_step4_run(st.Ws, st.sg, ks, lane, st.vs, ldsK[wid], ldsP[wid]);
-          cov_step4_run(st.We, st.sg, ke, lane, st.ve, ldsK[wid], ldsP[wid]);
+          if constexpr (WEIGHTED) {
+            i64 runW = 0;                                          // prefix sums of the weights: once per step, for both windows
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const i64 v = w4[r], pw = (i64)wave_scan_add64((u64)v); ldsW[wid][64 * r + lane] = runW + pw - v; runW += rd64(pw, 63); }
+            if (lane == 0) ldsW[wid][256] = runW;
+            cov_step4_run_w(st.Ws, st.sg, ks, w4, runW, lane, st.vs, ldsK[wid], ldsW[wid], ldsWK[wid]);
+            cov_step4_run_w(st.We, st.sg, ke, w4, runW, lane, st.ve, ldsK[wid], ldsW[wid], ldsWK[wid]);
+          } else {
+            cov_step4_run(st.Ws, st.sg, ks, lane, st.vs, ldsK[wid], ldsP[wid]);
+            cov_step4_run(st.We, st.sg, ke, lane, st.ve, ldsK[wid], ldsP[wid]);
+          }
           at += 256;
           continue;
         }

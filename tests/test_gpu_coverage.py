@@ -64,3 +64,17 @@ def test_count_and_coverage_interleave(engine):
     np.testing.assert_array_equal(v1, v2)
     np.testing.assert_array_equal(c1, orc.count(refs, reads))
     np.testing.assert_array_equal(v1, orc.coverage(refs, reads))
+
+
+def test_weighted_sorted_reads_step_path_and_fallbacks(engine):
+    """Weighted sorted reads take steps of 256 with the prefix sums of w and w x key in LDS (64 bits: any label value);
+    variable read lengths break the order of the ends (general code for those steps); dense regions make a step cross windows."""
+    rng = np.random.default_rng(71)
+    for m, lens, wkind in ((30_000, (50, 51), "small"), (500_000, (50, 51), "small"), (30_000, (20, 2500), "small"),
+                           (30_000, (50, 51), "huge"), (500_000, (36, 37), "signed")):
+        refs = synth.genome_intervals(m, 70 + m % 3, 50, 2000)
+        reads = synth.genome_intervals(400_000, 72, lens[0], lens[1])
+        n = len(reads)
+        w = {"small": rng.integers(0, 100, size=n), "signed": rng.integers(-1000, 1000, size=n),
+             "huge": rng.integers(-(1 << 31), (1 << 31) - 1, size=n)}[wkind].astype(np.int32)
+        check(engine, refs, reads, w, n_classes=synth.n_classes())
