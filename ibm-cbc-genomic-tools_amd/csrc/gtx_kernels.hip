@@ -1533,12 +1533,12 @@ __global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ 
 // then slides over kWinPer consecutive windows (first sum, then +new -old).
 static constexpr int kWinPer = 8;
 static constexpr int kWinTile = 256 * kWinPer;
-static constexpr int kWinMaxComb = 2048;           // LDS: (kWinTile + kWinMaxComb) * 8 B = 32 KB
+static constexpr int kWinMaxComb = 2048;           // LDS: (kWinTile + kWinMaxComb) * 9/8 * 8 B = 36 KB
 
 template <class MT>
 __global__ __launch_bounds__(256) void scan_window_kernel(const MT *__restrict__ micro, ScanArgs a, u64 *__restrict__ out)
 {
-  __shared__ u64 lds[kWinTile + kWinMaxComb];
+  __shared__ u64 lds[(kWinTile + kWinMaxComb) / 8 * 9 + 8];
   // class of this tile (tileOff is a prefix over classes; few dozen entries)
   int c = 0;
   while (c + 1 < a.nClasses && (i64)blockIdx.x >= a.tileOff[c + 1]) c++;
@@ -1556,16 +1556,32 @@ __global__ __launch_bounds__(256) void scan_window_kernel(const MT *__restrict__
     for (i64 i = threadIdx.x; i < cntWin; i += 256) { u64 s = 0; for (int j = 0; j < a.comb; j++) s += src[i + j]; dst[i] = s; }
     return;
   }
+  // LDS index with one spare slot per 8: a thread slides over 8 consecutive windows, so neighbouring lanes are 8 elements
+  // apart -- 9 after padding: conflict-free for the 32-bit micro-windows of unweighted scans (the stride of 8 put all lanes
+  // on two banks).  The sums go back through the same buffer so that the stores to `out` are contiguous across the wave.
+  MT *in = (MT *)lds;
   const i64 need = cntWin + a.comb - 1;
-  for (i64 i = threadIdx.x; i < need; i += 256) lds[i] = src[i];
+  for (i64 i = threadIdx.x; i < need; i += 256) in[i + (i >> 3)] = src[i];
   __syncthreads();
   const i64 w0 = (i64)threadIdx.x * kWinPer;
+  u64 sum[kWinPer];
   if (w0 < cntWin) {
     u64 s = 0;
-    for (int j = 0; j < a.comb; j++) s += lds[w0 + j];
-    dst[w0] = s;
-    for (int q = 1; q < kWinPer && w0 + q < cntWin; q++) { s += lds[w0 + q + a.comb - 1] - lds[w0 + q - 1]; dst[w0 + q] = s; }
+    for (int j = 0; j < a.comb; j++) { const i64 i = w0 + j; s += in[i + (i >> 3)]; }
+    sum[0] = s;
+#pragma unroll
+    for (int q = 1; q < kWinPer; q++) {
+      if (w0 + q < cntWin) { const i64 ia = w0 + q + a.comb - 1, ib = w0 + q - 1; s += (u64)in[ia + (ia >> 3)] - (u64)in[ib + (ib >> 3)]; }
+      sum[q] = s;
+    }
   }
+  __syncthreads();                                 // all reads of `in` are done: the buffer now takes the sums
+  if (w0 < cntWin) {
+#pragma unroll
+    for (int q = 0; q < kWinPer; q++) if (w0 + q < cntWin) { const i64 i = w0 + q; lds[i + (i >> 3)] = sum[q]; }
+  }
+  __syncthreads();
+  for (i64 i = threadIdx.x; i < cntWin; i += 256) dst[i] = lds[i + (i >> 3)];
 }
 
 // ---------------------------------------------------------------------------------------------
