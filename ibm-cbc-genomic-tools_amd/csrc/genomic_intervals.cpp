@@ -438,25 +438,26 @@ GenomicRegionSetOverlaps::~GenomicRegionSetOverlaps() {}
 
 unsigned long int *GenomicRegionSetOverlaps::CountIndexOverlaps(bool match_gaps, bool ignore_strand, long int max_label_value)
 {
-  (void)match_gaps;   // single-interval regions have no gaps: both settings select the same pairs (genomic_intervals.cpp:5226)
+  // single-interval regions have no gaps: both settings select the same pairs (genomic_intervals.cpp:5226)
   if (IndexSet->load_in_memory == false) {
     fprintf(stderr, "[GenomicRegionSetOverlaps::CountIndexOverlaps]: index set must be loaded in memory for this operation!\n");
     exit(1);
   }
-  return Reduce(false, ignore_strand, max_label_value);
+  return Reduce(false, match_gaps, ignore_strand, max_label_value);
 }
 
 unsigned long int *GenomicRegionSetOverlaps::CalcIndexCoverage(bool match_gaps, bool ignore_strand, long int max_label_value)
 {
-  (void)match_gaps;   // single intervals: the envelope formula (:5278) and CalcOverlap (:1196-1202) coincide
+  // single intervals: the envelope formula (:5278) and CalcOverlap (:1196-1202) coincide except that the former is not clamped
+  // at 0 -- pairs with an inverted interval under the sorted merge (GTX_GAPS_FORMULA)
   if (IndexSet->load_in_memory == false) {
     fprintf(stderr, "[GenomicRegionSetOverlaps::CalcIndexCoverage]: index set must be loaded in memory for this operation!\n");
     exit(1);
   }
-  return Reduce(true, ignore_strand, max_label_value);
+  return Reduce(true, match_gaps, ignore_strand, max_label_value);
 }
 
-unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool ignore_strand, long int max_label_value)
+unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_gaps, bool ignore_strand, long int max_label_value)
 {
   const long int M = IndexSet->n_regions;
   const bool sorted = UsesSortedMerge(), by_strand = SortedByStrand();
@@ -464,9 +465,25 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool ignore_s
   Mark("CountIndexOverlaps: start");
 
   // ---- index side ----
+  // Sorted merge: the reference notices an index set that is out of order only at the moment the merge pulls the offending
+  // region (genomic_intervals.cpp:5868).  v = the first such region; the regions from v on are never matched (either the
+  // queries end before the merge gets there, or the run ends with the error), the packer's IndexGuard decides which.
+  long int v = M;
+  if (sorted) for (long int k = 1; k < M; k++) if (IndexSet->R[k]->IsBefore(IndexSet->R[k - 1], by_strand)) { v = k; break; }
+  gtxhost::IndexGuard guard;
+  if (v < M) {
+    guard.by_strand = by_strand;
+    for (long int k = 0; k < v; k++) {
+      GenomicInterval *i = IndexSet->R[k]->I.front();
+      guard.chrom.push_back(i->CHROMOSOME); guard.strand.push_back(i->STRAND); guard.start.push_back(i->START); guard.stop.push_back(i->STOP);
+    }
+    char buf[160];
+    snprintf(buf, sizeof buf, "\nError: Line %ld: index regions are not sorted (sorted-by-strand = %s)!", v, by_strand ? "true" : "false");
+    guard.msg = buf;
+  }
   ChromTable chroms;
   const char *last_name = NULL;                                                     // region files repeat a chromosome many times in a row
-  for (long int k = 0; k < M; k++) {
+  for (long int k = 0; k < v; k++) {
     GenomicInterval *i = IndexSet->R[k]->I.front();
     if (!sorted && (i->START > i->STOP || i->STOP <= 0)) continue;                 // :5609, :5659
     if (last_name && strcmp(last_name, i->CHROMOSOME) == 0) continue;
@@ -481,17 +498,13 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool ignore_s
   for (long int k = 0; k < M; k++) {
     GenomicRegion *r = IndexSet->R[k];
     GenomicInterval *i = r->I.front();
-    if (sorted) {
-      if (k > 0 && r->IsBefore(IndexSet->R[k - 1], by_strand))                    // :5868 (checked here for the whole set)
-        r->PrintError(std::string("index regions are not sorted (sorted-by-strand = ") + (by_strand ? "true" : "false") + ")!");
-      if (i->START > i->STOP + 1) r->PrintError("inverted interval (end < start) is outside the MI355X counting path!");
-      if (i->START == i->STOP + 1) zero_length_refs = true;
-    }
+    if (k >= v) { refs[3 * k] = -1; refs[3 * k + 1] = 1; refs[3 * k + 2] = 0; continue; }   // behind the out-of-order spot: a placeholder
+    if (sorted && i->START == i->STOP + 1) zero_length_refs = true;
     if (i->START >= INT_MAX - 1 || i->STOP >= INT_MAX - 1 || i->START <= INT_MIN + 1 || i->STOP <= INT_MIN + 1)
       r->PrintError("coordinate does not fit the packed 32-bit representation of the MI355X path!");
     if (!last_name || strcmp(last_name, i->CHROMOSOME) != 0) { last_name = i->CHROMOSOME; last_id = chroms.Find(i->CHROMOSOME); }
     const int id = last_id;
-    if (id < 0) { refs[3 * k] = 0; refs[3 * k + 1] = 1; refs[3 * k + 2] = 0; continue; }   // invalid region: never matches
+    if (id < 0) { refs[3 * k] = -1; refs[3 * k + 1] = 1; refs[3 * k + 2] = 0; continue; }  // invalid region: never matches
     refs[3 * k] = id + ((strand_aware && i->STRAND == '-') ? n_chrom : 0);
     refs[3 * k + 1] = (int32_t)i->START; refs[3 * k + 2] = (int32_t)i->STOP;
   }
@@ -507,6 +520,7 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool ignore_s
   opt.mode = sorted ? gtxhost::PACK_OVERLAPS_SORTED : gtxhost::PACK_OVERLAPS_UNSORTED;
   opt.chroms = &chroms; opt.strand_aware = strand_aware; opt.sorted_by_strand = by_strand;
   opt.max_label_value = max_label_value; opt.collect_zero_length = !coverage && sorted && zero_length_refs;
+  if (v < M) opt.guard = &guard;
   std::vector<int32_t> zero_len;
   unsigned long int *hits = new unsigned long int[M > 0 ? M : 1];
   gtx_count_info info;
@@ -514,10 +528,12 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool ignore_s
     // zero-length reads (sorted rules let them through) and zero-length regions contribute 0: the device leaves them out
     CheckGtx(ctx, gtx_coverage_begin(ctx));
     DrainSet(QuerySet, opt, [&](const PackedBatch &b) {
-      CheckGtx(ctx, gtx_coverage_add(ctx, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), 0));
+      CheckGtx(ctx, gtx_coverage_add(ctx, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3),
+                                     sorted ? (GTX_ZERO_LENGTH_OK | (match_gaps ? GTX_GAPS_FORMULA : 0u)) : 0u));
     });
     Mark("queries packed and enqueued");
     CheckGtx(ctx, gtx_coverage_end(ctx, (uint64_t *)hits, &info));
+    if (info.n_unplaced != 0) { fflush(stdout); fprintf(stderr, "\nError: %ld inverted query regions (start > stop) exceed what the MI355X path sets aside for pairwise matching!\n", (long)info.n_unplaced); exit(1); }
     Mark("coverage on the host");
     return hits;
   }
@@ -531,7 +547,9 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool ignore_s
   Mark("queries packed and enqueued");
   CheckGtx(ctx, gtx_count_end(ctx, (uint64_t *)hits, &info));
   Mark("counts on the host");
-  if (info.n_degenerate != 0) { fflush(stdout); fprintf(stderr, "\nError: internal: the packer let %ld degenerate reads through\n", (long)info.n_degenerate); exit(1); }
+  // (sorted merge: n_degenerate counts the inverted reads, which the library matched pair by pair)
+  if (!sorted && info.n_degenerate != 0) { fflush(stdout); fprintf(stderr, "\nError: internal: the packer let %ld degenerate reads through\n", (long)info.n_degenerate); exit(1); }
+  if (info.n_unplaced != 0) { fflush(stdout); fprintf(stderr, "\nError: %ld inverted query regions (start > stop) exceed what the MI355X path sets aside for pairwise matching!\n", (long)info.n_unplaced); exit(1); }
 
   // sorted merge only: a zero-length read never overlaps a zero-length region at the same spot
   // (rS <= qE and rE >= qS cannot both hold), while the rank difference counts it as -1: undo that.

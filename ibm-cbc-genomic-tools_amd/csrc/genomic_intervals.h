@@ -136,7 +136,7 @@ class GenomicRegionSetOverlaps
   GenomicRegion *current_ireg;
 
  protected:
-  unsigned long int *Reduce(bool coverage, bool ignore_strand, long int max_label_value);
+  unsigned long int *Reduce(bool coverage, bool match_gaps, bool ignore_strand, long int max_label_value);
   virtual bool UsesSortedMerge() const = 0;      // which reference algorithm's input rules apply
   virtual bool SortedByStrand() const { return false; }
 };

@@ -409,6 +409,21 @@ const char *NotSortedMsg(const PackOptions &o)
   return o.sorted_by_strand ? "input regions are not sorted (sorted-by-strand = true)!" : "input regions are not sorted (sorted-by-strand = false)!";
 }
 
+// one query against the pull loop of LoadIndexBuffer (genomic_intervals.cpp:5851-5870); false when it pulls region v
+static inline bool GuardStep(IndexGuard *g, const BedFields &f)
+{
+  const long v = (long)g->start.size();
+  while (g->p < v) {
+    const long k = g->p;
+    int d = strcmp(f.chrom, g->chrom[k]);                          // CalcDirection (:1225-1236)
+    if (d == 0 && g->by_strand) d = (int)f.strand - (int)g->strand[k];
+    if (d == 0) d = g->stop[k] < f.start ? 1 : (f.stop < g->start[k] ? -1 : 0);
+    if (d < 0) break;
+    if (++g->p == v) return false;                                 // Next() delivers region v: IsBefore(region v-1) holds
+  }
+  return true;
+}
+
 // What happens to one parsed region (the same for a text line and for a record of a packed file): order check,
 // chromosome lookup, the mode's validity rules, output.  Returns false when an error was recorded.
 struct ChromCache { std::string name; int id = -2; };
@@ -425,6 +440,7 @@ static inline bool HandleRecord(Piece *p, const PackOptions &o, const BedFields 
       if (p->last_chrom != f.chrom) p->last_chrom = f.chrom;
       p->last_strand = f.strand; p->last_start = f.start; p->any = true;
     }
+    if (o.guard && o.mode == PACK_OVERLAPS_SORTED && !GuardStep(o.guard, f)) { SetErr(&p->err, line_no, o.guard->msg, true); return false; }
     if (cc.id == -2 || cc.name != f.chrom) { cc.name = f.chrom; cc.id = o.chroms->Find(f.chrom); }
     const int id = cc.id;
     bool zero_len = false;
@@ -439,8 +455,7 @@ static inline bool HandleRecord(Piece *p, const PackOptions &o, const BedFields 
         break;
       case PACK_OVERLAPS_SORTED:
         if (id < 0) return true;
-        if (f.start > f.stop + 1) { SetErr(&p->err, line_no, "inverted interval (end < start) is outside the MI355X counting path!"); break; }
-        zero_len = f.start == f.stop + 1;
+        zero_len = f.start == f.stop + 1;                                  // (inverted reads go on: the library matches them pair by pair)
         break;
       case PACK_SCAN_UNSORTED:
         if (f.start > f.stop || f.stop <= 0) return true;
@@ -527,11 +542,13 @@ long CountLines(const char *b, const char *e)
 
 BedPacker::BedPacker(LineSource *src, const PackOptions &opt) : src_(src), opt_(opt)
 {
+  if (opt_.guard) opt_.threads = 1;
   if (opt_.threads <= 0) { unsigned hc = std::thread::hardware_concurrency(); opt_.threads = hc ? (int)std::min(hc, 64u) : 4; }
 }
 
 BedPacker::BedPacker(const GtxView *packed, const PackOptions &opt) : src_(nullptr), opt_(opt)
 {
+  if (opt_.guard) opt_.threads = 1;
   if (opt_.threads <= 0) { unsigned hc = std::thread::hardware_concurrency(); opt_.threads = hc ? (int)std::min(hc, 64u) : 4; }
   gtx_ = packed;
 }

@@ -106,6 +106,18 @@ enum PackMode {
   PACK_SCAN_SORTED          // SortedGenomicRegionSetScanner (:4928-4957)
 };
 
+// Sorted merge, index side: SortedGenomicRegionSetOverlaps pulls index regions while the current query is not before them
+// and checks their order only as it pulls (genomic_intervals.cpp:5851-5870), so an index set that is out of order at
+// region v is an error only if some query gets the merge as far as region v-1.  When the index set has such a spot, the
+// packer replays that pull loop over the sorted prefix [0, v) query by query (single-threaded: the loop is sequential
+// by nature) and raises the reference's error at the query that reaches it.
+struct IndexGuard {
+  std::vector<const char *> chrom; std::vector<char> strand; std::vector<long> start, stop;   // regions 0 .. v-1
+  bool by_strand = false;
+  long p = 0;                        // regions pulled so far
+  std::string msg;                   // the whole error text
+};
+
 struct PackOptions {
   PackMode mode = PACK_OVERLAPS_UNSORTED;
   const ChromTable *chroms = nullptr;
@@ -114,6 +126,7 @@ struct PackOptions {
   long max_label_value = 1;          // > 1: emit weights = min(max, atol(label))
   bool collect_zero_length = false;  // keep (class, start, weight) of zero-length reads (sorted mode correction)
   int threads = 0;                   // 0 = hardware concurrency
+  IndexGuard *guard = nullptr;       // PACK_OVERLAPS_SORTED with an out-of-order index set (forces one thread)
 };
 
 struct PackError {

@@ -35,7 +35,7 @@ struct __attribute__((packed, aligned(4))) Tri3 { int c, s, e; };
 static constexpr unsigned short kNoBucket = 0xFFFF;
 
 template <bool WEIGHTED>
-__global__ __launch_bounds__(1024) void bucket_hist_kernel(const Tri3 *__restrict__ reads, i64 n, CountArgs a, BucketTable t, BucketWork w)
+__global__ __launch_bounds__(1024) void bucket_hist_kernel(const Tri3 *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a, BucketTable t, BucketWork w)
 {
   extern __shared__ int lds[];
   int *posHi = lds; unsigned *cnt = (unsigned *)(lds + t.nB);
@@ -46,7 +46,10 @@ __global__ __launch_bounds__(1024) void bucket_hist_kernel(const Tri3 *__restric
     const Tri3 r = reads[i];
     unsigned short id = kNoBucket;
     if ((unsigned)r.c >= (unsigned)a.nClasses) nNoClass++;
-    else if (r.s > r.e + a.zeroLenOk) { nDegen++; if (i < firstDegen) firstDegen = i; }
+    else if (r.s > r.e + a.zeroLenOk) {
+      nDegen++; if (i < firstDegen) firstDegen = i;
+      if (a.side) { const unsigned k = atomicAdd(a.sideCount, 1u); if (k < (unsigned)a.sideCap) a.side[k] = make_int4(r.c, r.s, r.e, WEIGHTED ? weights[i] : 1); }   // see CountArgs::side
+    }
     else {
       int lo = t.clsStart[r.c], hi = t.clsStart[r.c + 1];
       if (lo < hi) {
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(1024) void bucket_hist_kernel(const Tri3 *__restric
   __syncthreads();
   for (int i = threadIdx.x; i < t.nB; i += blockDim.x) if (cnt[i]) atomicAdd(&w.count[i], cnt[i]);
   if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
-  if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen); }
+  if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen + a.indexBase); }
 }
 
 // offset[b] = reads in buckets < b; cursor = copy for the scatter's reservations; the totals are zeroed for the next call
@@ -202,8 +205,8 @@ hipError_t launch_count_bucketed(const void *reads, const void *weights, i64 n, 
   if (n <= 0) return hipSuccess;
   const size_t ldsHist = sizeof(int) * 2 * (size_t)t.nB;
   i64 blocks = (n + 1023) / 1024; if (blocks > 2048) blocks = 2048;
-  if (weights) bucket_hist_kernel<true><<<(unsigned)blocks, 1024, ldsHist, st>>>((const Tri3 *)reads, n, a, t, w);
-  else bucket_hist_kernel<false><<<(unsigned)blocks, 1024, ldsHist, st>>>((const Tri3 *)reads, n, a, t, w);
+  if (weights) bucket_hist_kernel<true><<<(unsigned)blocks, 1024, ldsHist, st>>>((const Tri3 *)reads, (const int *)weights, n, a, t, w);
+  else bucket_hist_kernel<false><<<(unsigned)blocks, 1024, ldsHist, st>>>((const Tri3 *)reads, (const int *)weights, n, a, t, w);
   bucket_scan_kernel<<<1, 1024, 0, st>>>(t, w);
   const unsigned sblocks = (unsigned)((n + 4095) / 4096);
   if (weights) bucket_scatter_kernel<true><<<sblocks, 1024, ldsHist, st>>>((const Tri3 *)reads, (const int *)weights, n, t, w);

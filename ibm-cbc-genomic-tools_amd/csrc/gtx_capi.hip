@@ -41,7 +41,13 @@ struct gtx_ctx {
   bool histDirty = false;              // a call was abandoned between begin and end
   // coverage (allocated on first use): 8 histograms, 8 tile-sum arrays, 8 prefix arrays, region coordinates
   u64 *d_cov[24] = {}; int *d_refS = nullptr, *d_refE = nullptr; bool covReady = false, covDirty = false, covOpen = false;
-  std::vector<int32_t> h_refS, h_refE;
+  std::vector<int32_t> h_refS, h_refE, h_refC;
+  // sorted-merge semantics, intervals with start > end + 1 (gtx_special.hip): the K inverted reference regions and their sums,
+  // the inverted reads the kernels set aside, the region columns the second pair kernel reads
+  bool mergeRefs = false;               // the reference set was given with GTX_REFS_KEEP_ZERO_LENGTH
+  int nSpecial = 0; int4 *d_specialRefs = nullptr; int *d_specialIdx = nullptr; u64 *d_specialOut = nullptr;
+  int4 *d_side = nullptr; unsigned *d_sideCount = nullptr; int sideCap = 1 << 20; int *d_refC = nullptr; bool sideUsed = false;
+  int specialMode = 0;                  // value of a pair in the open call: 0 count, 2 the -gaps coverage formula
   bool tileSumsValid = true;           // every kernel since the last finalize maintained the tile sums
   int64_t histLen = 0;
 
@@ -49,8 +55,14 @@ struct gtx_ctx {
   int infoCur = 0;
   gtx::DevInfo *h_info = nullptr;       // pinned: [0] = readback, [1] = init pattern
 
-  // staging for the host-buffer entry points
-  void *d_reads = nullptr; int *d_weights = nullptr; size_t capReads = 0;
+  // staging for the host-buffer entry points: two device slots fed from two pinned host slots by a copy stream, so that
+  // the host->device copy of batch i+1 runs under the kernels of batch i (Stage* functions below)
+  hipStream_t copyStream = nullptr;
+  void *d_stage[2] = {nullptr, nullptr}; int *d_stageW[2] = {nullptr, nullptr}; size_t capStage = 0, capStageW = 0;
+  char *h_pin[2] = {nullptr, nullptr}; size_t capPin = 0;       // bytes per slot
+  hipEvent_t evCopied[2] = {nullptr, nullptr}, evConsumed[2] = {nullptr, nullptr}; bool slotBusy[2] = {false, false};
+  long long stageSeq = 0; bool directPending = false;   // a DMA may still be reading the page-locked buffer of the last call
+  int copyThreads = 8;                  // host threads that move a pageable batch into the pinned slot (GTX_COPY_THREADS)
   u64 *d_out = nullptr; size_t capOut = 0;
 
   // scan state
@@ -67,9 +79,10 @@ struct gtx_ctx {
   hipEvent_t *ev = evRing[0];
 
   // streaming count (begin/add/end)
-  bool streamOpen = false; int64_t streamSeen = 0; gtx::DevInfo streamTotal; int32_t streamLast[2] = {0, 0};
+  bool streamOpen = false; int64_t streamSeen = 0; int32_t streamLast[2] = {0, 0};
+  int64_t seamUnsorted = INT64_MAX;    // first order violation found at a seam between batches (host-side check)
 
-  int64_t batchReads = 64ll << 20;      // reads per device batch of the host-buffer entry points (768 MiB of triples)
+  int64_t batchReads = 8ll << 20;       // reads per device batch of the host-buffer entry points (96 MiB of triples: ~2 ms of PCIe)
   int chunksPerWave = 0;                // 0 = choose per call from the number of reads
   int prefetch = 4;                     // reads per lane per step (R) of the streaming kernel (GTX_READS_PER_LANE)
 };
@@ -101,13 +114,20 @@ gtx_ctx *gtx_create(int device_id)
   if (hipMalloc(&c->d_info, 2 * sizeof(gtx::DevInfo)) != hipSuccess || hipHostMalloc(&c->h_info, 2 * sizeof(gtx::DevInfo)) != hipSuccess) {
     g_create_error = "gtx_create: allocation failed"; delete c; return nullptr;
   }
-  c->h_info[1].first_unsorted = INT64_MAX; c->h_info[1].n_no_class = 0; c->h_info[1].n_degenerate = 0; c->h_info[1].first_degenerate = INT64_MAX;
+  c->h_info[1].first_unsorted = INT64_MAX; c->h_info[1].n_no_class = 0; c->h_info[1].n_degenerate = 0; c->h_info[1].first_degenerate = INT64_MAX; c->h_info[1].n_unplaced = 0;
   c->h_info[0] = c->h_info[1];
   if (hipMemcpy(c->d_info, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->d_info + 1, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice) != hipSuccess) {
     g_create_error = "gtx_create: hipMemcpy failed"; delete c; return nullptr;
   }
   for (auto &slot : c->evRing) for (auto &ev : slot) if (hipEventCreate(&ev) != hipSuccess) { g_create_error = "gtx_create: hipEventCreate failed"; delete c; return nullptr; }
+  if (hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "gtx_create: hipStreamCreate failed"; delete c; return nullptr; }
+  for (int k = 0; k < 2; k++)
+    if (hipEventCreateWithFlags(&c->evCopied[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evConsumed[k], hipEventDisableTiming) != hipSuccess) {
+      g_create_error = "gtx_create: hipEventCreate failed"; delete c; return nullptr;
+    }
+  { unsigned hc = std::thread::hardware_concurrency(); c->copyThreads = (int)std::max(1u, std::min(hc ? hc : 4u, 8u));
+    if (const char *ct = getenv("GTX_COPY_THREADS")) if (atoi(ct) > 0) c->copyThreads = atoi(ct); }
   const char *cpw = getenv("GTX_CHUNKS_PER_WAVE");
   if (cpw && atoi(cpw) > 0) c->chunksPerWave = atoi(cpw);
   const char *br = getenv("GTX_BATCH_READS");
@@ -125,9 +145,17 @@ void gtx_destroy(gtx_ctx *c)
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
   dfree(c->d_bktIds); dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_bktCnt);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
-  dfree(c->d_reads); dfree(c->d_weights); dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
+  if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
+  for (int k = 0; k < 2; k++) {
+    dfree(c->d_stage[k]); dfree(c->d_stageW[k]);
+    if (c->h_pin[k]) (void)hipHostFree(c->h_pin[k]);
+    if (c->evCopied[k]) (void)hipEventDestroy(c->evCopied[k]);
+    if (c->evConsumed[k]) (void)hipEventDestroy(c->evConsumed[k]);
+  }
+  if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
+  dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
   for (auto &p : c->d_cov) dfree(p);
-  dfree(c->d_refS); dfree(c->d_refE);
+  dfree(c->d_refS); dfree(c->d_refE); dfree(c->d_refC); dfree(c->d_specialRefs); dfree(c->d_specialIdx); dfree(c->d_specialOut); dfree(c->d_side); dfree(c->d_sideCount);
   if (c->h_info) (void)hipHostFree(c->h_info);
   for (auto &slot : c->evRing) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
   delete c;
@@ -137,7 +165,24 @@ const char *gtx_last_error(const gtx_ctx *c) { return c ? c->err.c_str() : g_cre
 
 int gtx_set_stream(gtx_ctx *c, void *s) { if (!c) return GTX_E_ARG; c->stream = (hipStream_t)s; return GTX_OK; }
 
-int gtx_sync(gtx_ctx *c) { if (!c) return GTX_E_ARG; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return GTX_OK; }
+int gtx_sync(gtx_ctx *c)
+{
+  if (!c) return GTX_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->copyStream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GTX_OK;
+}
+
+void *gtx_host_alloc(gtx_ctx *c, size_t bytes)
+{
+  if (!c) return nullptr;
+  void *p = nullptr;
+  if (hipSetDevice(c->device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) { c->err = "gtx_host_alloc: hipHostMalloc failed"; (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+
+void gtx_host_free(gtx_ctx *c, void *p) { (void)c; if (p) (void)hipHostFree(p); }
 
 int64_t gtx_n_refs(const gtx_ctx *c) { return c ? c->nRefs : -1; }
 
@@ -154,7 +199,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   int maxc = -1;
   for (int64_t k = 0; k < m; k++) {
     int32_t cl = tri[3 * k], s = tri[3 * k + 1], e = tri[3 * k + 2];
-    if (cl < 0) return fail(c, GTX_E_RANGE, "gtx_set_refs: negative class id");
+    if (cl < -1) return fail(c, GTX_E_RANGE, "gtx_set_refs: negative class id");      // -1: a placeholder that never matches
     if (s >= INT32_MAX - 1 || e >= INT32_MAX - 1) return fail(c, GTX_E_RANGE, "gtx_set_refs: coordinate >= 2^31-2");
     if (cl > maxc) maxc = cl;
   }
@@ -169,7 +214,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   const bool keepZero = (flags & GTX_REFS_KEEP_ZERO_LENGTH) != 0;
   for (int64_t k = 0; k < m; k++) {
     int32_t s = tri[3 * k + 1], e = tri[3 * k + 2];
-    const bool take = keepZero ? (int64_t)s <= (int64_t)e + 1 : !(s > e || e <= 0);
+    const bool take = tri[3 * k] >= 0 && (keepZero ? (int64_t)s <= (int64_t)e + 1 : !(s > e || e <= 0));
     if (take) ord.push_back((int32_t)k);
   }
   const int64_t nv = (int64_t)ord.size();
@@ -278,8 +323,24 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   }
   for (auto &p : c->d_cov) dfree(p);
   dfree(c->d_refS); dfree(c->d_refE); c->covReady = false; c->covDirty = false;
-  c->h_refS.resize(m > 0 ? m : 1); c->h_refE.resize(m > 0 ? m : 1);
-  for (int64_t k = 0; k < m; k++) { c->h_refS[k] = tri[3 * k + 1]; c->h_refE[k] = tri[3 * k + 2]; }
+  c->h_refS.resize(m > 0 ? m : 1); c->h_refE.resize(m > 0 ? m : 1); c->h_refC.resize(m > 0 ? m : 1);
+  for (int64_t k = 0; k < m; k++) { c->h_refC[k] = tri[3 * k]; c->h_refS[k] = tri[3 * k + 1]; c->h_refE[k] = tri[3 * k + 2]; }
+  dfree(c->d_refC); dfree(c->d_specialRefs); dfree(c->d_specialIdx); dfree(c->d_specialOut);
+  c->mergeRefs = keepZero; c->nSpecial = 0;
+  if (keepZero) {
+    std::vector<int4> sp; std::vector<int32_t> spIdx;
+    for (int64_t k = 0; k < m; k++)
+      if (tri[3 * k] >= 0 && (int64_t)tri[3 * k + 1] > (int64_t)tri[3 * k + 2] + 1) { sp.push_back(make_int4(tri[3 * k], tri[3 * k + 1], tri[3 * k + 2], 0)); spIdx.push_back((int32_t)k); }
+    c->nSpecial = (int)sp.size();
+    if (c->nSpecial) {
+      HIPCHK(c, hipMalloc(&c->d_specialRefs, sizeof(int4) * sp.size()));
+      HIPCHK(c, hipMalloc(&c->d_specialIdx, sizeof(int32_t) * sp.size()));
+      HIPCHK(c, hipMalloc(&c->d_specialOut, sizeof(u64) * sp.size()));
+      HIPCHK(c, hipMemcpy(c->d_specialRefs, sp.data(), sizeof(int4) * sp.size(), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->d_specialIdx, spIdx.data(), sizeof(int32_t) * sp.size(), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemset(c->d_specialOut, 0, sizeof(u64) * sp.size()));
+    }
+  }
   c->nRefs = m; c->nValid = nv; c->nClasses = nClasses; c->histLen = histLen;
   return GTX_OK;
 }
@@ -287,9 +348,10 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
 // ---------------------------------------------------------------------------------------------
 // count
 // ---------------------------------------------------------------------------------------------
-static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
+static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int64_t indexBase = 0)
 {
   gtx::CountArgs a;
+  a.indexBase = indexBase;
   a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart;
   a.histA = c->d_histA; a.histB = c->d_histB; a.partA = c->d_partA; a.partB = c->d_partB; a.info = c->d_info + c->infoCur;
   a.nClasses = c->nClasses;
@@ -310,6 +372,8 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads)
   a.chunksPerWave = (cpw + r - 1) / r * r;
   a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0; a.prefetch = c->prefetch;
   a.zeroLenOk = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
+  const bool merge = (flags & GTX_ZERO_LENGTH_OK) && c->mergeRefs && c->d_side;       // full sorted-merge semantics (see merge_prepare)
+  a.side = merge ? c->d_side : nullptr; a.sideCount = merge ? c->d_sideCount : nullptr; a.sideCap = c->sideCap;
   a.sampE = c->d_sampE; a.sampS = c->d_sampS; a.sampShift = c->sampShift; a.nSamp = c->nSamp;
   a.topE = c->d_topE; a.topS = c->d_topS;
   // dense references (>= 4 boundaries per 256 reads and array): all boundaries of a window at once instead of the
@@ -343,6 +407,56 @@ static int launch_unsorted(gtx_ctx *c, const void *d_reads, const void *d_weight
   return GTX_OK;
 }
 
+// Full sorted-merge semantics (GTX_ZERO_LENGTH_OK on a reference set given with GTX_REFS_KEEP_ZERO_LENGTH): intervals with
+// start > end + 1 take part by the merge's two comparisons (gtx_special.hip).  Buffers are made on first use.
+static int ref_columns(gtx_ctx *c)
+{
+  if (!c->d_refS) {
+    HIPCHK(c, hipMalloc(&c->d_refS, sizeof(int32_t) * (c->nRefs + 1)));
+    HIPCHK(c, hipMalloc(&c->d_refE, sizeof(int32_t) * (c->nRefs + 1)));
+    if (c->nRefs > 0) {
+      HIPCHK(c, hipMemcpy(c->d_refS, c->h_refS.data(), sizeof(int32_t) * c->nRefs, hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->d_refE, c->h_refE.data(), sizeof(int32_t) * c->nRefs, hipMemcpyHostToDevice));
+    }
+  }
+  return GTX_OK;
+}
+
+static int merge_prepare(gtx_ctx *c, uint32_t flags, int mode)
+{
+  if (!(flags & GTX_ZERO_LENGTH_OK) || !c->mergeRefs) return GTX_OK;
+  if (!c->d_side) {
+    HIPCHK(c, hipMalloc(&c->d_side, sizeof(int4) * (size_t)c->sideCap));
+    HIPCHK(c, hipMalloc(&c->d_sideCount, sizeof(unsigned)));
+    HIPCHK(c, hipMemset(c->d_sideCount, 0, sizeof(unsigned)));
+  }
+  if (!c->d_refC) {
+    int rc = ref_columns(c); if (rc) return rc;
+    HIPCHK(c, hipMalloc(&c->d_refC, sizeof(int32_t) * (c->nRefs + 1)));
+    if (c->nRefs > 0) HIPCHK(c, hipMemcpy(c->d_refC, c->h_refC.data(), sizeof(int32_t) * c->nRefs, hipMemcpyHostToDevice));
+  }
+  c->sideUsed = true; c->specialMode = mode;
+  return GTX_OK;
+}
+
+// after the kernels of one batch: the batch against the inverted reference regions
+static int merge_batch(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n)
+{
+  if (c->sideUsed && c->nSpecial) HIPCHK(c, gtx::launch_special_refs(d_reads, d_weights, n, c->d_specialRefs, c->nSpecial, c->specialMode, c->d_specialOut, c->stream));
+  return GTX_OK;
+}
+
+// after the gather: the inverted reads against the other regions, then the inverted regions' sums into their places
+static int merge_end(gtx_ctx *c, void *d_out)
+{
+  if (!c->sideUsed) return GTX_OK;
+  c->sideUsed = false;
+  HIPCHK(c, gtx::launch_side_reads(c->d_refC, c->d_refS, c->d_refE, c->nRefs, c->d_side, c->d_sideCount, c->sideCap, c->specialMode, (u64 *)d_out,
+                                   c->d_info + c->infoCur, c->stream));
+  HIPCHK(c, gtx::launch_special_scatter(c->d_specialIdx, c->d_specialOut, c->nSpecial, (u64 *)d_out, c->d_sideCount, c->stream));
+  return GTX_OK;
+}
+
 // begin: zero histograms + info; accumulate: one kernel per resident batch; end: prefix + gather
 static int count_begin(gtx_ctx *c)
 {
@@ -353,7 +467,13 @@ static int count_begin(gtx_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_partA, 0, sizeof(u64) * (nTiles + 2), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_partB, 0, sizeof(u64) * (nTiles + 2), c->stream));
   }
-  if (c->histDirty) HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
+  // the info block is shared by count and coverage calls: an abandoned call of either kind leaves counts in it
+  if (c->histDirty || c->covDirty) HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
+  if ((c->histDirty || c->covDirty) && c->d_sideCount) {            // an abandoned call may have left inverted reads / sums behind
+    HIPCHK(c, hipMemsetAsync(c->d_sideCount, 0, sizeof(unsigned), c->stream));
+    if (c->nSpecial) HIPCHK(c, hipMemsetAsync(c->d_specialOut, 0, sizeof(u64) * c->nSpecial, c->stream));
+  }
+  c->sideUsed = false;
   c->histDirty = true; c->tileSumsValid = true;
   return GTX_OK;
 }
@@ -362,6 +482,7 @@ static int count_end(gtx_ctx *c, void *d_hits)
 {
   HIPCHK(c, gtx::launch_finalize(c->d_histA, c->d_histB, c->histLen, c->d_partA, c->d_partB, c->tileSumsValid, c->d_prefA, c->d_prefB,
                                  c->d_posE, c->d_posS, c->d_classBase, c->nRefs, (u64 *)d_hits, c->d_info + (c->infoCur ^ 1), c->stream));
+  { int rc = merge_end(c, d_hits); if (rc) return rc; }
   c->histDirty = false;
   c->infoCur ^= 1;                                // the block just used stays readable until the call after next
   return GTX_OK;
@@ -376,9 +497,13 @@ int gtx_count_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int
   int rc = count_begin(c); if (rc) return rc;
   c->profThis = c->prof && (c->profEvery <= 1 || (c->profSeq++ % c->profEvery) == 0);
   if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
-  if (!(flags & GTX_READS_SORTED)) c->tileSumsValid = false;
-  if (flags & GTX_READS_SORTED) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), true, c->stream));
+  rc = merge_prepare(c, flags, 0); if (rc) return rc;
+  // GTX_CHECK_SORTED is answered by the streaming kernel (exact for any order; only it looks at the order of the reads)
+  const bool streaming = (flags & (GTX_READS_SORTED | GTX_CHECK_SORTED)) != 0;
+  if (!streaming) c->tileSumsValid = false;
+  if (streaming) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), true, c->stream));
   else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n)); if (rc) return rc; }
+  rc = merge_batch(c, d_reads, d_weights, n); if (rc) return rc;
   if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   rc = count_end(c, d_hits); if (rc) return rc;
   if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
@@ -390,6 +515,7 @@ static void info_out(const gtx::DevInfo &d, gtx_count_info *o, int64_t base)
   o->first_unsorted = d.first_unsorted == INT64_MAX ? -1 : d.first_unsorted + base;
   o->n_no_class = d.n_no_class; o->n_degenerate = d.n_degenerate;
   o->first_degenerate = d.first_degenerate == INT64_MAX ? -1 : d.first_degenerate + base;
+  o->n_unplaced = d.n_unplaced;
 }
 
 int gtx_last_info(gtx_ctx *c, gtx_count_info *info)
@@ -402,17 +528,94 @@ int gtx_last_info(gtx_ctx *c, gtx_count_info *info)
   return GTX_OK;
 }
 
-static int ensure_staging(gtx_ctx *c, size_t nReads, bool weights)
+} // extern "C" (templates below)
+
+// ---------------------------------------------------------------------------------------------
+// host buffers -> device, double-buffered
+// ---------------------------------------------------------------------------------------------
+// A batch of the caller's reads travels: [pageable memory -> pinned slot (host threads)] -> device slot (DMA on the copy
+// stream) -> kernels (the context's stream).  Two slots of each kind alternate, so the copy of batch i+1 -- host part and
+// DMA -- runs under the kernels of batch i; the only host waits are for a slot to come free.  Memory the caller obtained
+// from gtx_host_alloc (or any other page-locked memory HIP knows) skips the pinned slot: the DMA reads it directly.
+static bool is_pinned(const void *p)
 {
-  if (nReads > c->capReads) {
-    dfree(c->d_reads); dfree(c->d_weights); c->capReads = 0;
-    HIPCHK(c, hipMalloc(&c->d_reads, nReads * 12));
-    HIPCHK(c, hipMalloc(&c->d_weights, nReads * 4));
-    c->capReads = nReads;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+
+static void parallel_copy(char *dst, const char *src, size_t bytes, int threads)
+{
+  const int T = (int)std::min<size_t>((size_t)threads, bytes / (4u << 20) + 1);
+  if (T <= 1) { memcpy(dst, src, bytes); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) th.emplace_back([=] { const size_t b0 = bytes * (size_t)t / T, b1 = bytes * (size_t)(t + 1) / T; memcpy(dst + b0, src + b0, b1 - b0); });
+  memcpy(dst, src, bytes / T);
+  for (auto &x : th) x.join();
+}
+
+static int stage_reserve(gtx_ctx *c, size_t nReads, bool weights, bool pinnedSlots)
+{
+  if (nReads > c->capStage || (weights && nReads > c->capStageW) || (pinnedSlots && nReads * 16 > c->capPin)) {
+    // growing: nothing may still be in flight on the old buffers
+    HIPCHK(c, hipStreamSynchronize(c->copyStream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->slotBusy[0] = c->slotBusy[1] = false;
   }
-  (void)weights;
+  if (nReads > c->capStage) {
+    for (int k = 0; k < 2; k++) { dfree(c->d_stage[k]); HIPCHK(c, hipMalloc(&c->d_stage[k], nReads * 12)); }
+    c->capStage = nReads;
+  }
+  if (weights && nReads > c->capStageW) {
+    for (int k = 0; k < 2; k++) { dfree(c->d_stageW[k]); HIPCHK(c, hipMalloc(&c->d_stageW[k], nReads * 4)); }
+    c->capStageW = nReads;
+  }
+  if (pinnedSlots && nReads * 16 > c->capPin) {
+    for (int k = 0; k < 2; k++) { if (c->h_pin[k]) { (void)hipHostFree(c->h_pin[k]); c->h_pin[k] = nullptr; } HIPCHK(c, hipHostMalloc((void **)&c->h_pin[k], nReads * 16)); }
+    c->capPin = nReads * 16;
+  }
   return GTX_OK;
 }
+
+// Streams reads[0..n) (and weights) through the device in batches; launch(d_reads, d_weights, cnt, off) enqueues the
+// kernels of one batch on the context's stream.  Returns with everything enqueued; the caller's buffers are free again
+// when the function returns unless they are page-locked, in which case they must stay untouched until the context's next
+// host-buffer call, gtx_*_end or gtx_sync has returned.
+template <class Launch>
+static int stage_batches(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, Launch launch)
+{
+  if (c->directPending) { HIPCHK(c, hipStreamSynchronize(c->copyStream)); c->directPending = false; }   // the previous call's page-locked source is free now
+  if (n <= 0) return GTX_OK;
+  const int64_t batch = c->batchReads;
+  const bool direct = is_pinned(reads) && (!weights || is_pinned(weights));
+  c->directPending = direct;
+  int rc = stage_reserve(c, (size_t)std::min<int64_t>(n, batch), weights != nullptr, !direct); if (rc) return rc;
+  for (int64_t off = 0; off < n; off += batch) {
+    const int64_t cnt = std::min(batch, n - off);
+    const int slot = (int)(c->stageSeq++ & 1);
+    if (c->slotBusy[slot]) {
+      // the pinned slot is free once its DMA is done; the device slot once the kernels that read it are
+      if (!direct) HIPCHK(c, hipEventSynchronize(c->evCopied[slot]));
+      HIPCHK(c, hipStreamWaitEvent(c->copyStream, c->evConsumed[slot], 0));
+    }
+    const char *srcR = (const char *)(reads + 3 * off), *srcW = (const char *)(weights ? weights + off : nullptr);
+    if (!direct) {
+      parallel_copy(c->h_pin[slot], srcR, (size_t)cnt * 12, c->copyThreads);
+      if (weights) parallel_copy(c->h_pin[slot] + (size_t)cnt * 12, srcW, (size_t)cnt * 4, c->copyThreads);
+      srcR = c->h_pin[slot]; srcW = c->h_pin[slot] + (size_t)cnt * 12;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_stage[slot], srcR, (size_t)cnt * 12, hipMemcpyHostToDevice, c->copyStream));
+    if (weights) HIPCHK(c, hipMemcpyAsync(c->d_stageW[slot], srcW, (size_t)cnt * 4, hipMemcpyHostToDevice, c->copyStream));
+    HIPCHK(c, hipEventRecord(c->evCopied[slot], c->copyStream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evCopied[slot], 0));
+    rc = launch(c->d_stage[slot], weights ? c->d_stageW[slot] : nullptr, cnt, off); if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->evConsumed[slot], c->stream));
+    c->slotBusy[slot] = true;
+  }
+  return GTX_OK;
+}
+
+extern "C" {
 
 static int ensure_out(gtx_ctx *c, size_t n)
 {
@@ -429,7 +632,7 @@ int gtx_count_begin(gtx_ctx *c)
   if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_count_begin: gtx_set_refs has not been called");
   HIPCHK(c, hipSetDevice(c->device));
   int rc = count_begin(c); if (rc) return rc;
-  c->streamTotal = c->h_info[1]; c->streamSeen = 0; c->streamOpen = true; c->streamLast[0] = c->streamLast[1] = INT32_MIN;
+  c->streamSeen = 0; c->streamOpen = true; c->streamLast[0] = c->streamLast[1] = INT32_MIN; c->seamUnsorted = INT64_MAX;
   return GTX_OK;
 }
 
@@ -439,33 +642,27 @@ int gtx_count_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int6
   if (!c->streamOpen) return fail(c, GTX_E_STATE, "gtx_count_add: gtx_count_begin has not been called");
   if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_count_add: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
-  const int64_t batch = c->batchReads;
-  int rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
-  for (int64_t off = 0; off < n; off += batch) {
-    const int64_t cnt = std::min(batch, n - off);
-    HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
-    if (weights) HIPCHK(c, hipMemcpyAsync(c->d_weights, weights + off, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
-    if (!(flags & GTX_READS_SORTED)) c->tileSumsValid = false;
-    if (flags & GTX_READS_SORTED) HIPCHK(c, gtx::launch_count(c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags, cnt), true, c->stream));
-    else { int rcu = launch_unsorted(c, c->d_reads, weights ? c->d_weights : nullptr, cnt, count_args(c, flags, cnt)); if (rcu) return rcu; }
-    // fold this batch's info (indices are batch-relative) and reset the device block for the next one
-    HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + c->infoCur, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is reused by the next batch
-    const gtx::DevInfo &d = c->h_info[0];
-    gtx::DevInfo &t = c->streamTotal;
-    const int64_t pos = c->streamSeen + off;
-    if (d.first_unsorted != INT64_MAX && t.first_unsorted == INT64_MAX) t.first_unsorted = d.first_unsorted + pos;
-    if (d.first_degenerate != INT64_MAX && t.first_degenerate == INT64_MAX) t.first_degenerate = d.first_degenerate + pos;
-    t.n_no_class += d.n_no_class; t.n_degenerate += d.n_degenerate;
-    if ((flags & GTX_CHECK_SORTED) && pos > 0 && cnt > 0) {
-      // order across the batch seam
+  const bool streaming = (flags & (GTX_READS_SORTED | GTX_CHECK_SORTED)) != 0;
+  if ((flags & GTX_CHECK_SORTED) && n > 0) {
+    // order across the seams between batches (inside a batch the kernel checks): host-side, two reads per seam
+    const int64_t batch = c->batchReads;
+    for (int64_t off = 0; off < n; off += batch) {
       const int32_t *q = reads + 3 * off;
-      if ((q[0] < c->streamLast[0] || (q[0] == c->streamLast[0] && q[1] < c->streamLast[1])) && (t.first_unsorted == INT64_MAX || t.first_unsorted > pos))
-        t.first_unsorted = pos;
+      const int32_t pc = off ? q[-3] : c->streamLast[0], ps = off ? q[-2] : c->streamLast[1];
+      if ((c->streamSeen + off) > 0 && (q[0] < pc || (q[0] == pc && q[1] < ps)) && c->seamUnsorted == INT64_MAX) c->seamUnsorted = c->streamSeen + off;
     }
-    if (cnt > 0) { c->streamLast[0] = reads[3 * (off + cnt - 1)]; c->streamLast[1] = reads[3 * (off + cnt - 1) + 1]; }
   }
+  if (n > 0) { c->streamLast[0] = reads[3 * (n - 1)]; c->streamLast[1] = reads[3 * (n - 1) + 1]; }
+  const int64_t seen = c->streamSeen;
+  int rc = merge_prepare(c, flags, 0); if (rc) return rc;
+  rc = stage_batches(c, reads, weights, n, [&](const void *dR, const int *dW, int64_t cnt, int64_t off) -> int {
+    // indices in the info block are positions in the whole stream (indexBase); the block accumulates over the batches
+    if (!streaming) c->tileSumsValid = false;
+    if (streaming) HIPCHK(c, gtx::launch_count(dR, dW, cnt, count_args(c, flags, cnt, seen + off), true, c->stream));
+    else { int rcu = launch_unsorted(c, dR, dW, cnt, count_args(c, flags, cnt, seen + off)); if (rcu) return rcu; }
+    return merge_batch(c, dR, dW, cnt);
+  });
+  if (rc) return rc;
   c->streamSeen += n;
   return GTX_OK;
 }
@@ -479,9 +676,14 @@ int gtx_count_end(gtx_ctx *c, uint64_t *hits, gtx_count_info *info)
   c->streamOpen = false;
   int rc = ensure_out(c, (size_t)c->nRefs); if (rc) return rc;
   rc = count_end(c, c->d_out); if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + (c->infoCur ^ 1), sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
   if (c->nRefs > 0) HIPCHK(c, hipMemcpyAsync(hits, c->d_out, sizeof(u64) * c->nRefs, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (info) info_out(c->streamTotal, info, 0);
+  HIPCHK(c, hipStreamSynchronize(c->copyStream));
+  if (info) {
+    info_out(c->h_info[0], info, 0);
+    if (c->seamUnsorted != INT64_MAX && (info->first_unsorted < 0 || c->seamUnsorted < info->first_unsorted)) info->first_unsorted = c->seamUnsorted;
+  }
   return GTX_OK;
 }
 
@@ -509,22 +711,20 @@ static int cover_prepare(gtx_ctx *c)
     HIPCHK(c, hipMemset(c->d_cov[q], 0, sizeof(u64) * c->histLen));
     HIPCHK(c, hipMemset(c->d_cov[8 + q], 0, sizeof(u64) * (nTiles + 2)));
   }
-  HIPCHK(c, hipMalloc(&c->d_refS, sizeof(int32_t) * (c->nRefs + 1)));
-  HIPCHK(c, hipMalloc(&c->d_refE, sizeof(int32_t) * (c->nRefs + 1)));
-  if (c->nRefs > 0) {
-    HIPCHK(c, hipMemcpy(c->d_refS, c->h_refS.data(), sizeof(int32_t) * c->nRefs, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_refE, c->h_refE.data(), sizeof(int32_t) * c->nRefs, hipMemcpyHostToDevice));
-  }
+  { int rc = ref_columns(c); if (rc) return rc; }
   c->covReady = true; c->covDirty = false;
   return GTX_OK;
 }
 
-static gtx::CoverArgs cover_args(gtx_ctx *c, int64_t nReads)
+static gtx::CoverArgs cover_args(gtx_ctx *c, int64_t nReads, int64_t indexBase = 0, uint32_t flags = 0)
 {
   gtx::CoverArgs a;
+  a.indexBase = indexBase;
   a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart; a.topE = c->d_topE; a.topS = c->d_topS;
   for (int q = 0; q < 8; q++) { a.hist[q] = c->d_cov[q]; a.part[q] = c->d_cov[8 + q]; }
   a.info = c->d_info + c->infoCur; a.nClasses = c->nClasses;
+  const bool merge = (flags & GTX_ZERO_LENGTH_OK) && (flags & GTX_GAPS_FORMULA) && c->mergeRefs && c->d_side;
+  a.side = merge ? c->d_side : nullptr; a.sideCount = merge ? c->d_sideCount : nullptr; a.sideCap = c->sideCap;
   { static const bool wf = !(getenv("GTX_WEIGHTED_FAST") && atoi(getenv("GTX_WEIGHTED_FAST")) == 0); a.wfast = wf ? 1 : 0; }
   int64_t nChunks = (nReads + 63) >> 6;
   a.chunksPerWave = c->chunksPerWave > 0 ? c->chunksPerWave : (int)std::min<int64_t>(56, std::max<int64_t>(8, nChunks / 24576));   // as count_args
@@ -540,8 +740,15 @@ static int cover_begin(gtx_ctx *c)
       HIPCHK(c, hipMemsetAsync(c->d_cov[q], 0, sizeof(u64) * c->histLen, c->stream));
       HIPCHK(c, hipMemsetAsync(c->d_cov[8 + q], 0, sizeof(u64) * (nTiles + 2), c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
   }
+  if (c->covDirty || c->histDirty) {
+    HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
+    if (c->d_sideCount) {
+      HIPCHK(c, hipMemsetAsync(c->d_sideCount, 0, sizeof(unsigned), c->stream));
+      if (c->nSpecial) HIPCHK(c, hipMemsetAsync(c->d_specialOut, 0, sizeof(u64) * c->nSpecial, c->stream));
+    }
+  }
+  c->sideUsed = false;
   c->covDirty = true;
   return GTX_OK;
 }
@@ -552,6 +759,7 @@ static int cover_end(gtx_ctx *c, void *d_cov_out)
   for (int q = 0; q < 8; q++) { g.pref[q] = c->d_cov[16 + q]; g.part[q] = c->d_cov[8 + q]; }
   g.posE = c->d_posE; g.posS = c->d_posS; g.classBase = c->d_classBase; g.refS = c->d_refS; g.refE = c->d_refE;
   HIPCHK(c, gtx::launch_coverage_finalize(cover_args(c, 0), c->histLen, g, c->nRefs, (u64 *)d_cov_out, c->d_info + (c->infoCur ^ 1), c->stream));
+  { int rc = merge_end(c, d_cov_out); if (rc) return rc; }
   c->covDirty = false;
   c->infoCur ^= 1;
   return GTX_OK;
@@ -559,7 +767,6 @@ static int cover_end(gtx_ctx *c, void *d_cov_out)
 
 int gtx_coverage_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, void *d_cov)
 {
-  (void)flags;
   if (!c) return GTX_E_ARG;
   if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_coverage_device: gtx_set_refs has not been called");
   if (n < 0 || (n > 0 && !d_reads) || (c->nRefs > 0 && !d_cov)) return fail(c, GTX_E_ARG, "gtx_coverage_device: bad argument");
@@ -567,7 +774,9 @@ int gtx_coverage_device(gtx_ctx *c, const void *d_reads, const void *d_weights, 
   int rc = cover_begin(c); if (rc) return rc;
   c->profThis = c->prof && (c->profEvery <= 1 || (c->profSeq++ % c->profEvery) == 0);
   if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
-  HIPCHK(c, gtx::launch_coverage(d_reads, d_weights, n, cover_args(c, n), c->stream));
+  if (flags & GTX_GAPS_FORMULA) { rc = merge_prepare(c, flags, 2); if (rc) return rc; }
+  HIPCHK(c, gtx::launch_coverage(d_reads, d_weights, n, cover_args(c, n, 0, flags), c->stream));
+  rc = merge_batch(c, d_reads, d_weights, n); if (rc) return rc;
   if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   rc = cover_end(c, d_cov); if (rc) return rc;
   if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
@@ -580,32 +789,24 @@ int gtx_coverage_begin(gtx_ctx *c)
   if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_coverage_begin: gtx_set_refs has not been called");
   HIPCHK(c, hipSetDevice(c->device));
   int rc = cover_begin(c); if (rc) return rc;
-  c->streamTotal = c->h_info[1]; c->streamSeen = 0; c->covOpen = true;
+  c->streamSeen = 0; c->covOpen = true;
   return GTX_OK;
 }
 
 int gtx_coverage_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, uint32_t flags)
 {
-  (void)flags;
   if (!c) return GTX_E_ARG;
   if (!c->covOpen) return fail(c, GTX_E_STATE, "gtx_coverage_add: gtx_coverage_begin has not been called");
   if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_coverage_add: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
-  const int64_t batch = c->batchReads;
-  int rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
-  for (int64_t off = 0; off < n; off += batch) {
-    const int64_t cnt = std::min(batch, n - off);
-    HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
-    if (weights) HIPCHK(c, hipMemcpyAsync(c->d_weights, weights + off, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, gtx::launch_coverage(c->d_reads, weights ? c->d_weights : nullptr, cnt, cover_args(c, cnt), c->stream));
-    HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + c->infoCur, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_info + c->infoCur, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const gtx::DevInfo &d = c->h_info[0];
-    gtx::DevInfo &t = c->streamTotal;
-    if (d.first_degenerate != INT64_MAX && t.first_degenerate == INT64_MAX) t.first_degenerate = d.first_degenerate + c->streamSeen + off;
-    t.n_no_class += d.n_no_class; t.n_degenerate += d.n_degenerate;
-  }
+  const int64_t seen = c->streamSeen;
+  int rc = GTX_OK;
+  if (flags & GTX_GAPS_FORMULA) { rc = merge_prepare(c, flags, 2); if (rc) return rc; }
+  rc = stage_batches(c, reads, weights, n, [&](const void *dR, const int *dW, int64_t cnt, int64_t off) -> int {
+    HIPCHK(c, gtx::launch_coverage(dR, dW, cnt, cover_args(c, cnt, seen + off, flags), c->stream));
+    return merge_batch(c, dR, dW, cnt);
+  });
+  if (rc) return rc;
   c->streamSeen += n;
   return GTX_OK;
 }
@@ -619,9 +820,11 @@ int gtx_coverage_end(gtx_ctx *c, uint64_t *cov, gtx_count_info *info)
   c->covOpen = false;
   int rc = ensure_out(c, (size_t)c->nRefs); if (rc) return rc;
   rc = cover_end(c, c->d_out); if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + (c->infoCur ^ 1), sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
   if (c->nRefs > 0) HIPCHK(c, hipMemcpyAsync(cov, c->d_out, sizeof(u64) * c->nRefs, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (info) info_out(c->streamTotal, info, 0);
+  HIPCHK(c, hipStreamSynchronize(c->copyStream));
+  if (info) info_out(c->h_info[0], info, 0);
   return GTX_OK;
 }
 
@@ -718,21 +921,18 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
   for (int i = 0; i < nClasses; i++) extent = std::max<int64_t>(extent, classOff[i] + gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size));
   if (extent > 0 && !out) return fail(c, GTX_E_ARG, "gtx_scan: null output");
   rc = ensure_out(c, (size_t)extent); if (rc) return rc;
-  const int64_t batch = c->batchReads;
-  rc = ensure_staging(c, (size_t)std::min<int64_t>(std::max<int64_t>(n, 1), batch), weights != nullptr); if (rc) return rc;
   const bool micro64 = weights != nullptr;
   if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (micro64 ? 8 : 4), c->stream));
-  for (int64_t off = 0; off < n; off += batch) {
-    const int64_t cnt = std::min(batch, n - off);
-    HIPCHK(c, hipMemcpyAsync(c->d_reads, reads + 3 * off, (size_t)cnt * 12, hipMemcpyHostToDevice, c->stream));
-    if (weights) HIPCHK(c, hipMemcpyAsync(c->d_weights, weights + off, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, gtx::launch_scan_hist(c->d_reads, weights ? c->d_weights : nullptr, cnt, a, c->stream));
-    if (n > batch) HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
+  rc = stage_batches(c, reads, weights, n, [&](const void *dR, const int *dW, int64_t cnt, int64_t) -> int {
+    HIPCHK(c, gtx::launch_scan_hist(dR, dW, cnt, a, c->stream));
+    return GTX_OK;
+  });
+  if (rc) return rc;
   if (extent > 0) HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)extent * sizeof(u64), c->stream));
   HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, c->d_out, c->stream));
   if (extent > 0) HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)extent * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->copyStream));
   return GTX_OK;
 }
 

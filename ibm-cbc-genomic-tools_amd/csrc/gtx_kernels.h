@@ -11,6 +11,7 @@ struct DevInfo {
   long long n_no_class;
   long long n_degenerate;
   long long first_degenerate;
+  long long n_unplaced;          // inverted reads that did not fit the side buffer (counts incomplete: the caller must fail)
 };
 
 struct CountArgs {
@@ -34,6 +35,11 @@ struct CountArgs {
   const int *topE;               // every 256th element of sortedE / sortedS (index i << 8): first hop of the streaming
   const int *topS;               //   kernel's start-of-span search (rank_pair)
   int flip;                      // streaming kernel: meet all boundaries of a window at once (dense references)
+  long long indexBase;           // position of reads[0] in the caller's stream: added to the indices reported in `info`
+  // sorted-merge semantics (zeroLenOk): inverted reads (start > end + 1) are not degenerate there -- the merge matches them
+  // by its two comparisons like any other read (genomic_intervals.cpp:1225-1236).  The rank difference does not hold for
+  // them, so the kernels set them aside here (class, start, end, weight) for the pair kernels of gtx_special.hip.
+  int4 *side; unsigned *sideCount; int sideCap;
 };
 
 // coverage: 8 histograms / tile-sum arrays in the order
@@ -46,6 +52,8 @@ struct CoverArgs {
   DevInfo *info;
   int nClasses, chunksPerWave;
   int wfast;                       // weighted reads: steps of 4 x 64 with prefix sums in LDS (0: general per-chunk code only)
+  long long indexBase;             // as CountArgs
+  int4 *side; unsigned *sideCount; int sideCap;   // as CountArgs (only the -gaps coverage formula needs them)
 };
 
 struct CoverGather {
@@ -89,6 +97,16 @@ int bucket_e_size();
 int bucket_s_size();
 hipError_t launch_count_bucketed(const void *reads, const void *weights, long long n, const CountArgs &a, const BucketTable &t,
                                  const BucketWork &w, hipStream_t st);
+
+// ---- intervals the rank difference does not cover (gtx_special.hip): plain pair tests, reference semantics of the sorted merge
+// value of a matching pair: mode 0 = w (count), mode 2 = w x (min(ends) - max(starts) + 1), the unclamped -gaps formula of
+// CalcIndexCoverage (genomic_intervals.cpp:5278)
+hipError_t launch_special_refs(const void *reads, const void *weights, long long n, const int4 *refs, int nSpecial, int mode,
+                               unsigned long long *out, hipStream_t st);                 // out[j] += sum over reads matching special ref j
+hipError_t launch_side_reads(const int *refC, const int *refS, const int *refE, long long m, const int4 *side, const unsigned *sideCount,
+                             int sideCap, int mode, unsigned long long *hits, DevInfo *info, hipStream_t st);   // hits[k] += sum over side reads matching ref k
+hipError_t launch_special_scatter(const int *specialIdx, unsigned long long *specialOut, int nSpecial, unsigned long long *hits,
+                                  unsigned *sideCount, hipStream_t st);                  // hits[idx[j]] = out[j]; out and the side counter cleared
 
 int search_sample_shift(long long nValid);   // stride of the sample arrays such that both fit the LDS budget
 int scan_tiles(long long len);

@@ -307,6 +307,16 @@ struct Win {
 
 struct __attribute__((packed, aligned(4))) Tri { int c, s, e; };
 
+// sets the reads of the lanes in `m` aside for the pair kernels (see CountArgs::side); any control flow
+template <class ARGS>
+__device__ __forceinline__ void side_append(const ARGS &a, int c, int s, int e, int w, bool mine)
+{
+  if (a.side && mine) {
+    const unsigned i = atomicAdd(a.sideCount, 1u);
+    if (i < (unsigned)a.sideCap) a.side[i] = make_int4(c, s, e, w);
+  }
+}
+
 // the read stream is touched exactly once: non-temporal loads keep it from displacing the boundary
 // arrays and histograms in L2 / Infinity Cache (+10 % on the bare load pattern, scripts/membench.hip)
 __device__ __forceinline__ Tri load_tri(const char *p)
@@ -364,7 +374,10 @@ __device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountA
   if (degen | noclass) {
     st.nNoClass += __popcll(noclass);
     u64 dg = degen & ~noclass;
-    if (dg) { st.nDegen += __popcll(dg); i64 at = firstIndex + (__ffsll((unsigned long long)dg) - 1); if (at < st.firstDegen) st.firstDegen = at; }
+    if (dg) {
+      st.nDegen += __popcll(dg); i64 at = firstIndex + (__ffsll((unsigned long long)dg) - 1); if (at < st.firstDegen) st.firstDegen = at;
+      side_append(a, t.c, t.s, t.e, w, (dg >> lane) & 1);
+    }
   }
   if (mine && st.sg.start != st.sg.end) {
     u64 ra = st.A.walk(st.sg, t.s, w, mine, lane, st.validA);
@@ -833,8 +846,8 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
   if (st.validB) st.B.flush(st.sg, lane);
   if (lane == 0) {
     if (st.nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)st.nNoClass);
-    if (st.nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)st.nDegen); atomicMin((i64 *)&a.info->first_degenerate, st.firstDegen); }
-    if (st.firstUnsorted != INT64_MAX) atomicMin((i64 *)&a.info->first_unsorted, st.firstUnsorted);
+    if (st.nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)st.nDegen); atomicMin((i64 *)&a.info->first_degenerate, st.firstDegen + a.indexBase); }
+    if (st.firstUnsorted != INT64_MAX) atomicMin((i64 *)&a.info->first_unsorted, st.firstUnsorted + a.indexBase);
   }
 }
 
@@ -1080,7 +1093,10 @@ __device__ __forceinline__ void cov_chunk(CovState<WEIGHTED, STRICT> &st, const 
   if (!STRICT && (degen | noclass)) {                                 // reported once, by the pass over the ends array
     st.nNoClass += __popcll(noclass);
     const u64 inv = __ballot(t.s > t.e + 1) & degen;                // only these are reported (the packer's business)
-    if (inv) { st.nDegen += __popcll(inv); i64 p = firstIndex + (__ffsll((unsigned long long)inv) - 1); if (p < st.firstDegen) st.firstDegen = p; }
+    if (inv) {
+      st.nDegen += __popcll(inv); i64 p = firstIndex + (__ffsll((unsigned long long)inv) - 1); if (p < st.firstDegen) st.firstDegen = p;
+      side_append(a, t.c, t.s, t.e, w, (inv >> lane) & 1);
+    }
   }
   if (mine && sg.start != sg.end) {
     u64 r0, r1;
@@ -1196,7 +1212,7 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
   if (st.ve) st.We.flush(st.sg, lane);
   if (!STRICT && lane == 0) {
     if (st.nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)st.nNoClass);
-    if (st.nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)st.nDegen); atomicMin((i64 *)&a.info->first_degenerate, st.firstDegen); }
+    if (st.nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)st.nDegen); atomicMin((i64 *)&a.info->first_degenerate, st.firstDegen + a.indexBase); }
   }
 }
 
@@ -1238,7 +1254,7 @@ __global__ __launch_bounds__(1024) void count_search_kernel(const Tri *__restric
       if (WEIGHTED) w = (i64)weights[i];
       const int s0 = (unsigned)t.c < (unsigned)a.nClasses ? a.segStart[t.c] : 0, s1 = (unsigned)t.c < (unsigned)a.nClasses ? a.segStart[t.c + 1] : 0;
       if ((unsigned)t.c >= (unsigned)a.nClasses) nNoClass++;
-      else if (t.s > t.e + a.zeroLenOk) { nDegen++; if (i < firstDegen) firstDegen = i; }
+      else if (t.s > t.e + a.zeroLenOk) { nDegen++; if (i < firstDegen) firstDegen = i; side_append(a, t.c, t.s, t.e, (int)w, true); }
       else if (s0 != s1) {
         // samples i0..i1-1 are the ones that lie inside the class segment [s0, s1)
         const int i0 = (int)(((i64)s0 + rnd) >> sh), i1 = (int)(((i64)s1 + rnd) >> sh);
@@ -1263,7 +1279,7 @@ __global__ __launch_bounds__(1024) void count_search_kernel(const Tri *__restric
     }
   }
   if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
-  if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen); }
+  if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen + a.indexBase); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1358,7 +1374,7 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict_
 {
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < nTiles) { ta[k] = 0; tb[k] = 0; }         // the tile sums have been consumed: clean for the next call
-  if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; }
+  if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; nextInfo->n_unplaced = 0; }
   if (k >= m) return;
   int pe = posE[k];
   u64 h = 0;
@@ -1377,7 +1393,7 @@ __global__ __launch_bounds__(256) void gather_coverage_kernel(CoverGather g, i64
 #pragma unroll
     for (int q = 0; q < 8; q++) g.part[q][k] = 0;
   }
-  if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; }
+  if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; nextInfo->n_unplaced = 0; }
   if (k >= m) return;
   const int pe = g.posE[k];
   u64 c = 0;

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgtx.so")
 READS_SORTED = 1
 CHECK_SORTED = 2
 ZERO_LENGTH_OK = 4
+GAPS_FORMULA = 8
 REFS_KEEP_ZERO_LENGTH = 1
 
 _lib = None
@@ -26,7 +27,7 @@ class GtxError(RuntimeError):
 
 class CountInfo(ctypes.Structure):
     _fields_ = [("first_unsorted", ctypes.c_int64), ("n_no_class", ctypes.c_int64),
-                ("n_degenerate", ctypes.c_int64), ("first_degenerate", ctypes.c_int64)]
+                ("n_degenerate", ctypes.c_int64), ("first_degenerate", ctypes.c_int64), ("n_unplaced", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -40,6 +41,8 @@ ABI = {
     "gtx_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "gtx_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_host_alloc": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_size_t]),
+    "gtx_host_free": (None, [ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_set_refs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]),
     "gtx_set_refs_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32]),
     "gtx_n_refs": (ctypes.c_int64, [ctypes.c_void_p]),
@@ -148,6 +151,24 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.gtx_sync(self.ctx))
+
+    def pinned_array(self, shape, dtype=np.int32):
+        """numpy array over page-locked memory from gtx_host_alloc (the DMA engine reads it without a staging copy).
+        The memory lives until free_pinned(array) or the end of the process."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.gtx_host_alloc(self.ctx, max(n, 1))
+        if not p:
+            raise GtxError(self.lib.gtx_last_error(self.ctx).decode())
+        buf = (ctypes.c_char * max(n, 1)).from_address(p)
+        a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def free_pinned(self, a):
+        p = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        if p:
+            self.lib.gtx_host_free(self.ctx, ctypes.c_void_p(p))
 
     def set_refs(self, refs, n_classes=0, flags=0):
         refs = _triples(refs)

@@ -16,7 +16,7 @@
  *   - regions are packed int32 triples (class_id, start, end), 1-based inclusive coordinates,
  *     exactly what GenomicRegionBED::Read produces from a BED3..BED6 line
  *     (genomic_intervals.cpp:2157-2172: start = atol(col2)+1, stop = atol(col3)).
- *     Coordinates must be < 2^31-1.
+ *     Coordinates must lie in (-2^31+2, 2^31-2) (the kernels keep +-inf sentinels beyond them).
  *   - class_id = rank of the chromosome name in strcmp order (genomic_intervals.cpp:1227), so
  *     id order == the sort order -S expects; for strand-aware runs the caller folds the strand
  *     into the id (any injective mapping works; (strand, chrom) major order keeps a
@@ -33,6 +33,7 @@
 #ifndef GTX_H
 #define GTX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -62,12 +63,25 @@ typedef struct gtx_ctx gtx_ctx;
                                    (start == end+1, BED start == end) IS counted, as
                                    SortedGenomicRegionSetOverlaps does (genomic_intervals.cpp:5903-5918
                                    has no start<=stop check); only start > end+1 is reported as
-                                   degenerate.  Scans: GTX_ZERO_LENGTH_OK selects the sorted scanner's
+                                   degenerate.  On a reference set given with GTX_REFS_KEEP_ZERO_LENGTH the
+                                   call has the merge's semantics in full: an inverted read or region
+                                   (start > end+1) matches by the two comparisons of CalcDirection
+                                   (:1225-1236) -- q.start <= r.stop and q.stop >= r.start -- like any other;
+                                   such reads are still counted in n_degenerate, for information.
+                                   Scans: GTX_ZERO_LENGTH_OK selects the sorted scanner's
                                    rule (no validity test, genomic_intervals.cpp:4933-4947).       */
+#define GTX_GAPS_FORMULA     8u  /* gtx_coverage*: the overlap of a matching pair is min(ends) - max(starts) + 1 without
+                                   clamping at 0 -- what CalcIndexCoverage computes under match_gaps
+                                   (genomic_intervals.cpp:5278); it differs from the clamped CalcOverlap (:427-432)
+                                   only for pairs with an inverted interval, so it matters only together with
+                                   GTX_ZERO_LENGTH_OK on a GTX_REFS_KEEP_ZERO_LENGTH reference set            */
 #define GTX_CHECK_SORTED    2u  /* also verify the order the sorted merge requires
                                    (SortedGenomicRegionSetOverlaps::NextQuery,
                                    genomic_intervals.cpp:5889-5898) and report the first
-                                   violation in gtx_count_info.first_unsorted                  */
+                                   violation in gtx_count_info.first_unsorted.  Only the streaming
+                                   kernel looks at the order of the reads, so this flag selects it
+                                   whether or not GTX_READS_SORTED is given (counts stay exact for
+                                   any order; unsorted input is only slower that way)          */
 
 /* what one count/scan call observed; valid after the call's stream has been synchronised
  * (gtx_count/gtx_scan synchronise themselves; after a *_device call use gtx_sync). */
@@ -79,6 +93,9 @@ typedef struct {
                                 caller applies the reference's rule for them (error exit in the
                                 unsorted algorithm, genomic_intervals.cpp:5740-5741)           */
   int64_t first_degenerate;  /* index of the first such read, -1 if none                       */
+  int64_t n_unplaced;        /* sorted-merge semantics only: inverted reads (start > end+1) beyond the
+                                capacity of the side buffer (2^20) that could NOT be matched -- nonzero
+                                means the result is incomplete and the caller must treat it as an error */
 } gtx_count_info;
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -90,8 +107,19 @@ void        gtx_destroy(gtx_ctx *ctx);
 const char *gtx_last_error(const gtx_ctx *ctx);
 /* All later work is enqueued on this hipStream_t (NULL = the default stream). */
 int         gtx_set_stream(gtx_ctx *ctx, void *hip_stream);
-/* hipStreamSynchronize on the context's stream. */
+/* Waits for everything the context has enqueued (its stream and its host->device copy stream). */
 int         gtx_sync(gtx_ctx *ctx);
+
+/* Page-locked host memory for the host-buffer entry points (gtx_count[_add], gtx_coverage[_add], gtx_scan).
+ * Those calls stream their input through the device in batches, the host->device copy of one batch under the
+ * kernels of the one before.  Ordinary (pageable) buffers are first moved into page-locked staging slots by a few
+ * host threads and are free again when the call returns.  Buffers from gtx_host_alloc are read by the DMA engine
+ * directly -- no staging copy -- and the call returns with the copy still in flight: such a buffer must stay
+ * untouched until the context's NEXT host-buffer call, gtx_*_end or gtx_sync has returned (a producer that fills
+ * two of them in turn -- what the reference's streaming GenomicRegionSet::Next loop, genomic_intervals.cpp:3855-3861,
+ * becomes here -- never waits). */
+void       *gtx_host_alloc(gtx_ctx *ctx, size_t bytes);
+void        gtx_host_free(gtx_ctx *ctx, void *p);
 
 /* ---- index side ------------------------------------------------------------------------- */
 
@@ -104,8 +132,10 @@ int         gtx_sync(gtx_ctx *ctx);
 int gtx_set_refs(gtx_ctx *ctx, const int32_t *ref_triples, int64_t n_refs, int32_t n_classes);
 /* flags for gtx_set_refs_ex */
 #define GTX_REFS_KEEP_ZERO_LENGTH 1u   /* sorted-merge semantics: the merge never validates index
-                                          regions, so zero-length ones (start == end+1) and ones with
-                                          end <= 0 take part; start > end+1 still never matches here */
+                                          regions, so zero-length ones (start == end+1), ones with
+                                          end <= 0 and inverted ones (start > end+1) all take part
+                                          (the last only in calls made with GTX_ZERO_LENGTH_OK)      */
+/* A region with class id -1 is a placeholder: it keeps its place in the numbering and never matches. */
 int gtx_set_refs_ex(gtx_ctx *ctx, const int32_t *ref_triples, int64_t n_refs, int32_t n_classes, uint32_t flags);
 int64_t gtx_n_refs(const gtx_ctx *ctx);
 

@@ -401,3 +401,107 @@ def test_packed_inputs_for_peaks(packed):
     pk = product("scans", base + ["peaks_signal.gtx", "peaks_control.gtx"], cwd=packed)
     assert pk[0] == text[0] == 0 and pk[1] == text[1] and len(pk[1]) > 100
     assert pk[2].replace(".gtx", ".bed") == text[2]
+
+
+# ---- sorted merge (-S): what the reference does with an index set that is out of order, and with inverted intervals ------------
+def write_lines(path, rows):
+    with open(path, "w") as f:
+        for r in rows:
+            f.write("\t".join(str(x) for x in r) + "\n")
+
+
+@pytest.fixture(scope="module")
+def merge_beds(tmp_path_factory):
+    d = tmp_path_factory.mktemp("merge")
+    rng = np.random.default_rng(71)
+    names = ["chr1", "chr10", "chr2"]
+    # index set sorted up to line 300 (0-based ordinal), then out of order; reads that stop before / go past that spot
+    def regs(n, lo, hi, maxlen):
+        c = np.sort(rng.integers(0, 3, size=n)); s = rng.integers(lo, hi, size=n); e = s + rng.integers(0, maxlen, size=n)
+        o = np.lexsort((s, c))
+        return c[o], s[o], e[o]
+    c, s, e = regs(400, 1000, 900_000, 3000)
+    st = rng.choice(["+", "-"], size=400)
+    rows = [[names[c[i]], s[i], e[i], "g%d" % i, 0, st[i]] for i in range(400)]
+    rows_bad = list(rows)
+    rows_bad[300], rows_bad[301] = rows_bad[301], rows_bad[300]                      # disorder at ordinal 301 (class chr2)
+    if rows_bad[300][1] == rows_bad[301][1]:
+        rows_bad[301][1] -= 1
+    write_lines(d / "refs_ok.bed", rows)
+    write_lines(d / "refs_disorder.bed", rows_bad)
+    qc, qs, qe = regs(20000, 1000, 900_000, 200)
+    ql = rng.integers(0, 5, size=20000); qst = rng.choice(["+", "-"], size=20000)
+    q = [[names[qc[i]], qs[i], qe[i], ql[i], 0, qst[i]] for i in range(20000)]
+    write_lines(d / "reads_all.bed", q)                                               # reaches chr2: the merge gets to the bad spot
+    stop_at = rows_bad[300][1]
+    early = [r for r in q if r[0] != "chr2" or r[2] < min(rows[295][1], stop_at) - 5000]
+    write_lines(d / "reads_early.bed", early)                                         # ends well before it: counts, exit 0
+    write_lines(d / "reads_chr1.bed", [r for r in q if r[0] == "chr1"])
+    write_lines(d / "reads_unknown_last.bed", [r for r in q if r[0] == "chr1"] + [["chrZ", 5, 9, 1, 0, "+"]])   # an unknown chromosome pulls everything
+    # a query that is itself out of order BEFORE the merge reaches the bad spot: the query error wins
+    qq = [r for r in q if r[0] != "chr2"]
+    qq[100], qq[101] = qq[101], qq[100]
+    if qq[100][1] == qq[101][1]:
+        qq[101][1] -= 1
+    write_lines(d / "reads_query_disorder.bed", qq + [r for r in q if r[0] == "chr2"])
+    # inverted and zero-length intervals on both sides (BED start > end), sorted by start
+    ic, is_, ie = regs(300, 1000, 200_000, 2000)
+    irows = []
+    for i in range(300):
+        e2 = ie[i]
+        if i % 17 == 0: e2 = is_[i] - int(rng.integers(1, 400))                     # inverted: BED end < start
+        if i % 23 == 0: e2 = is_[i]                                                  # zero length: BED start == end
+        irows.append([names[ic[i]], is_[i], e2, "h%d" % i, 0, "+-"[i % 2]])
+    write_lines(d / "refs_inverted.bed", irows)
+    jc, js, je = regs(30000, 500, 210_000, 300)
+    jrows = []
+    for i in range(30000):
+        e2 = je[i]
+        if i % 101 == 0: e2 = js[i] - int(rng.integers(1, 600))
+        if i % 211 == 0: e2 = js[i]
+        jrows.append([names[jc[i]], js[i], e2, int(rng.integers(0, 6)), 0, "+-"[int(rng.integers(0, 2))]])
+    write_lines(d / "reads_inverted.bed", jrows)
+    return d
+
+
+MERGE_RUNS = [
+    ["count", "-S", "-i", "refs_disorder.bed", "reads_early.bed"],          # disorder behind the last query: counts, rc 0
+    ["count", "-S", "refs_disorder.bed", "reads_chr1.bed"],
+    ["count", "-S", "-i", "refs_disorder.bed", "reads_all.bed"],            # the merge reaches it: the reference's error
+    ["count", "-S", "-i", "refs_disorder.bed", "reads_unknown_last.bed"],   # a query on a chromosome behind all of the index pulls all of it
+    ["count", "-S", "-i", "refs_disorder.bed", "reads_query_disorder.bed"], # the query error comes first
+    ["coverage", "-S", "-i", "refs_disorder.bed", "reads_early.bed"],
+    ["coverage", "-S", "-i", "refs_disorder.bed", "reads_all.bed"],
+    ["count", "-S", "-i", "refs_ok.bed", "reads_all.bed"],
+    ["count", "-S", "-i", "refs_inverted.bed", "reads_inverted.bed"],       # inverted intervals follow CalcDirection, no error
+    ["count", "-S", "refs_inverted.bed", "reads_inverted.bed"],
+    ["count", "-S", "-i", "--max-label-value", "4", "refs_inverted.bed", "reads_inverted.bed"],
+    ["coverage", "-S", "-i", "refs_inverted.bed", "reads_inverted.bed"],
+    ["coverage", "-S", "-i", "-gaps", "--max-label-value", "3", "refs_inverted.bed", "reads_inverted.bed"],
+    ["coverage", "-S", "-gaps", "refs_inverted.bed", "reads_inverted.bed"],
+    ["count", "-S", "-i", "-gaps", "refs_inverted.bed", "reads_inverted.bed"],
+    ["density", "-S", "-i", "refs_inverted.bed", "reads_inverted.bed"],
+    ["count", "-i", "refs_inverted.bed", "reads_early.bed"],                # bin index: invalid index regions are skipped
+    ["count", "-i", "refs_ok.bed", "reads_inverted.bed"],                   # bin index: the inverted query is the reference's error
+]
+
+
+@pytest.mark.parametrize("args", MERGE_RUNS, ids=[" ".join(a) for a in MERGE_RUNS])
+def test_sorted_merge_cli_equals_oracle_cli(merge_beds, args):
+    want = oracle(args, cwd=merge_beds)
+    got = product("overlaps", args, cwd=merge_beds)
+    assert got[0] == want[0], (got[2], want[2])
+    assert got[1] == want[1]
+    assert got[2].strip() == want[2].strip()
+
+
+def test_sorted_merge_cli_cases_are_what_they_claim(merge_beds):
+    """The fixture really produces both outcomes of the lazy order check (so the parity above is not vacuous)."""
+    rc, out, err = oracle(["count", "-S", "-i", "refs_disorder.bed", "reads_early.bed"], cwd=merge_beds)
+    assert rc == 0 and len(out.splitlines()) == 400
+    rc, out, err = oracle(["count", "-S", "-i", "refs_disorder.bed", "reads_all.bed"], cwd=merge_beds)
+    assert rc == 1 and out == "" and "Line 301: index regions are not sorted" in err
+    rc, out, err = oracle(["count", "-S", "-i", "refs_disorder.bed", "reads_query_disorder.bed"], cwd=merge_beds)
+    assert rc == 1 and "query regions are not sorted" in err
+    rc, out, err = oracle(["count", "-S", "-i", "refs_inverted.bed", "reads_inverted.bed"], cwd=merge_beds)
+    assert rc == 0 and len(out.splitlines()) == 300

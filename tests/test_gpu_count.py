@@ -10,7 +10,17 @@ pytestmark = pytest.mark.gpu
 
 
 def both_oracles(refs, reads, weights=None):
+    """The oracle's two restated algorithms (bin index and sorted merge) wherever both apply: reads sorted by
+    (class, start) and regions the merge accepts; otherwise the bin index alone."""
     a = orc.count(refs, reads, weights, algo=orc.BIN_INDEX)
+    n = len(reads)
+    in_order = n < 2 or bool(np.all((reads[1:, 0] > reads[:-1, 0]) | ((reads[1:, 0] == reads[:-1, 0]) & (reads[1:, 1] >= reads[:-1, 1]))))
+    refs = np.asarray(refs)
+    if in_order and len(refs) and bool(np.all((refs[:, 1] <= refs[:, 2]) & (refs[:, 2] > 0))) and bool(np.all(reads[:, 1] <= reads[:, 2])):
+        order = np.lexsort((refs[:, 1], refs[:, 0]))               # the merge wants the index set sorted; counts go back to file order
+        b = np.empty_like(a)
+        b[order] = orc.count(refs[order], reads, weights, algo=orc.SORTED_MERGE)
+        np.testing.assert_array_equal(a, b)
     return a
 
 
@@ -348,3 +358,235 @@ def test_weighted_fast_path_and_its_fallbacks(engine):
             w[big] = rng.integers(1 << 22, (1 << 31) - 1, size=200)            # steps holding one of these fall back
             w[rng.integers(0, n, size=50)] = -(1 << 30)
         check(engine, refs, reads, w.astype(np.int32), n_classes=synth.n_classes())
+
+
+def first_violation(reads):
+    bad = (reads[1:, 0] < reads[:-1, 0]) | ((reads[1:, 0] == reads[:-1, 0]) & (reads[1:, 1] < reads[:-1, 1]))
+    nz = np.nonzero(bad)[0]
+    return int(nz[0]) + 1 if len(nz) else -1
+
+
+def test_check_sorted_without_the_sorted_hint(engine):
+    """GTX_CHECK_SORTED alone (no GTX_READS_SORTED): the order is still verified -- the flag selects the streaming kernel,
+    which is exact for any order -- on shuffled reads, on sorted reads, and over several batches of one stream."""
+    rng = np.random.default_rng(91)
+    refs = synth.genome_intervals(20000, 91, 50, 2000)
+    reads = synth.genome_intervals(300000, 92, 50, 51)
+    shuffled = reads[rng.permutation(len(reads))]
+    engine.set_refs(refs, synth.n_classes())
+    hits, info = engine.count(shuffled, None, gtx.CHECK_SORTED)
+    np.testing.assert_array_equal(hits, orc.count(refs, shuffled, algo=orc.BIN_INDEX))
+    assert info["first_unsorted"] == first_violation(shuffled)
+    hits, info = engine.count(reads, None, gtx.CHECK_SORTED)
+    np.testing.assert_array_equal(hits, orc.count(refs, reads, algo=orc.BIN_INDEX))
+    assert info["first_unsorted"] == -1
+    late = reads.copy()
+    late[[250000, 250001]] = late[[250001, 250000]]
+    if late[250000, 1] == late[250001, 1]:
+        late[250001, 1] -= 1
+    cuts = [0, 100000, 250001, len(reads)]
+    _, info = engine.count_stream([(late[a:b], None) for a, b in zip(cuts[:-1], cuts[1:])], gtx.CHECK_SORTED)
+    assert info["first_unsorted"] == 250001
+
+
+def test_page_locked_source_and_many_batches():
+    """Host buffers from gtx_host_alloc are read by the DMA engine directly (no staging copy), pageable ones go through
+    the pinned slots; both are double-buffered over many small batches and must give the oracle's counts, info included."""
+    import os
+    os.environ["GTX_BATCH_READS"] = "30000"
+    try:
+        e = gtx.Engine(0)
+    finally:
+        del os.environ["GTX_BATCH_READS"]
+    rng = np.random.default_rng(93)
+    refs = synth.genome_intervals(8000, 93, 50, 3000)
+    reads = synth.genome_intervals(400_003, 94, 30, 400)
+    reads[123456, 0] = 99                                           # unknown class
+    reads[300000, 2] = reads[300000, 1] - 5                         # degenerate
+    w = rng.integers(0, 4, size=len(reads)).astype(np.int32)
+    e.set_refs(refs, synth.n_classes())
+    want = orc.count(refs, np.delete(reads, [300000], axis=0), np.delete(w, [300000]))
+    pr = e.pinned_array(reads.shape); pr[:] = reads
+    pw = e.pinned_array(w.shape); pw[:] = w
+    for rr, ww in ((reads, w), (pr, pw), (pr, None), (reads, None)):
+        for flags in (gtx.READS_SORTED, 0):
+            hits, info = e.count(rr, ww, flags)
+            ref = want if ww is not None else orc.count(refs, np.delete(reads, [300000], axis=0))
+            np.testing.assert_array_equal(hits, ref)
+            assert info["n_no_class"] == 1 and info["n_degenerate"] == 1 and info["first_degenerate"] == 300000
+    # two page-locked producer buffers filled in turn (the contract of gtx_host_alloc): reuse after the NEXT call returned
+    bufs = [e.pinned_array((50_000, 3)), e.pinned_array((50_000, 3))]
+    lib, ctx = e.lib, e.ctx
+    assert lib.gtx_count_begin(ctx) == 0
+    for i, at in enumerate(range(0, len(reads), 50_000)):
+        part = reads[at:at + 50_000]
+        b = bufs[i & 1]
+        b[:len(part)] = part
+        assert lib.gtx_count_add(ctx, b.ctypes.data, None, len(part), gtx.READS_SORTED) == 0
+    hits = np.zeros(len(refs), dtype=np.uint64)
+    assert lib.gtx_count_end(ctx, hits.ctypes.data, None) == 0
+    np.testing.assert_array_equal(hits, orc.count(refs, np.delete(reads, [300000], axis=0)))
+    win, _ = e.scan(pr, synth.CHROM_LEN, 1000, 3000, weights=pw)
+    valid = np.delete(np.arange(len(reads)), [123456, 300000])
+    want_w, _ = orc.scan(reads[valid], synth.CHROM_LEN, 1000, 3000, weights=w[valid])
+    np.testing.assert_array_equal(win, want_w)
+    cov, _ = e.coverage(pr, pw)
+    np.testing.assert_array_equal(cov, orc.coverage(refs, reads[valid], w[valid]))
+    e.close()
+
+
+def test_abandoned_call_leaves_no_stale_info(engine):
+    """A count stream that is begun, fed and never ended must not leak its n_no_class / n_degenerate into the next call
+    of either kind (count and coverage share the info block)."""
+    refs = synth.genome_intervals(5000, 95, 50, 2000)
+    reads = synth.genome_intervals(50000, 96, 50, 51)
+    junk = reads.copy(); junk[:, 0] = 77                              # all of an unknown class
+    engine.set_refs(refs, synth.n_classes())
+    lib, ctx = engine.lib, engine.ctx
+    assert lib.gtx_count_begin(ctx) == 0
+    assert lib.gtx_count_add(ctx, junk.ctypes.data, None, len(junk), gtx.READS_SORTED) == 0
+    cov, info = engine.coverage(reads)                                # the count stream above is abandoned
+    assert info["n_no_class"] == 0 and info["n_degenerate"] == 0
+    np.testing.assert_array_equal(cov, orc.coverage(refs, reads))
+    assert lib.gtx_coverage_begin(ctx) == 0
+    assert lib.gtx_coverage_add(ctx, junk.ctypes.data, None, len(junk), 0) == 0
+    hits, info = engine.count(reads)                                  # ... and the other way round
+    assert info["n_no_class"] == 0
+    np.testing.assert_array_equal(hits, orc.count(refs, reads))
+
+
+def test_extreme_coordinates(engine):
+    """Coordinates at the edge of the packed representation (|x| up to 2^31-3) on every path: streaming kernel, per-read
+    search kernel, bucket path (forced for a small batch)."""
+    import os
+    top = 2**31 - 3
+    rng = np.random.default_rng(97)
+    refs = synth.genome_intervals(30000, 97, 50, 2000)
+    refs = np.concatenate([refs, np.array([[0, 1, top], [0, top - 5, top], [5, top, top], [23, 100, top]], dtype=np.int32)])
+    reads = synth.genome_intervals(300000, 98, 50, 51)
+    extra = np.array([[0, top, top], [0, 1, top], [0, top - 1, top], [5, 7, top], [23, top - 3, top - 2], [23, 248_000_000, top]], dtype=np.int32)
+    reads = np.concatenate([reads, extra])
+    reads = reads[np.lexsort((reads[:, 1], reads[:, 0]))]
+    want = orc.count(refs, reads, algo=orc.BIN_INDEX)
+    engine.set_refs(refs, synth.n_classes())
+    for rr in (reads, reads[rng.permutation(len(reads))]):
+        for flags in (gtx.READS_SORTED, 0):
+            hits, info = engine.count(rr, None, flags)
+            np.testing.assert_array_equal(hits, want)
+            assert info["n_degenerate"] == 0
+    os.environ["GTX_BUCKET_MIN_READS"] = "1"
+    try:
+        e = gtx.Engine(0)
+    finally:
+        del os.environ["GTX_BUCKET_MIN_READS"]
+    e.set_refs(refs, synth.n_classes())
+    hits, _ = e.count(reads[rng.permutation(len(reads))], None, 0)
+    np.testing.assert_array_equal(hits, want)
+    e.close()
+
+
+def test_config5_1b_reads_2m_refs(engine):
+    """BASELINE config 5, count part: 1 B reads (12 GB resident in HBM) x 2 M regions over the 24 hg38 chromosomes.
+    The CPU oracle does not run at this size, so: (i) counts are additive over a split of the stream into uneven parts,
+    (ii) the grand total equals the sum over the parts, (iii) one chromosome's regions are checked against the oracle on
+    that chromosome's ~15 M reads, (iv) nothing was dropped (no degenerate / unknown-class reads)."""
+    torch = pytest.importorskip("torch")
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 1_000_000_000
+    dev = torch.device("cuda", 0)
+    reads = bench.make_reads_on_device(n, np.arange(24), 55, dev)
+    refs = synth.genome_intervals(2_000_000, 45, 50, 2000)
+    engine.set_refs(refs, 24)
+    engine.set_stream(torch.cuda.current_stream().cuda_stream)
+    whole = torch.zeros(len(refs), dtype=torch.int64, device=dev)
+    part = torch.zeros_like(whole)
+    acc = torch.zeros_like(whole)
+    engine.count_device(reads.data_ptr(), n, whole.data_ptr())
+    info = engine.last_info()
+    assert info["n_degenerate"] == 0 and info["n_no_class"] == 0
+    cuts = [0, 3, 333_333_333, 700_000_001, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        engine.count_device(reads[a:b].data_ptr(), b - a, part.data_ptr())
+        acc += part
+    engine.sync()
+    engine.set_stream(0)
+    assert torch.equal(whole, acc)
+    c = int(np.argmin(synth.CHROM_LEN))                               # the shortest chromosome: ~1.5 % of the reads
+    sub = reads[reads[:, 0] == c].cpu().numpy()
+    assert 5_000_000 < len(sub) < 40_000_000
+    rsel = np.nonzero(refs[:, 0] == c)[0]
+    want = orc.count(refs[rsel], sub, algo=orc.SORTED_MERGE)
+    np.testing.assert_array_equal(whole.cpu().numpy().view(np.uint64)[rsel], want)
+    # every read overlaps the regions it overlaps: grand total = sum over reads of its overlap count, checked on the sample's class
+    assert int(whole.sum().item()) > n // 2
+
+
+def merge_inputs(rng, m, n, nc, span, inv_refs, inv_reads):
+    def mk(k, inv_p):
+        c = rng.integers(0, nc, size=k); s = rng.integers(-5, span, size=k)
+        e = s + rng.integers(0, 400, size=k) - 1                     # zero-length ones included (e = s - 1)
+        e = np.where(rng.random(k) < inv_p, s - rng.integers(2, 300, size=k), e)
+        a = np.stack([c, s, e], 1).astype(np.int32)
+        return a[np.lexsort((a[:, 1], a[:, 0]))]
+    return mk(m, inv_refs), mk(n, inv_reads)
+
+
+@pytest.mark.parametrize("m,n,inv_refs,inv_reads", [(3000, 200_000, 0.0, 0.001), (3000, 200_000, 0.01, 0.0), (5000, 300_000, 0.02, 0.01),
+                                                    (40, 500, 0.3, 0.3), (2000, 600_000, 0.001, 0.0005)])
+def test_sorted_merge_semantics_with_inverted_intervals(engine, m, n, inv_refs, inv_reads):
+    """GTX_ZERO_LENGTH_OK on a GTX_REFS_KEEP_ZERO_LENGTH reference set = the merge's matching rule for ANY interval
+    (genomic_intervals.cpp:1225-1236, :5844-5918): inverted reads and regions take part by the two comparisons.  Against the
+    restated merge, on the streaming kernel, the per-read search kernel and the bucket path, weighted and not, in one call
+    and over several batches."""
+    rng = np.random.default_rng(m + n)
+    refs, reads = merge_inputs(rng, m, n, 5, 3_000_000, inv_refs, inv_reads)
+    w = rng.integers(-2, 6, size=n).astype(np.int32)
+    engine.set_refs(refs, 5, gtx.REFS_KEEP_ZERO_LENGTH)
+    n_inv = int((reads[:, 1] > reads[:, 2] + 1).sum())
+    for ww in (None, w):
+        want = orc.count(refs, reads, ww, algo=orc.SORTED_MERGE)
+        for flags in (gtx.READS_SORTED, 0):
+            hits, info = engine.count(reads, ww, flags | gtx.ZERO_LENGTH_OK)
+            np.testing.assert_array_equal(hits, want)
+            assert info["n_degenerate"] == n_inv and info["n_unplaced"] == 0
+        cuts = [0, n // 3, n // 3 + 1, n]
+        hits, _ = engine.count_stream([(reads[a:b], None if ww is None else ww[a:b]) for a, b in zip(cuts[:-1], cuts[1:])],
+                                      gtx.READS_SORTED | gtx.ZERO_LENGTH_OK)
+        np.testing.assert_array_equal(hits, want)
+        cov, _ = engine.coverage(reads, ww, gtx.ZERO_LENGTH_OK)                      # clamped overlaps: inverted intervals add nothing
+        np.testing.assert_array_equal(cov, orc.coverage(refs, reads, ww, algo=orc.SORTED_MERGE))
+    # the call after one with inverted reads starts clean
+    plain = reads[reads[:, 1] <= reads[:, 2] + 1]
+    hits, info = engine.count(plain, None, gtx.READS_SORTED | gtx.ZERO_LENGTH_OK)
+    np.testing.assert_array_equal(hits, orc.count(refs, plain, algo=orc.SORTED_MERGE))
+    assert info["n_degenerate"] == 0
+
+
+def test_gaps_coverage_formula_with_inverted_intervals(engine):
+    """CalcIndexCoverage under match_gaps adds min(stops) - max(starts) + 1 per match WITHOUT clamping at 0
+    (genomic_intervals.cpp:5278): pairs with an inverted interval subtract.  GTX_GAPS_FORMULA against a direct evaluation."""
+    rng = np.random.default_rng(123)
+    refs, reads = merge_inputs(rng, 800, 60_000, 3, 400_000, 0.02, 0.01)
+    w = rng.integers(0, 5, size=len(reads)).astype(np.int32)
+    engine.set_refs(refs, 3, gtx.REFS_KEEP_ZERO_LENGTH)
+    cov, info = engine.coverage(reads, w, gtx.ZERO_LENGTH_OK | gtx.GAPS_FORMULA)
+    want = np.zeros(len(refs), dtype=np.uint64)
+    for k in range(len(refs)):
+        c, rs, re = map(int, refs[k])
+        sel = (reads[:, 0] == c) & (reads[:, 1] <= re) & (reads[:, 2] >= rs)
+        ov = np.minimum(reads[sel, 2], re).astype(np.int64) - np.maximum(reads[sel, 1], rs) + 1
+        want[k] = np.uint64(int((ov * w[sel]).sum()) % (1 << 64))
+    np.testing.assert_array_equal(cov, want)
+    assert info["n_unplaced"] == 0
+
+
+def test_placeholder_regions_never_match(engine):
+    refs = np.array([[0, 100, 200], [-1, 1, 0], [0, 150, 300], [-1, 120, 130]], dtype=np.int32)
+    reads = np.array([[0, 90, 160], [0, 125, 126], [0, 290, 400]], dtype=np.int32)
+    for fl in (0, gtx.REFS_KEEP_ZERO_LENGTH):
+        engine.set_refs(refs, 1, fl)
+        hits, _ = engine.count(reads, None, gtx.READS_SORTED | (gtx.ZERO_LENGTH_OK if fl else 0))
+        assert hits.tolist() == [2, 0, 2, 0]

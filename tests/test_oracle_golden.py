@@ -105,3 +105,30 @@ def test_scanners_agree(step, size):
         nw = max(0, n - comb + 1)
         want = np.array([v[k:k + comb].sum() for k in range(nw)], dtype=np.uint64)
         np.testing.assert_array_equal(a[off[c]:off[c] + nw], want)
+
+
+def test_sorted_merge_is_the_two_sided_condition_for_any_interval():
+    """The restated merge (LoadIndexBuffer / GetMatch loop, genomic_intervals.cpp:5844-5918) on start-sorted inputs matches
+    a query q and an index region r iff q.start <= r.stop and q.stop >= r.start -- whatever the order of start and stop
+    inside either interval (zero-length and inverted ones included).  This is the closed form the device path implements
+    (rank difference + pair kernels); coverage adds max(0, min(stops) - max(starts) + 1) per match."""
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        nc = int(rng.integers(1, 4)); m = int(rng.integers(0, 25)); n = int(rng.integers(0, 40)); span = int(rng.integers(5, 60))
+
+        def mk(k, inv_p):
+            c = rng.integers(0, nc, size=k); s = rng.integers(-3, span, size=k)
+            e = s + rng.integers(0, 15, size=k) - 1
+            e = np.where(rng.random(k) < inv_p, s - rng.integers(1, 8, size=k), e)
+            a = np.stack([c, s, e], 1).astype(np.int32)
+            return a[np.lexsort((a[:, 1], a[:, 0]))]
+        refs, reads = mk(m, rng.choice([0, 0.2, 0.5])), mk(n, rng.choice([0, 0.2, 0.5]))
+        w = rng.integers(-2, 5, size=n).astype(np.int32)
+        cnt, cov = np.zeros(m, dtype=np.uint64), np.zeros(m, dtype=np.uint64)
+        for k in range(m):
+            c, rs, re = map(int, refs[k])
+            sel = (reads[:, 0] == c) & (reads[:, 1] <= re) & (reads[:, 2] >= rs)
+            ov = np.maximum(np.minimum(reads[sel, 2], re).astype(np.int64) - np.maximum(reads[sel, 1], rs) + 1, 0)
+            cnt[k] = np.uint64(int(w[sel].sum()) % (1 << 64)); cov[k] = np.uint64(int((ov * w[sel]).sum()) % (1 << 64))
+        np.testing.assert_array_equal(orc.count(refs, reads, w, algo=orc.SORTED_MERGE), cnt)
+        np.testing.assert_array_equal(orc.coverage(refs, reads, w, algo=orc.SORTED_MERGE), cov)
