@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric: overlap-counted reads/sec, 100M reads x 1M ref intervals (config 3).
 
-One step = one pass of the hot path (gtx_count_device: memsets + streaming count kernel + prefix /
-gather kernels) over one batch of 100M synthetic 50 bp reads, sorted by (chromosome, start), already
-resident in HBM, against 1M reference intervals spread over the 24 hg38 chromosomes, strand ignored
-(`genomic_overlaps count -S -i`).  N GPUs = one process per GPU (torch.distributed / RCCL): the
-chromosomes are dealt to the ranks (LPT), every rank counts its own 100M reads on its chromosomes
-against the replicated reference set, and the per-region count vector is summed with one all-reduce
-over xGMI per step (entries of different ranks are disjoint, so the sum is the global vector).
-Weak scaling: per-GPU work is fixed.
+One step = one pass of the hot path (gtx_count_device: streaming count kernel + prefix / gather kernels) over the
+synthetic 50 bp reads, sorted by (chromosome, start), already resident in HBM, against 1M reference intervals spread
+over the 24 hg38 chromosomes, strand ignored (`genomic_overlaps count -S -i`).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the streaming count kernel: algorithmic bytes
-(12 B per read) / its mean duration measured with HIP events on the launch stream inside the timed
-loop.  `cpu_baseline` is the CPU oracle (sorted-merge restatement of the reference) on a bounded
-sample of the same reads, single thread, on this box's host cores; its counts are also compared
-with the GPU's (full-size parity check of the sample).
+N GPUs = one process per GPU (torch.distributed / RCCL).  ONE global read set -- N x 100M reads (default, "weak": the work
+per GPU stays ~fixed as N grows) or --reads in total (--scaling strong) -- is apportioned to the chromosomes in proportion
+to their length; the chromosomes are dealt to the ranks by the product's own longest-processing-time packing
+(gtx_lpt_assign of libgtx.so) of the per-chromosome read counts, so the ranks' shares are NOT equal: the line carries
+`reads_per_rank` and `imbalance` (max / mean), and `value` = all reads / the slowest rank's time.  Every rank counts its
+chromosomes' reads against the replicated reference set and the per-region uint64 vector is reduced (sum) to rank 0 over
+xGMI each step -- vectors of different ranks are disjoint by chromosome, so the sum is the one-GPU vector.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the streaming count kernel of rank 0: algorithmic bytes (12 B per read)
+/ its mean duration measured with HIP events on the launch stream inside the timed loop.  `cpu_baseline` is the CPU
+oracle (sorted-merge restatement of the reference) on a bounded sample of the same reads, single thread, on this box's
+host cores; its counts are also compared with the GPU's (parity check of the sample).  At N = 1 the line also carries
+`host_to_result` (packed host arrays -> counts on the host, PCIe included) and `text_to_stdout` (the product CLI from BED
+text / a packed region file to its last output line) -- reported beside `value`, never part of it.
 """
 import argparse
 import json
@@ -43,17 +47,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 READ_LEN = 50
 
 
-def make_reads_on_device(n, chrom_ids, seed, device):
-    """n reads of READ_LEN bp on the given chromosomes (proportional to length), sorted by (class, start)."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    per = synth.apportion(n, synth.CHROM_LEN[chrom_ids])
+def make_reads_on_device(n, chrom_ids, seed, device, per=None):
+    """n reads of READ_LEN bp on the given chromosomes (proportional to length, or `per` reads on each), sorted by
+    (class, start).  The reads of a chromosome depend on (seed, chromosome) only, not on which rank makes them."""
+    if per is None:
+        per = synth.apportion(n, synth.CHROM_LEN[chrom_ids])
+    n = int(np.sum(per))
     out = torch.empty((n, 3), dtype=torch.int32, device=device)
     at = 0
     for ci, cnt in zip(chrom_ids, per):
         cnt = int(cnt)
         if cnt == 0:
             continue
+        g = torch.Generator(device=device)
+        g.manual_seed(int(seed) * 1000 + int(ci))
         s = torch.randint(1, int(synth.CHROM_LEN[ci]) - READ_LEN - 1, (cnt,), device=device, generator=g, dtype=torch.int32)
         s, _ = torch.sort(s)
         out[at:at + cnt, 0] = int(ci)
@@ -87,7 +94,16 @@ def emit(obj):
         os.write(_REAL_STDOUT, line)
 
 
-def bench_scans(args, eng, reads, n, rank, world, device, rehearse):
+def kernel_source_sha16():
+    """identity of the kernel sources a committed PMC profile belongs to (the GPU box has no .git to ask)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gtx_kernels.hip", "gtx_kernels.h", "gtx_capi.hip"):
+        h.update(open(os.path.join(PKG, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads, reads_per_rank):
     """BASELINE config 4: sliding-window read counts (1 kb windows) over the reads of this rank's chromosomes;
     the per-window vectors of the ranks are disjoint by chromosome and are combined with one all-reduce(sum)."""
     step_bp, size_bp = 1000, 1000
@@ -135,18 +151,19 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse):
         eng.sync()
         if not np.array_equal(out.cpu().numpy().view(np.uint64), want):
             sys.exit("PARITY FAILURE: GPU window counts differ from the CPU oracle on the %d-read sample" % ns)
-        cpu = {"value": ns / cpu_s, "unit": "reads/s", "cores": 1, "kind": "port",
+        cpu = {"value": ns / cpu_s, "unit": "reads/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
                "sample": "first %d reads, sorted-scanner restatement (oracle/gtx_oracle.c) on packed triples; windows bit-equal to the GPU's" % ns}
     if rank == 0:
         n_micro = int((synth.CHROM_LEN // step_bp).sum())
         alg = 12.0 * n + 4.0 * n_micro
         emit(({
             "metric": "window-counted reads/sec, genomic_scans counts 1 kb windows (BASELINE config 4)",
-            "value": world * n * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": total_reads * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 4: genomic_scans counts -i -w 1000 -d 1000 over %d 50bp reads/GPU, hg38 chromosome shards, "
-                                   "all-reduce(sum) of the %d-window vector" % (n, tot), "reads_per_gpu": n, "windows": tot},
+            "config": {"workload": "BASELINE config 4: genomic_scans counts -i -w 1000 -d 1000 over %d 50bp reads in total, hg38 chromosome "
+                                   "shards (LPT), all-reduce(sum) of the %d-window vector" % (total_reads, tot), "total_reads": total_reads,
+                       "reads_per_rank": reads_per_rank, "imbalance": max(reads_per_rank) / (sum(reads_per_rank) / world), "windows": tot},
             "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "scan_hist_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes": alg},
@@ -205,7 +222,7 @@ def bench_perm(args, rank, world, local, device, rehearse):
         cpu_s = time.perf_counter() - t1
         if not np.array_equal(e.count_ge("sum", Y, 2024, 0, ps), want) or not np.array_equal(Y.view(np.uint64), porc.statistic(t, "sum").view(np.uint64)):
             sys.exit("PARITY FAILURE: GPU exceed-counts differ from the CPU oracle on the %d-shuffle sample" % ps)
-        cpu = {"value": nnz * ps / cpu_s, "unit": "member-sums/s", "cores": 1, "kind": "port",
+        cpu = {"value": nnz * ps / cpu_s, "unit": "member-sums/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
                "sample": "first %d shuffles of the same table, oracle/perm_oracle.c (permute + per-category sums + compare); "
                          "counts bit-equal to the GPU's" % ps}
     traffic = None                                                        # L2->fabric bytes per launch from the committed --pmc pass of this command
@@ -254,6 +271,10 @@ def main():
                     help="count = BASELINE config 3 (the headline metric); scans = config 4: genomic_scans counts -i -w 1000 -d 1000; "
                          "permutation_test = the shuffle part of config 5")
     ap.add_argument("--shuffles", type=int, default=10000, help="permutation_test: shuffles per GPU per step")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = N x --reads in total (default), strong = --reads in total; either way ONE global read set, "
+                         "sharded by chromosome with the product's LPT packing")
+    ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the host_to_result / text_to_stdout measurements")
     ap.add_argument("--two-streams", action="store_true",
                     help="count, N=1: after the timed region also time the same steps alternating two contexts on two HIP streams "
                          "(extra 'two_streams' object; off by default so that a kernel trace of the default command sees only the timed steps)")
@@ -295,10 +316,16 @@ def main():
 
     # ---- workload -------------------------------------------------------------------------------
     refs = synth.genome_intervals(args.refs, 43, 50, 2000)                 # 1M refs, all chromosomes, every rank
-    shards = shard.rank_chroms(synth.CHROM_LEN, world)                     # chromosomes -> ranks (LPT)
-    my_chroms = np.asarray(shards[rank], dtype=np.int64)
-    reads = make_reads_on_device(args.reads, my_chroms, 1000 + rank, device)
+    # one global read set, apportioned to the chromosomes by length; chromosomes -> ranks by the product's LPT packing of the
+    # per-chromosome read counts (gtx_lpt_assign, the function genomic_overlaps --ngpu uses)
+    total_reads = args.reads * (world if args.scaling == "weak" else 1)
+    per_chrom = synth.apportion(total_reads, synth.CHROM_LEN)
+    owner = gtx.lpt_assign(per_chrom, world)
+    reads_per_rank = [int(per_chrom[owner == r].sum()) for r in range(world)]
+    my_chroms = np.nonzero(owner == rank)[0].astype(np.int64)
+    reads = make_reads_on_device(0, my_chroms, 1000, device, per=per_chrom[my_chroms])
     n = reads.shape[0]
+    assert n == reads_per_rank[rank]
     hits = torch.zeros(len(refs), dtype=torch.int64, device=device)        # uint64 bit pattern; int64 for RCCL sum
     # two count vectors in ping-pong: the all-reduce of step i (RCCL's own stream) overlaps the kernels of step i+1
     hits_pp = [hits, torch.zeros_like(hits)]
@@ -309,7 +336,7 @@ def main():
 
     eng = gtx.Engine(local)
     if args.workload == "scans":
-        return bench_scans(args, eng, reads, n, rank, world, device, rehearse)
+        return bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads, reads_per_rank)
     eng.set_refs(refs, synth.n_classes())
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
@@ -348,18 +375,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    try:
-        for _ in range(max(args.warmup, 2 if pipelined else 0)):
-            step()
-        fence()
-    except Exception as exc:                                                # never lose the measurement to the overlap trick
-        if not pipelined:
-            raise
-        sys.stderr.write("bench: pipelined all-reduce failed (%s); falling back to the synchronous reduce\n" % exc)
-        pipelined = False
-        pending[0] = pending[1] = None
-        for _ in range(args.warmup):
-            step()
+    # (no fallback: if the pipelined reduce fails the run fails -- a silently different reduce path would still print a number)
+    for _ in range(max(args.warmup, 2 if pipelined else 0)):
+        step()
+    fence()
     eng.profile(PROFILE_EVERY if args.steps >= PROFILE_EVERY else 1)
     fence()
     t0 = time.perf_counter()
@@ -393,12 +412,14 @@ def main():
         import glob
         cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_count_walk.json")))
         if cand:
-            traffic = json.load(open(cand[-1])).get("traffic_bytes_per_launch")
+            pmc = json.load(open(cand[-1]))
+            if pmc.get("kernel_source_sha16") == kernel_source_sha16():    # counters of THIS kernel source, else unknown
+                traffic = pmc.get("traffic_bytes_per_launch")
 
     kernel_ms = float(np.mean(k_ms))
     alg_bytes = 12.0 * n                                                    # the triples the kernel must read once
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    value = world * n * args.steps / elapsed
+    value = total_reads * args.steps / elapsed
 
     # ---- CPU baseline + parity on the sample (rank 0, N=1 only) -----------------------------------
     cpu = None
@@ -414,7 +435,7 @@ def main():
         got = hits.cpu().numpy().view(np.uint64)
         if not np.array_equal(got, want):
             sys.exit("PARITY FAILURE: GPU counts differ from the CPU oracle on the %d-read sample" % ns)
-        cpu = {"value": ns / cpu_s, "unit": "reads/s", "cores": 1, "kind": "port",
+        cpu = {"value": ns / cpu_s, "unit": "reads/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
                "sample": "first %d reads of the same workload vs all %d refs, packed triples in memory, "
                          "sorted-merge restatement (oracle/gtx_oracle.c); counts bit-equal to the GPU's" % (ns, len(refs))}
 
@@ -447,14 +468,18 @@ def main():
         line = {
             "metric": "overlap-counted reads/sec, 100M reads x 1M ref intervals",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: %d 50bp reads/GPU sorted by (chrom,start) x %d ref intervals over 24 hg38 "
-                                   "chromosomes, strand ignored (genomic_overlaps count -S -i); reads resident in HBM" % (n, len(refs)),
-                       "reads_per_gpu": n, "refs": len(refs),
-                       "parallelism": "chromosome shards (LPT) x%d, RCCL %s of the uint64 count vector%s"
-                                      % (world, "reduce(sum) to rank 0" if pipelined and not use_allreduce else "all-reduce(sum)",
-                                         " overlapped with the next step" if pipelined else "")},
+            "config": {"workload": "BASELINE config 3: %d 50bp reads in total, sorted by (chrom,start), x %d ref intervals over 24 hg38 "
+                                   "chromosomes, strand ignored (genomic_overlaps count -S -i); reads resident in HBM" % (total_reads, len(refs)),
+                       "total_reads": total_reads, "refs": len(refs), "reads_per_rank": reads_per_rank,
+                       "imbalance": max(reads_per_rank) / (sum(reads_per_rank) / world),
+                       "parallelism": "%s scaling: one global read set, chromosomes dealt to %d rank(s) by LPT packing of their read counts "
+                                      "(gtx_lpt_assign), reference set replicated" % (args.scaling if world > 1 else "single GPU;", world),
+                       "reduce": ("none (one rank)" if not DIST_ON else "gloo rehearsal on one GPU (not a measurement)" if rehearse else
+                                  ("RCCL reduce(sum) to rank 0" if pipelined and not use_allreduce else "RCCL all-reduce(sum)") +
+                                  (" of the uint64 count vector per step, enqueued on RCCL's stream under the next step's kernels" if pipelined
+                                   else " of the uint64 count vector per step, synchronous"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "count_walk_kernel", "kernel_ms": kernel_ms, "kernel_samples": len(k_ms), "algorithmic_bytes": alg_bytes},

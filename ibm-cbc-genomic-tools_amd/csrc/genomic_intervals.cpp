@@ -328,36 +328,49 @@ LineSource *GenomicRegionSet::DetachStream(std::string *current_line, long int *
 // ---------------------------------------------------------------------------------------------------
 // HIP start-up takes ~0.2 s: it runs on its own thread from the first region set on, next to the
 // parsing of the reference file (GtxWarmUp), and is joined when the context is first needed.
-static std::future<gtx_ctx *> g_ctx_future;
+// The classes of this file drive a gtx_group: one context per GPU (--ngpu N / GTX_NGPU, default 1; devices GTX_DEVICE,
+// GTX_DEVICE+1, ...), classes dealt to the GPUs, RCCL reduce of the result vector (include/gtx.h).  A group of one is a
+// plain context.
+static std::future<gtx_group *> g_group_future;
 static std::string g_ctx_error;
+static int g_ngpu = 0;                                   // 0 = not set: GTX_NGPU or 1
 
-static gtx_ctx *CreateContext()
+void GtxSetDevices(int n) { g_ngpu = n; }
+
+static gtx_group *CreateGroup()
 {
+  int n = g_ngpu;
+  if (n <= 0) { const char *e = getenv("GTX_NGPU"); n = e ? atoi(e) : 1; }
+  if (n < 1) n = 1;
   const char *d = getenv("GTX_DEVICE");
-  gtx_ctx *c = gtx_create(d ? atoi(d) : 0);
-  if (!c) g_ctx_error = gtx_last_error(NULL);      // thread-local in the library: copy it out on this thread
-  return c;
+  const int first = d ? atoi(d) : 0;
+  std::vector<int> ids(n);
+  const char *rh = getenv("GTX_GROUP_REHEARSE");           // test mode of the library: all members on one device
+  for (int i = 0; i < n; i++) ids[i] = first + ((rh && atoi(rh)) ? 0 : i);
+  gtx_group *g = gtx_group_create(n, ids.data());
+  if (!g) g_ctx_error = gtx_group_last_error(NULL);      // thread-local in the library: copy it out on this thread
+  return g;
 }
 
 void GtxWarmUp()
 {
-  if (!g_ctx_future.valid()) g_ctx_future = std::async(std::launch::async, CreateContext);
+  if (!g_group_future.valid()) g_group_future = std::async(std::launch::async, CreateGroup);
 }
 
-static gtx_ctx *Device()
+static gtx_group *Devices()
 {
-  static gtx_ctx *ctx = NULL;
-  if (!ctx) {
+  static gtx_group *grp = NULL;
+  if (!grp) {
     GtxWarmUp();
-    ctx = g_ctx_future.get();
-    if (!ctx) { fflush(stdout); fprintf(stderr, "\nError: %s\n", g_ctx_error.c_str()); exit(1); }
+    grp = g_group_future.get();
+    if (!grp) { fflush(stdout); fprintf(stderr, "\nError: %s\n", g_ctx_error.c_str()); exit(1); }
   }
-  return ctx;
+  return grp;
 }
 
-static void CheckGtx(gtx_ctx *c, int rc)
+static void CheckGrp(gtx_group *g, int rc)
 {
-  if (rc != GTX_OK) { fflush(stdout); fprintf(stderr, "\nError: [gtx %d] %s\n", rc, gtx_last_error(c)); exit(1); }
+  if (rc != GTX_OK) { fflush(stdout); fprintf(stderr, "\nError: [gtx %d] %s\n", rc, gtx_group_last_error(g)); exit(1); }
 }
 
 // Packs the rest of a query/input set batch by batch and hands every batch to `sink`.
@@ -509,10 +522,10 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
     refs[3 * k + 1] = (int32_t)i->START; refs[3 * k + 2] = (int32_t)i->STOP;
   }
   Mark("index packed");
-  gtx_ctx *ctx = Device();
+  gtx_group *grp = Devices();
   Mark("device ready");
   const int n_classes = std::max(1, n_chrom * (strand_aware ? 2 : 1));
-  CheckGtx(ctx, gtx_set_refs_ex(ctx, refs.data(), M, n_classes, sorted ? GTX_REFS_KEEP_ZERO_LENGTH : 0));
+  CheckGrp(grp, gtx_group_set_refs(grp, refs.data(), M, n_classes, sorted ? GTX_REFS_KEEP_ZERO_LENGTH : 0));
   Mark("gtx_set_refs done");
 
   // ---- query side: stream -> packed batches -> device ----
@@ -526,26 +539,31 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   gtx_count_info info;
   if (coverage) {
     // zero-length reads (sorted rules let them through) and zero-length regions contribute 0: the device leaves them out
-    CheckGtx(ctx, gtx_coverage_begin(ctx));
+    CheckGrp(grp, gtx_group_coverage_begin(grp));
     DrainSet(QuerySet, opt, [&](const PackedBatch &b) {
-      CheckGtx(ctx, gtx_coverage_add(ctx, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3),
-                                     sorted ? (GTX_ZERO_LENGTH_OK | (match_gaps ? GTX_GAPS_FORMULA : 0u)) : 0u));
+      CheckGrp(grp, gtx_group_coverage_add(grp, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3),
+                                           sorted ? (GTX_ZERO_LENGTH_OK | (match_gaps ? GTX_GAPS_FORMULA : 0u)) : 0u));
     });
     Mark("queries packed and enqueued");
-    CheckGtx(ctx, gtx_coverage_end(ctx, (uint64_t *)hits, &info));
+    CheckGrp(grp, gtx_group_coverage_end(grp, (uint64_t *)hits, &info));
     if (info.n_unplaced != 0) { fflush(stdout); fprintf(stderr, "\nError: %ld inverted query regions (start > stop) exceed what the MI355X path sets aside for pairwise matching!\n", (long)info.n_unplaced); exit(1); }
     Mark("coverage on the host");
     return hits;
   }
-  CheckGtx(ctx, gtx_count_begin(ctx));
+  CheckGrp(grp, gtx_group_count_begin(grp));
   const uint32_t mode_flags = sorted ? GTX_ZERO_LENGTH_OK : 0;
   DrainSet(QuerySet, opt, [&](const PackedBatch &b) {
     uint32_t flags = mode_flags | (LooksSorted(b.tri) ? GTX_READS_SORTED : 0);
-    CheckGtx(ctx, gtx_count_add(ctx, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), flags));
+    CheckGrp(grp, gtx_group_count_add(grp, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), flags));
     zero_len.insert(zero_len.end(), b.zero_len.begin(), b.zero_len.end());
   });
   Mark("queries packed and enqueued");
-  CheckGtx(ctx, gtx_count_end(ctx, (uint64_t *)hits, &info));
+  CheckGrp(grp, gtx_group_count_end(grp, (uint64_t *)hits, &info));
+  if (getenv("GTX_TIMING") && gtx_group_size(grp) > 1) {
+    std::vector<int64_t> mr((size_t)gtx_group_size(grp));
+    gtx_group_member_reads(grp, mr.data());
+    for (size_t i = 0; i < mr.size(); i++) fprintf(stderr, "[gtx] GPU %zu counted %ld reads\n", i, (long)mr[i]);
+  }
   Mark("counts on the host");
   // (sorted merge: n_degenerate counts the inverted reads, which the library matched pair by pair)
   if (!sorted && info.n_degenerate != 0) { fflush(stdout); fprintf(stderr, "\nError: internal: the packer let %ld degenerate reads through\n", (long)info.n_degenerate); exit(1); }
@@ -662,11 +680,11 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
     tri.insert(tri.end(), b.tri.begin(), b.tri.end());
     w.insert(w.end(), b.w.begin(), b.w.end());
   });
-  gtx_ctx *ctx = Device();
+  gtx_group *grp = Devices();
   const char prep = (preprocess == 'c' && !sorted_rules) ? 'c' : '1';
-  CheckGtx(ctx, gtx_scan(ctx, tri.data(), w.empty() ? NULL : w.data(), (int64_t)(tri.size() / 3), class_len.data(), n_chrom * ns,
-                         (int32_t)win_step, (int32_t)win_size, prep, sorted_rules ? GTX_ZERO_LENGTH_OK : 0,
-                         (uint64_t *)values.data(), class_off.data()));
+  CheckGrp(grp, gtx_group_scan(grp, tri.data(), w.empty() ? NULL : w.data(), (int64_t)(tri.size() / 3), class_len.data(), n_chrom * ns,
+                               (int32_t)win_step, (int32_t)win_size, prep, sorted_rules ? GTX_ZERO_LENGTH_OK : 0,
+                               (uint64_t *)values.data(), class_off.data()));
 }
 
 long int GenomicRegionSetScanner::TotalLabelValue()

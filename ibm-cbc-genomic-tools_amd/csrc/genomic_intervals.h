@@ -240,6 +240,7 @@ class UnsortedGenomicRegionSetScanner : public GenomicRegionSetScanner
                                   bool ignore_strand, char preprocess);
 };
 
+void GtxSetDevices(int n_gpus);                                // MI355X path: GPUs the reductions are spread over (--ngpu; not in the reference)
 void GtxMark(const char *what);                                  // GTX_TIMING=1: wall-clock mark on stderr (not in the reference)
 void GtxFinish(int code);                                        // flush and leave without the teardown (see genomic_intervals.cpp)
 

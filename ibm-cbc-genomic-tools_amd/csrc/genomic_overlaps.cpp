@@ -48,7 +48,9 @@ int main(int argc, char *argv[])
   else if (op == "coverage") opts.ULong("-min", &MIN_COUNT, 0, "minimum coverage");
   else if (op == "density") opts.Double("-min", &MIN_DENSITY, 0.0, "minimum density");
   else opts.Double("-min", &MIN_RPKM, 0.0, "minimum RPKM");
+  long NGPU; opts.Long("--ngpu", &NGPU, 0, "MI355X: number of GPUs the reduction is spread over, by chromosome, RCCL reduce of the result (default: GTX_NGPU or 1)");
   int next_arg = opts.Parse(argc, argv, 2);
+  if (NGPU > 0) GtxSetDevices((int)NGPU);
   if (HELP || HELP2 || argc - next_arg < 1) { opts.Usage(PROGRAM, op.c_str(), "[OPTIONS] REFERENCE-REGION-FILE <TEST-REGION-FILE>"); return 1; }
   _MESSAGES_ = VERBOSE;
 

@@ -185,7 +185,9 @@ int main(int argc, char *argv[])
     o.Double("-pval", &P_PVAL_CUTOFF, 1.0, "pvalue cutoff");
     o.Double("-qval", &P_QVAL_CUTOFF, 0.05, "qvalue cutoff");
     o.Flag("-D", &P_PRINT_DETAILS, "print details");
+    long P_NGPU; o.Long("--ngpu", &P_NGPU, 0, "MI355X: number of GPUs the scans are spread over, by chromosome (default: GTX_NGPU or 1)");
     const int next_arg = o.Parse(argc, argv, 2);
+    if (P_NGPU > 0) GtxSetDevices((int)P_NGPU);
     if (HELP || HELP2 || argc - next_arg < 1) { o.Usage(PROGRAM, "peaks", "[OPTIONS] SIGNAL-REG-FILE [CONTROL-REG-FILE [GENOME-UNIQ-REG-FILE]]"); return 1; }
     _MESSAGES_ = P_VERBOSE;
     return RunPeaks(argv[next_arg], next_arg + 1 < argc ? argv[next_arg + 1] : NULL, next_arg + 2 < argc ? argv[next_arg + 2] : NULL);
@@ -208,7 +210,9 @@ int main(int argc, char *argv[])
   opts.Long("-w", &WIN_SIZE, 500, "window size (must be a multiple of window distance)");
   opts.Long("-d", &WIN_DIST, 25, "window distance");
   opts.Long("-min", &MIN_READS, 10, "minimum reads in window");
+  long NGPU; opts.Long("--ngpu", &NGPU, 0, "MI355X: number of GPUs the scan is spread over, by chromosome (default: GTX_NGPU or 1)");
   int next_arg = opts.Parse(argc, argv, 2);
+  if (NGPU > 0) GtxSetDevices((int)NGPU);
   if (HELP || HELP2) { opts.Usage(PROGRAM, "counts", "[OPTIONS] <REG-FILE>"); return 1; }
   _MESSAGES_ = VERBOSE;
 

@@ -667,23 +667,36 @@ int gtx_count_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int6
   return GTX_OK;
 }
 
-int gtx_count_end(gtx_ctx *c, uint64_t *hits, gtx_count_info *info)
+// closes the open stream call: finalize into the context's own output vector in HBM (enqueued, not waited for)
+int gtxi_count_finish(gtx_ctx *c, void **d_out)
 {
-  if (!c) return GTX_E_ARG;
   if (!c->streamOpen) return fail(c, GTX_E_STATE, "gtx_count_end: gtx_count_begin has not been called");
-  if (c->nRefs > 0 && !hits) return fail(c, GTX_E_ARG, "gtx_count_end: null output");
   HIPCHK(c, hipSetDevice(c->device));
   c->streamOpen = false;
   int rc = ensure_out(c, (size_t)c->nRefs); if (rc) return rc;
   rc = count_end(c, c->d_out); if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + (c->infoCur ^ 1), sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
-  if (c->nRefs > 0) HIPCHK(c, hipMemcpyAsync(hits, c->d_out, sizeof(u64) * c->nRefs, hipMemcpyDeviceToHost, c->stream));
+  *d_out = c->d_out;
+  return GTX_OK;
+}
+
+// after gtxi_*_finish and a wait for the stream: what the call observed
+void gtxi_fetch_info(gtx_ctx *c, gtx_count_info *info)
+{
+  info_out(c->h_info[0], info, 0);
+  if (c->seamUnsorted != INT64_MAX && (info->first_unsorted < 0 || c->seamUnsorted < info->first_unsorted)) info->first_unsorted = c->seamUnsorted;
+}
+
+int gtx_count_end(gtx_ctx *c, uint64_t *hits, gtx_count_info *info)
+{
+  if (!c) return GTX_E_ARG;
+  if (c->streamOpen && c->nRefs > 0 && !hits) return fail(c, GTX_E_ARG, "gtx_count_end: null output");
+  void *d = nullptr;
+  int rc = gtxi_count_finish(c, &d); if (rc) return rc;
+  if (c->nRefs > 0) HIPCHK(c, hipMemcpyAsync(hits, d, sizeof(u64) * c->nRefs, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipStreamSynchronize(c->copyStream));
-  if (info) {
-    info_out(c->h_info[0], info, 0);
-    if (c->seamUnsorted != INT64_MAX && (info->first_unsorted < 0 || c->seamUnsorted < info->first_unsorted)) info->first_unsorted = c->seamUnsorted;
-  }
+  if (info) gtxi_fetch_info(c, info);
   return GTX_OK;
 }
 
@@ -811,20 +824,28 @@ int gtx_coverage_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, i
   return GTX_OK;
 }
 
-int gtx_coverage_end(gtx_ctx *c, uint64_t *cov, gtx_count_info *info)
+int gtxi_coverage_finish(gtx_ctx *c, void **d_out)
 {
-  if (!c) return GTX_E_ARG;
   if (!c->covOpen) return fail(c, GTX_E_STATE, "gtx_coverage_end: gtx_coverage_begin has not been called");
-  if (c->nRefs > 0 && !cov) return fail(c, GTX_E_ARG, "gtx_coverage_end: null output");
   HIPCHK(c, hipSetDevice(c->device));
-  c->covOpen = false;
+  c->covOpen = false; c->seamUnsorted = INT64_MAX;
   int rc = ensure_out(c, (size_t)c->nRefs); if (rc) return rc;
   rc = cover_end(c, c->d_out); if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + (c->infoCur ^ 1), sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
-  if (c->nRefs > 0) HIPCHK(c, hipMemcpyAsync(cov, c->d_out, sizeof(u64) * c->nRefs, hipMemcpyDeviceToHost, c->stream));
+  *d_out = c->d_out;
+  return GTX_OK;
+}
+
+int gtx_coverage_end(gtx_ctx *c, uint64_t *cov, gtx_count_info *info)
+{
+  if (!c) return GTX_E_ARG;
+  if (c->covOpen && c->nRefs > 0 && !cov) return fail(c, GTX_E_ARG, "gtx_coverage_end: null output");
+  void *d = nullptr;
+  int rc = gtxi_coverage_finish(c, &d); if (rc) return rc;
+  if (c->nRefs > 0) HIPCHK(c, hipMemcpyAsync(cov, d, sizeof(u64) * c->nRefs, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipStreamSynchronize(c->copyStream));
-  if (info) info_out(c->h_info[0], info, 0);
+  if (info) gtxi_fetch_info(c, info);
   return GTX_OK;
 }
 
@@ -905,10 +926,10 @@ int gtx_scan_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int6
   return GTX_OK;
 }
 
-int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, const int32_t *classLen, int32_t nClasses,
-             int32_t step, int32_t size, char prep, uint32_t flags, uint64_t *out, const int64_t *classOff)
+// the whole scan of host reads enqueued, result left in the context's own output vector in HBM
+int gtxi_scan_enqueue(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, const int32_t *classLen, int32_t nClasses,
+                      int32_t step, int32_t size, char prep, uint32_t flags, const int64_t *classOff, void **d_out, int64_t *extent_out)
 {
-  if (!c) return GTX_E_ARG;
   if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_scan: bad argument");
   if (prep != '1' && prep != 'c') return fail(c, GTX_E_ARG, "gtx_scan: preprocess operator must be '1' or 'c'");
   if (!weights && n >= (1ll << 32)) return fail(c, GTX_E_ARG, "gtx_scan: unweighted scans count in 32 bits per micro-window: at most 2^32-1 reads per call");
@@ -919,7 +940,6 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
   // output layout in the caller's buffer is given by class_offsets: find its extent
   int64_t extent = 0;
   for (int i = 0; i < nClasses; i++) extent = std::max<int64_t>(extent, classOff[i] + gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size));
-  if (extent > 0 && !out) return fail(c, GTX_E_ARG, "gtx_scan: null output");
   rc = ensure_out(c, (size_t)extent); if (rc) return rc;
   const bool micro64 = weights != nullptr;
   if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (micro64 ? 8 : 4), c->stream));
@@ -930,11 +950,26 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
   if (rc) return rc;
   if (extent > 0) HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)extent * sizeof(u64), c->stream));
   HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, c->d_out, c->stream));
-  if (extent > 0) HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)extent * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  *d_out = c->d_out; *extent_out = extent;
+  return GTX_OK;
+}
+
+int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, const int32_t *classLen, int32_t nClasses,
+             int32_t step, int32_t size, char prep, uint32_t flags, uint64_t *out, const int64_t *classOff)
+{
+  if (!c) return GTX_E_ARG;
+  void *d = nullptr; int64_t extent = 0;
+  int rc = gtxi_scan_enqueue(c, reads, weights, n, classLen, nClasses, step, size, prep, flags, classOff, &d, &extent); if (rc) return rc;
+  if (extent > 0 && !out) return fail(c, GTX_E_ARG, "gtx_scan: null output");
+  if (extent > 0) HIPCHK(c, hipMemcpyAsync(out, d, (size_t)extent * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipStreamSynchronize(c->copyStream));
   return GTX_OK;
 }
+
+hipStream_t gtxi_stream(gtx_ctx *c) { return c->stream; }
+int gtxi_device(gtx_ctx *c) { return c->device; }
+void gtxi_set_error(gtx_ctx *c, const char *msg) { c->err = msg; }
 
 // ---------------------------------------------------------------------------------------------
 // measurement

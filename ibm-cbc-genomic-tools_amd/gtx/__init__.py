@@ -68,6 +68,24 @@ ABI = {
     "gtx_scan_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32,
                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_group_create": (ctypes.c_void_p, [ctypes.c_int, ctypes.c_void_p]),
+    "gtx_group_destroy": (None, [ctypes.c_void_p]),
+    "gtx_group_size": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_group_ctx": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "gtx_group_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "gtx_group_assign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
+    "gtx_lpt_assign": (None, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int, ctypes.c_void_p]),
+    "gtx_group_set_refs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32]),
+    "gtx_group_count_begin": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_group_count_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]),
+    "gtx_group_count_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_group_coverage_begin": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_group_coverage_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]),
+    "gtx_group_coverage_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_group_scan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32,
+                                      ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_group_member_reads": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gtx_profile_last": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_profile_count": (ctypes.c_int, [ctypes.c_void_p]),
@@ -244,3 +262,80 @@ class Engine:
         a, b = ctypes.c_float(), ctypes.c_float()
         self._chk(self.lib.gtx_profile_read(self.ctx, int(back), ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+
+def lpt_assign(class_load, n_members):
+    """class -> member by longest-processing-time packing (gtx_lpt_assign: pure host code, no GPU needed)."""
+    class_load = np.ascontiguousarray(class_load, dtype=np.int64)
+    owner = np.zeros(len(class_load), dtype=np.int32)
+    load().gtx_lpt_assign(_ptr(class_load), len(class_load), int(n_members), _ptr(owner))
+    return owner
+
+
+class Group:
+    """gtx_group: one context per device, classes dealt to the members, RCCL reduce of the result vector."""
+
+    def __init__(self, devices):
+        self.lib = load()
+        ids = np.ascontiguousarray(devices, dtype=np.int32)
+        self.g = self.lib.gtx_group_create(len(ids), _ptr(ids))
+        if not self.g:
+            raise GtxError(self.lib.gtx_group_last_error(None).decode())
+        self.n = len(ids)
+        self.n_refs = 0
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.lib.gtx_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise GtxError("gtx group error %d: %s" % (rc, self.lib.gtx_group_last_error(self.g).decode()))
+
+    def assign(self, load):
+        load = np.ascontiguousarray(load, dtype=np.int64)
+        owner = np.zeros(len(load), dtype=np.int32)
+        self._chk(self.lib.gtx_group_assign(self.g, _ptr(load), len(load), _ptr(owner)))
+        return owner
+
+    def set_refs(self, refs, n_classes=0, flags=0):
+        refs = _triples(refs)
+        self._chk(self.lib.gtx_group_set_refs(self.g, _ptr(refs), refs.shape[0], int(n_classes), int(flags)))
+        self.n_refs = refs.shape[0]
+
+    def _reduce(self, kind, batches, flags):
+        begin, add, end = [getattr(self.lib, "gtx_group_%s_%s" % (kind, x)) for x in ("begin", "add", "end")]
+        self._chk(begin(self.g))
+        for reads, w in batches:
+            reads = _triples(reads)
+            w = None if w is None else np.ascontiguousarray(w, dtype=np.int32)
+            self._chk(add(self.g, _ptr(reads), _ptr(w), reads.shape[0], int(flags)))
+        out = np.zeros(max(self.n_refs, 1), dtype=np.uint64)
+        info = CountInfo()
+        self._chk(end(self.g, _ptr(out), ctypes.byref(info)))
+        return out[:self.n_refs], info.as_dict()
+
+    def count(self, batches, flags=READS_SORTED):
+        return self._reduce("count", batches, flags)
+
+    def coverage(self, batches, flags=0):
+        return self._reduce("coverage", batches, flags)
+
+    def member_reads(self):
+        out = np.zeros(self.n, dtype=np.int64)
+        self._chk(self.lib.gtx_group_member_reads(self.g, _ptr(out)))
+        return out
+
+    def scan(self, reads, class_len, win_step, win_size, preprocess="1", weights=None, flags=0):
+        reads = _triples(reads)
+        cl = np.ascontiguousarray(class_len, dtype=np.int32)
+        off, tot = scan_layout(cl, win_step, win_size)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.int32)
+        out = np.zeros(max(tot, 1), dtype=np.uint64)
+        self._chk(self.lib.gtx_group_scan(self.g, _ptr(reads), _ptr(w), reads.shape[0], _ptr(cl), len(cl), int(win_step), int(win_size),
+                                          preprocess.encode()[0:1], int(flags), _ptr(out), _ptr(off)))
+        return out[:tot], off

@@ -206,6 +206,51 @@ int gtx_scan_device(gtx_ctx *ctx, const void *d_read_triples, const void *d_weig
                     const int32_t *class_len, int32_t n_classes, int32_t win_step, int32_t win_size, char preprocess,
                     uint32_t flags, void *d_windows_out, const int64_t *class_offsets);
 
+/* ---- several GPUs of one node ------------------------------------------------------------ */
+
+/* Two regions overlap only inside one class (genomic_intervals.cpp:624-630), so a class is an independent unit of work.
+ * A group is one context per device; classes are dealt to the members (longest-processing-time packing of a per-class
+ * load), every member holds the whole reference set and counts the reads of ITS classes into a full-length vector, and
+ * one RCCL reduce(sum) over xGMI of that uint64 vector to member 0 yields the result (the members' vectors are disjoint
+ * by class, so the sum is the one-GPU vector bit for bit).  genomic_scans windows are per class too: same split, same
+ * reduce of the window vector.  One process and one caller thread drive all members; calls enqueue and return.
+ * What the reference's single loop over queries (genomic_intervals.cpp:5304-5317) becomes on a node. */
+typedef struct gtx_group gtx_group;
+
+/* device_ids == NULL: devices 0 .. n_devices-1.  NULL on failure (gtx_group_last_error(NULL) has the text).  librccl is
+ * loaded at run time, for groups of more than one device only. */
+gtx_group  *gtx_group_create(int n_devices, const int *device_ids);
+void        gtx_group_destroy(gtx_group *g);
+int         gtx_group_size(const gtx_group *g);
+gtx_ctx    *gtx_group_ctx(gtx_group *g, int member);
+const char *gtx_group_last_error(const gtx_group *g);
+
+/* class -> member by LPT packing of class_load (e.g. reads per class, or chromosome lengths); owner_out (n_classes, may be
+ * NULL) receives the assignment.  Without this call gtx_group_set_refs assigns by the span of each class's reference
+ * regions and gtx_group_scan by class_len.  gtx_lpt_assign is the packing itself (no group, no GPU). */
+int  gtx_group_assign(gtx_group *g, const int64_t *class_load, int32_t n_classes, int32_t *owner_out);
+void gtx_lpt_assign(const int64_t *class_load, int32_t n_classes, int n_members, int32_t *owner_out);
+
+/* gtx_set_refs_ex on every member. */
+int gtx_group_set_refs(gtx_group *g, const int32_t *ref_triples, int64_t n_refs, int32_t n_classes, uint32_t flags);
+
+/* The streaming count / coverage calls of a single context, on the group: every read goes to the owner of its class (reads
+ * of no known class to member 0).  Sorted input is cut into a few contiguous runs per batch; interleaved input is
+ * partitioned on the host.  info: the sums over the members; first_unsorted / first_degenerate are not tracked (-1), and
+ * GTX_CHECK_SORTED is ignored. */
+int gtx_group_count_begin(gtx_group *g);
+int gtx_group_count_add(gtx_group *g, const int32_t *read_triples, const int32_t *weights, int64_t n_reads, uint32_t flags);
+int gtx_group_count_end(gtx_group *g, uint64_t *hits_out /* n_refs */, gtx_count_info *info /* may be NULL */);
+int gtx_group_coverage_begin(gtx_group *g);
+int gtx_group_coverage_add(gtx_group *g, const int32_t *read_triples, const int32_t *weights, int64_t n_reads, uint32_t flags);
+int gtx_group_coverage_end(gtx_group *g, uint64_t *cov_out /* n_refs */, gtx_count_info *info /* may be NULL */);
+/* gtx_scan on the group (arguments as gtx_scan). */
+int gtx_group_scan(gtx_group *g, const int32_t *read_triples, const int32_t *weights, int64_t n_reads,
+                   const int32_t *class_len, int32_t n_classes, int32_t win_step, int32_t win_size, char preprocess,
+                   uint32_t flags, uint64_t *windows_out, const int64_t *class_offsets);
+/* reads each member received in the last (or open) group call: the load balance actually achieved */
+int gtx_group_member_reads(const gtx_group *g, int64_t *reads_out /* gtx_group_size */);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 /* on = 1: every *_device call brackets its dominant kernel and the whole call with HIP events on the

@@ -96,3 +96,62 @@ def test_two_ranks_split_the_shuffles(tmp_path):
     t = perm.PermTable.synthetic(600, 40, 20, seed=5, values="gamma")
     want = porc.count_ge(t, "sum", porc.statistic(t, "sum"), 77, 0, 180)
     np.testing.assert_array_equal(np.load(out), want.view(np.int64))
+
+
+# ---- one global read set, sharded by the product's LPT packing (bench.py N > 1, genomic_overlaps --ngpu) ------------------
+def test_product_lpt_packing():
+    import gtx
+    for world in (1, 2, 3, 4, 8):
+        per_chrom = synth.apportion(100_000_000 * world, synth.CHROM_LEN)
+        owner = gtx.lpt_assign(per_chrom, world)
+        assert owner.min() >= 0 and owner.max() < world and len(owner) == 24
+        loads = np.bincount(owner, weights=per_chrom, minlength=world)
+        assert loads.min() > 0
+        assert loads.max() / loads.mean() < 1.08                      # chr1 alone is 8 % of the genome: 8 GPUs cannot do better than ~1.04
+        np.testing.assert_array_equal(owner, gtx.lpt_assign(per_chrom, world))     # deterministic
+    # zero and equal loads: every class still gets an owner, ties go to the lowest member
+    assert gtx.lpt_assign([5, 5, 5, 5], 2).tolist() == [0, 1, 0, 1]
+    assert gtx.lpt_assign([0, 0, 7], 2).tolist() == [1, 0, 0] or gtx.lpt_assign([0, 0, 7], 2).max() < 2
+
+
+def _reads_of(chroms, per, seed):
+    parts = []
+    for c, k in zip(chroms, per):
+        rng = np.random.default_rng(seed * 1000 + int(c))
+        s = np.sort(rng.integers(1, int(synth.CHROM_LEN[c]) - 60, size=int(k)))
+        parts.append(np.stack([np.full(int(k), c), s, s + 49], axis=1))
+    return np.concatenate(parts).astype(np.int32) if parts else np.zeros((0, 3), dtype=np.int32)
+
+
+def _strong_worker(rank, world, port, total, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gtx
+        refs = synth.genome_intervals(3000, 71, 50, 3000)
+        per_chrom = synth.apportion(total, synth.CHROM_LEN)
+        owner = gtx.lpt_assign(per_chrom, world)
+        mine = np.nonzero(owner == rank)[0]
+        reads = _reads_of(mine, per_chrom[mine], 9)
+        hits = orc.count(refs, reads, algo=orc.SORTED_MERGE)           # stand-in for gtx_count_device on this rank's GPU
+        t = torch.from_numpy(hits.view(np.int64).copy())
+        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)                    # the exchange step: reduce(sum) of the count vector to rank 0
+        n = torch.tensor([len(reads)])
+        dist.all_reduce(n)
+        if rank == 0:
+            assert int(n.item()) == total                              # ONE fixed read set, partitioned by the ranks
+            np.save(out, t.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_fixed_read_set(tmp_path):
+    total = 60_000
+    out = str(tmp_path / "strong.npy")
+    mp.spawn(_strong_worker, args=(2, _free_port(), total, out), nprocs=2, join=True)
+    refs = synth.genome_intervals(3000, 71, 50, 3000)
+    per_chrom = synth.apportion(total, synth.CHROM_LEN)
+    reads = _reads_of(np.arange(24), per_chrom, 9)
+    want = orc.count(refs, reads, algo=orc.SORTED_MERGE)
+    np.testing.assert_array_equal(np.load(out).view(np.uint64), want)
