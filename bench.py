@@ -103,6 +103,76 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def measure_host_to_result(eng, reads, n, hits, flags):
+    """(ii) packed host arrays -> counts on the host through gtx_count (host->device copies, kernels, result copy): from
+    ordinary pageable memory (staged through page-locked slots by host threads) and from gtx_host_alloc memory (the DMA
+    engine reads it directly).  Counts are compared with the device-resident run."""
+    eng.count_device(reads.data_ptr(), n, hits.data_ptr(), None, flags)
+    eng.sync()
+    want = hits.cpu().numpy().view(np.uint64).copy()
+    eng.set_stream(0)
+    host = reads.cpu().numpy()
+    out = {}
+    pin = eng.pinned_array(host.shape)
+    pin[:] = host
+    for name, src in (("pageable", host), ("page_locked", pin)):
+        eng.count(src[:1_000_000], None, flags)                                # slots and streams are up
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            got, _ = eng.count(src, None, flags)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        if not np.array_equal(got, want):
+            sys.exit("PARITY FAILURE: gtx_count from %s host memory differs from the device-resident run" % name)
+        out[name] = {"seconds": best, "reads_per_s": n / best, "GB_per_s": 12.0 * n / best / 1e9}
+    eng.free_pinned(pin)
+    out["note"] = "gtx_count on %d packed reads in host memory, best of 3, PCIe included; never part of `value`" % n
+    return out
+
+
+def measure_text_to_stdout(n, m):
+    """(iii) the product CLI `genomic_overlaps count -S -i REFS READS` from BED text and from a packed region file (.gtx) of the
+    same reads, wall time of the whole process with stdout going to a file; workload files made by gtx_packtool synth."""
+    import hashlib
+    import subprocess
+    import tempfile
+    bins = os.path.join(PKG, "csrc")
+    tmp = tempfile.mkdtemp(prefix="gtx_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    rp, qp, gp, op = [os.path.join(tmp, f) for f in ("refs.bed", "reads.bed", "reads.gtx", "out.txt")]
+    res = {}
+    try:
+        subprocess.run([os.path.join(bins, "gtx_packtool"), "synth", str(n), "7", qp], check=True)
+        subprocess.run([os.path.join(bins, "gtx_packtool"), "synthrefs", str(m), "8", rp], check=True)
+        t0 = time.perf_counter()
+        subprocess.run([os.path.join(bins, "gtx_packtool"), "pack", qp, gp], check=True)
+        res["pack_seconds"] = time.perf_counter() - t0
+        digest = {}
+        for name, q in (("bed_text", qp), ("packed_gtx", gp)):
+            best = None
+            for _ in range(2):
+                with open(op, "wb") as f:
+                    t0 = time.perf_counter()
+                    r = subprocess.run([os.path.join(bins, "genomic_overlaps"), "count", "-S", "-i", rp, q], stdout=f, stderr=subprocess.PIPE)
+                    dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    sys.exit("text_to_stdout: genomic_overlaps failed: " + r.stderr.decode()[-300:])
+                best = dt if best is None else min(best, dt)
+            digest[name] = hashlib.md5(open(op, "rb").read()).hexdigest()
+            res[name] = {"seconds": best, "reads_per_s": n / best, "input_bytes": os.path.getsize(q)}
+        if digest["bed_text"] != digest["packed_gtx"]:
+            sys.exit("PARITY FAILURE: the CLI's output differs between BED text and the packed region file")
+        res["output_md5"] = digest["bed_text"]
+        res["note"] = ("genomic_overlaps count -S -i, %d reads x %d regions, process wall time to exit with stdout to a file, best of 2; "
+                       "host cores %d; never part of `value`" % (n, m, os.cpu_count()))
+    finally:
+        for f in (rp, qp, gp, op):
+            if os.path.exists(f):
+                os.remove(f)
+        os.rmdir(tmp)
+    return res
+
+
 def bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads, reads_per_rank):
     """BASELINE config 4: sliding-window read counts (1 kb windows) over the reads of this rank's chromosomes;
     the per-window vectors of the ranks are disjoint by chromosome and are combined with one all-reduce(sum)."""
@@ -464,6 +534,12 @@ def main():
                        "note": "two contexts alternating on two HIP streams; informational, not the reported value"}
         eng2.close()
 
+    # ---- not part of `value`: the same job timed from the host side (SURVEY 8(d) ii, iii), N = 1 only ----------------------
+    host_to_result = text_to_stdout = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        host_to_result = measure_host_to_result(eng, reads, n, hits, flags)
+        text_to_stdout = measure_text_to_stdout(n, len(refs))
+
     if rank == 0:
         line = {
             "metric": "overlap-counted reads/sec, 100M reads x 1M ref intervals",
@@ -487,6 +563,10 @@ def main():
         }
         if two_streams:
             line["two_streams"] = two_streams
+        if host_to_result:
+            line["host_to_result"] = host_to_result
+        if text_to_stdout:
+            line["text_to_stdout"] = text_to_stdout
         emit(line)
     if world > 1 or force_dist:
         dist.destroy_process_group()
