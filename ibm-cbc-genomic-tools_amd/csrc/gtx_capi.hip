@@ -40,7 +40,11 @@ struct gtx_ctx {
   u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr, *d_prefA = nullptr, *d_prefB = nullptr;
   bool histDirty = false;              // a call was abandoned between begin and end
   // coverage (allocated on first use): 8 histograms, 8 tile-sum arrays, 8 prefix arrays, region coordinates
-  u64 *d_cov[24] = {}; int *d_refS = nullptr, *d_refE = nullptr; bool covReady = false, covDirty = false, covOpen = false;
+  // coverage (made on first use): the merged threshold array of the regions (E_k and S_k - 1, sorted per class) with its
+  // 4 histograms, 4 tile-sum arrays, 4 prefix arrays; region coordinates in file order
+  u64 *d_cov[12] = {}; int *d_refS = nullptr, *d_refE = nullptr; bool covReady = false, covDirty = false, covOpen = false;
+  int *d_sortedT = nullptr, *d_segT = nullptr, *d_topT = nullptr, *d_posTE = nullptr, *d_posTS = nullptr, *d_classBaseT = nullptr;
+  int64_t histLenT = 0;
   std::vector<int32_t> h_refS, h_refE, h_refC;
   // sorted-merge semantics, intervals with start > end + 1 (gtx_special.hip): the K inverted reference regions and their sums,
   // the inverted reads the kernels set aside, the region columns the second pair kernel reads
@@ -155,6 +159,7 @@ void gtx_destroy(gtx_ctx *c)
   if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
   dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
   for (auto &p : c->d_cov) dfree(p);
+  dfree(c->d_sortedT); dfree(c->d_segT); dfree(c->d_topT); dfree(c->d_posTE); dfree(c->d_posTS); dfree(c->d_classBaseT);
   dfree(c->d_refS); dfree(c->d_refE); dfree(c->d_refC); dfree(c->d_specialRefs); dfree(c->d_specialIdx); dfree(c->d_specialOut); dfree(c->d_side); dfree(c->d_sideCount);
   if (c->h_info) (void)hipHostFree(c->h_info);
   for (auto &slot : c->evRing) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
@@ -322,6 +327,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
     HIPCHK(c, hipMemcpy(c->d_classBase, classBase.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
   }
   for (auto &p : c->d_cov) dfree(p);
+  dfree(c->d_sortedT); dfree(c->d_segT); dfree(c->d_topT); dfree(c->d_posTE); dfree(c->d_posTS); dfree(c->d_classBaseT);
   dfree(c->d_refS); dfree(c->d_refE); c->covReady = false; c->covDirty = false;
   c->h_refS.resize(m > 0 ? m : 1); c->h_refE.resize(m > 0 ? m : 1); c->h_refC.resize(m > 0 ? m : 1);
   for (int64_t k = 0; k < m; k++) { c->h_refC[k] = tri[3 * k]; c->h_refS[k] = tri[3 * k + 1]; c->h_refE[k] = tri[3 * k + 2]; }
@@ -716,13 +722,53 @@ int gtx_count(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t 
 static int cover_prepare(gtx_ctx *c)
 {
   if (c->covReady) return GTX_OK;
-  const int nTiles = gtx::scan_tiles(c->histLen);
-  for (int q = 0; q < 8; q++) {
-    HIPCHK(c, hipMalloc(&c->d_cov[q], sizeof(u64) * c->histLen));           // histograms
-    HIPCHK(c, hipMalloc(&c->d_cov[8 + q], sizeof(u64) * (nTiles + 2)));     // tile sums
-    HIPCHK(c, hipMalloc(&c->d_cov[16 + q], sizeof(u64) * c->histLen));      // prefixes
-    HIPCHK(c, hipMemset(c->d_cov[q], 0, sizeof(u64) * c->histLen));
-    HIPCHK(c, hipMemset(c->d_cov[8 + q], 0, sizeof(u64) * (nTiles + 2)));
+  // the thresholds of every region that takes part (the rule of gtx_set_refs_ex): E_k and S_k - 1, sorted by (class, value)
+  const int64_t m = c->nRefs;
+  struct Item { int32_t cls, val, k2; };                      // k2 = 2 * region + (0: the E threshold, 1: the S - 1 threshold)
+  std::vector<Item> it;
+  it.reserve((size_t)2 * c->nValid);
+  for (int64_t k = 0; k < m; k++) {
+    const int32_t cl = c->h_refC[k], s = c->h_refS[k], e = c->h_refE[k];
+    const bool take = cl >= 0 && (c->mergeRefs ? (int64_t)s <= (int64_t)e + 1 : !(s > e || e <= 0));
+    if (!take) continue;
+    it.push_back({cl, e, (int32_t)(2 * k)}); it.push_back({cl, s - 1, (int32_t)(2 * k + 1)});
+  }
+  std::sort(it.begin(), it.end(), [](const Item &a, const Item &b) { return a.cls != b.cls ? a.cls < b.cls : (a.val != b.val ? a.val < b.val : a.k2 < b.k2); });
+  const int64_t nt = (int64_t)it.size();
+  std::vector<int32_t> sortedT(nt + 1), seg(c->nClasses + 1, 0), posTE(m > 0 ? m : 1, -1), posTS(m > 0 ? m : 1, -1), base(m > 0 ? m : 1, -1);
+  for (int64_t i = 0; i < nt; i++) seg[it[i].cls + 1]++;
+  for (int cl = 0; cl < c->nClasses; cl++) seg[cl + 1] += seg[cl];
+  for (int64_t i = 0; i < nt; i++) {
+    sortedT[i] = it[i].val;
+    const int32_t k = it[i].k2 >> 1;
+    ((it[i].k2 & 1) ? posTS : posTE)[k] = (int32_t)(i + it[i].cls);          // histogram slot = rank + class id, as in gtx_set_refs_ex
+    base[k] = seg[it[i].cls] + it[i].cls - 1;
+  }
+  const int64_t nTop = (nt + 255) >> 8;
+  std::vector<int32_t> topT(nTop + 1);
+  for (int64_t i = 0; i < nTop; i++) topT[i] = sortedT[i << 8];
+  c->histLenT = nt + c->nClasses;
+  const int nTiles = gtx::scan_tiles(c->histLenT);
+  HIPCHK(c, hipMalloc(&c->d_sortedT, sizeof(int32_t) * (nt + 1)));
+  HIPCHK(c, hipMalloc(&c->d_segT, sizeof(int32_t) * (c->nClasses + 1)));
+  HIPCHK(c, hipMalloc(&c->d_topT, sizeof(int32_t) * (nTop + 1)));
+  HIPCHK(c, hipMalloc(&c->d_posTE, sizeof(int32_t) * (m + 1)));
+  HIPCHK(c, hipMalloc(&c->d_posTS, sizeof(int32_t) * (m + 1)));
+  HIPCHK(c, hipMalloc(&c->d_classBaseT, sizeof(int32_t) * (m + 1)));
+  HIPCHK(c, hipMemcpy(c->d_sortedT, sortedT.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_segT, seg.data(), sizeof(int32_t) * (c->nClasses + 1), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_topT, topT.data(), sizeof(int32_t) * (nTop + 1), hipMemcpyHostToDevice));
+  if (m > 0) {
+    HIPCHK(c, hipMemcpy(c->d_posTE, posTE.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_posTS, posTS.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_classBaseT, base.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
+  }
+  for (int q = 0; q < 4; q++) {
+    HIPCHK(c, hipMalloc(&c->d_cov[q], sizeof(u64) * c->histLenT));          // histograms
+    HIPCHK(c, hipMalloc(&c->d_cov[4 + q], sizeof(u64) * (nTiles + 2)));     // tile sums
+    HIPCHK(c, hipMalloc(&c->d_cov[8 + q], sizeof(u64) * c->histLenT));      // prefixes
+    HIPCHK(c, hipMemset(c->d_cov[q], 0, sizeof(u64) * c->histLenT));
+    HIPCHK(c, hipMemset(c->d_cov[4 + q], 0, sizeof(u64) * (nTiles + 2)));
   }
   { int rc = ref_columns(c); if (rc) return rc; }
   c->covReady = true; c->covDirty = false;
@@ -733,14 +779,16 @@ static gtx::CoverArgs cover_args(gtx_ctx *c, int64_t nReads, int64_t indexBase =
 {
   gtx::CoverArgs a;
   a.indexBase = indexBase;
-  a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart; a.topE = c->d_topE; a.topS = c->d_topS;
-  for (int q = 0; q < 8; q++) { a.hist[q] = c->d_cov[q]; a.part[q] = c->d_cov[8 + q]; }
+  a.sortedT = c->d_sortedT; a.segStartT = c->d_segT; a.topT = c->d_topT;
+  for (int q = 0; q < 4; q++) { a.hist[q] = c->d_cov[q]; a.part[q] = c->d_cov[4 + q]; }
   a.info = c->d_info + c->infoCur; a.nClasses = c->nClasses;
   const bool merge = (flags & GTX_ZERO_LENGTH_OK) && (flags & GTX_GAPS_FORMULA) && c->mergeRefs && c->d_side;
   a.side = merge ? c->d_side : nullptr; a.sideCount = merge ? c->d_sideCount : nullptr; a.sideCap = c->sideCap;
   { static const bool wf = !(getenv("GTX_WEIGHTED_FAST") && atoi(getenv("GTX_WEIGHTED_FAST")) == 0); a.wfast = wf ? 1 : 0; }
   int64_t nChunks = (nReads + 63) >> 6;
-  a.chunksPerWave = c->chunksPerWave > 0 ? c->chunksPerWave : (int)std::min<int64_t>(56, std::max<int64_t>(8, nChunks / 24576));   // as count_args
+  // span per wave: as count_args, a little longer (the start of a span costs more here: 100 M reads: 0.55 ms at 16 chunks, 0.44 at 32,
+  // 0.382 at 56, 0.374 at 64, 0.383 at 96)
+  a.chunksPerWave = c->chunksPerWave > 0 ? c->chunksPerWave : (int)std::min<int64_t>(64, std::max<int64_t>(8, nChunks / 24576));
   return a;
 }
 
@@ -748,10 +796,10 @@ static int cover_begin(gtx_ctx *c)
 {
   int rc = cover_prepare(c); if (rc) return rc;
   if (c->covDirty) {
-    const int nTiles = gtx::scan_tiles(c->histLen);
-    for (int q = 0; q < 8; q++) {
-      HIPCHK(c, hipMemsetAsync(c->d_cov[q], 0, sizeof(u64) * c->histLen, c->stream));
-      HIPCHK(c, hipMemsetAsync(c->d_cov[8 + q], 0, sizeof(u64) * (nTiles + 2), c->stream));
+    const int nTiles = gtx::scan_tiles(c->histLenT);
+    for (int q = 0; q < 4; q++) {
+      HIPCHK(c, hipMemsetAsync(c->d_cov[q], 0, sizeof(u64) * c->histLenT, c->stream));
+      HIPCHK(c, hipMemsetAsync(c->d_cov[4 + q], 0, sizeof(u64) * (nTiles + 2), c->stream));
     }
   }
   if (c->covDirty || c->histDirty) {
@@ -769,9 +817,9 @@ static int cover_begin(gtx_ctx *c)
 static int cover_end(gtx_ctx *c, void *d_cov_out)
 {
   gtx::CoverGather g;
-  for (int q = 0; q < 8; q++) { g.pref[q] = c->d_cov[16 + q]; g.part[q] = c->d_cov[8 + q]; }
-  g.posE = c->d_posE; g.posS = c->d_posS; g.classBase = c->d_classBase; g.refS = c->d_refS; g.refE = c->d_refE;
-  HIPCHK(c, gtx::launch_coverage_finalize(cover_args(c, 0), c->histLen, g, c->nRefs, (u64 *)d_cov_out, c->d_info + (c->infoCur ^ 1), c->stream));
+  for (int q = 0; q < 4; q++) { g.pref[q] = c->d_cov[8 + q]; g.part[q] = c->d_cov[4 + q]; }
+  g.posTE = c->d_posTE; g.posTS = c->d_posTS; g.classBaseT = c->d_classBaseT; g.refS = c->d_refS; g.refE = c->d_refE;
+  HIPCHK(c, gtx::launch_coverage_finalize(cover_args(c, 0), c->histLenT, g, c->nRefs, (u64 *)d_cov_out, c->d_info + (c->infoCur ^ 1), c->stream));
   { int rc = merge_end(c, d_cov_out); if (rc) return rc; }
   c->covDirty = false;
   c->infoCur ^= 1;

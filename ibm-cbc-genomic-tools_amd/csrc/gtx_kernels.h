@@ -42,13 +42,13 @@ struct CountArgs {
   int4 *side; unsigned *sideCount; int sideCap;
 };
 
-// coverage: 8 histograms / tile-sum arrays in the order
-//   0 (E-array, key s, w)  1 (E-array, key s, w*s)  2 (E-array, key e, w)  3 (E-array, key e, w*e)
-//   4 (S-array, key s, w)  5 (S-array, key s, w*s)  6 (S-array, key e, w)  7 (S-array, key e, w*e)
+// coverage: ONE boundary array per class -- the thresholds E_k and S_k - 1 of all its regions, merged and sorted (sortedT) --
+// walked by two windows, keyed by the read starts and by the read ends; 4 histograms / tile-sum arrays over its slots:
+//   0 (key s, w)   1 (key s, w*s)   2 (key e, w)   3 (key e, w*e)
 struct CoverArgs {
-  const int *sortedE, *sortedS, *segStart;
-  const int *topE, *topS;          // every 256th boundary (as CountArgs)
-  unsigned long long *hist[8], *part[8];
+  const int *sortedT, *segStartT;  // thresholds sorted by (class, value); [nClasses+1] class segments
+  const int *topT;                 // every 256th threshold (as CountArgs::topE)
+  unsigned long long *hist[4], *part[4];
   DevInfo *info;
   int nClasses, chunksPerWave;
   int wfast;                       // weighted reads: steps of 4 x 64 with prefix sums in LDS (0: general per-chunk code only)
@@ -57,8 +57,8 @@ struct CoverArgs {
 };
 
 struct CoverGather {
-  unsigned long long *pref[8], *part[8];
-  const int *posE, *posS, *classBase;
+  unsigned long long *pref[4], *part[4];
+  const int *posTE, *posTS, *classBaseT;   // slot of E_k / of S_k - 1 / just below the class's first slot, per region in FILE order
   const int *refS, *refE;        // region coordinates in FILE order
 };
 

@@ -876,11 +876,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void coun
 // With Ws(x) = sum w[s<=x], We(x) = sum w[e<=x], Fs(x) = sum w*s[s<=x], Fe(x) = sum w*e[e<=x] (valid reads,
 // s <= e) the overlapping reads split by where their ends lie, and
 //   cov[k] = Fe(E) - Fe(S-1) + E*(Ws(E) - We(E))  -  Fs(E) + Fs(S-1) - S*(Ws(S-1) - We(S-1))  +  Ws(E) - We(S-1)
-// (all in wrap-around 64-bit arithmetic, like the reference's unsigned long).  So the same streaming pass
-// walks four windows -- (ends array, key s), (ends array, key e), (starts array, key s), (starts array,
-// key e) -- each with a weight histogram and a weight x key histogram.  Zero-length reads and regions
-// always contribute 0 and are left out.  This kernel is the general per-chunk form (no hand-tuned fast
-// path yet): correctness first for this "next" row.
+// (all in wrap-around 64-bit arithmetic, like the reference's unsigned long).  All eight sums are "weight [x key] of the
+// reads whose key lies at or below a threshold", the thresholds being E_k and S_k - 1: so the thresholds of a class are
+// merged into ONE sorted array (sortedT, built by the host) and ONE streaming pass walks two windows over it -- keyed by
+// the read starts and by the read ends -- each with a weight histogram and a weight x key histogram.  (Round 1 walked
+// four windows, over the ends array and over the starts array, in two launches that each read the triples.)
+// Zero-length reads and regions always contribute 0 and are left out.
 // ---------------------------------------------------------------------------------------------
 // Fast form of Win::walk for one full chunk of the coverage pass (unweighted, all 64 lanes of the wave's class,
 // window placed).  When the keys are non-decreasing across the lanes -- sorted reads: always for the starts,
@@ -1061,21 +1062,19 @@ __device__ __forceinline__ void cov_step4_run(WIN &X, const Seg &sg, const int (
   }
 }
 
-// per-wave state of one coverage pass.  The pass over one boundary array (STRICT = false: the ends array,
-// true: the starts array) walks two windows, keyed by the read starts (Ws) and by the read ends (We).  The two
-// arrays are two launches: half the live state per wave (twice the waves per SIMD) and half the code in the
-// instruction cache for one extra streaming read of the 12-byte triples.
-template <bool WEIGHTED, bool STRICT>
+// per-wave state of the coverage pass: two windows over the merged threshold array, keyed by the read starts (Ws) and by
+// the read ends (We); a key x belongs to the slots at or below threshold T iff x <= T
+template <bool WEIGHTED>
 struct CovState {
-  Win<WEIGHTED, STRICT, true> Ws, We;
+  Win<WEIGHTED, false, true> Ws, We;
   bool vs, ve;
   Seg sg;
   int nNoClass, nDegen; i64 firstDegen;
 };
 
 // one chunk of 64 reads, any mix of classes / invalid reads (`active` masks a partial chunk)
-template <bool WEIGHTED, bool STRICT>
-__device__ __forceinline__ void cov_chunk(CovState<WEIGHTED, STRICT> &st, const CoverArgs &a, const Tri &t, int w, u64 active, i64 firstIndex, int lane)
+template <bool WEIGHTED>
+__device__ __forceinline__ void cov_chunk(CovState<WEIGHTED> &st, const CoverArgs &a, const Tri &t, int w, u64 active, i64 firstIndex, int lane)
 {
   Seg &sg = st.sg;
   int c0 = rdlane(t.c, 0);
@@ -1084,13 +1083,13 @@ __device__ __forceinline__ void cov_chunk(CovState<WEIGHTED, STRICT> &st, const 
     if (st.vs) st.Ws.flush(sg, lane);
     if (st.ve) st.We.flush(sg, lane);
     st.vs = st.ve = false;
-    sg.start = rfl(a.segStart[c0]); sg.end = rfl(a.segStart[c0 + 1]); sg.cls = c0;
+    sg.start = rfl(a.segStartT[c0]); sg.end = rfl(a.segStartT[c0 + 1]); sg.cls = c0;
   }
   const u64 noclass = __ballot((unsigned)t.c >= (unsigned)a.nClasses) & active;
   const u64 degen = __ballot(t.s > t.e) & active & ~noclass;        // zero-length or inverted: contributes nothing
   const u64 mine = __ballot(t.c == sg.cls) & active & ~degen & ~noclass;
   const u64 other = active & ~mine & ~degen & ~noclass;
-  if (!STRICT && (degen | noclass)) {                                 // reported once, by the pass over the ends array
+  if (degen | noclass) {
     st.nNoClass += __popcll(noclass);
     const u64 inv = __ballot(t.s > t.e + 1) & degen;                // only these are reported (the packer's business)
     if (inv) {
@@ -1112,14 +1111,14 @@ __device__ __forceinline__ void cov_chunk(CovState<WEIGHTED, STRICT> &st, const 
   }
   if (other) {
     Seg so; so.start = 0; so.end = 0; so.cls = 0;
-    if ((other >> lane) & 1) { so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c; }
+    if ((other >> lane) & 1) { so.start = a.segStartT[t.c]; so.end = a.segStartT[t.c + 1]; so.cls = t.c; }
     const u64 has = __ballot(so.start != so.end) & other;
     if (has) { st.Ws.lanes_add(so, t.s, w, has, lane); st.We.lanes_add(so, t.e, w, has, lane); }
   }
 }
 
 // (5 waves per SIMD at 90 VGPRs; forcing 6-8 with launch bounds + an SGPR cap spills and measured 3-8 % slower)
-template <bool WEIGHTED, bool STRICT>
+template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CoverArgs a)
 {
   const int lane = threadIdx.x & 63;
@@ -1132,11 +1131,10 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
   __shared__ int ldsK[4][256], ldsP[WEIGHTED ? 1 : 4][WEIGHTED ? 1 : 264];   // per wave: the keys of a step and their prefix sums
   __shared__ i64 ldsW[WEIGHTED ? 4 : 1][WEIGHTED ? 264 : 1], ldsWK[WEIGHTED ? 4 : 1][WEIGHTED ? 264 : 1];   // weighted: prefix sums of w and of w x key
   const int wid = rfl(threadIdx.x >> 6);
-  CovState<WEIGHTED, STRICT> st;
-  constexpr int h0 = STRICT ? 4 : 0;                              // histograms 0..3 belong to the ends array, 4..7 to the starts array
-  st.Ws.arr = st.We.arr = STRICT ? a.sortedS : a.sortedE;
-  st.Ws.hist = a.hist[h0]; st.Ws.hist2 = a.hist[h0 + 1]; st.Ws.part = a.part[h0]; st.Ws.part2 = a.part[h0 + 1];
-  st.We.hist = a.hist[h0 + 2]; st.We.hist2 = a.hist[h0 + 3]; st.We.part = a.part[h0 + 2]; st.We.part2 = a.part[h0 + 3];
+  CovState<WEIGHTED> st;
+  st.Ws.arr = st.We.arr = a.sortedT;
+  st.Ws.hist = a.hist[0]; st.Ws.hist2 = a.hist[1]; st.Ws.part = a.part[0]; st.Ws.part2 = a.part[1];
+  st.We.hist = a.hist[2]; st.We.hist2 = a.hist[3]; st.We.part = a.part[2]; st.We.part2 = a.part[3];
   st.Ws.acc = st.We.acc = 0; st.Ws.acc2 = st.We.acc2 = 0; st.Ws.pend = st.We.pend = 0; st.Ws.pend2 = st.We.pend2 = 0;
   st.Ws.j = st.We.j = 0; st.Ws.base = st.We.base = 0;
   st.Ws.W = st.Ws.Wn = st.We.W = st.We.Wn = kHi;
@@ -1161,10 +1159,10 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) odd |= t[r].c != c0 || t[r].s > t[r].e;
     if ((unsigned)c0 < (unsigned)a.nClasses && __ballot(odd) == 0) {
-      st.sg.start = rfl(a.segStart[c0]); st.sg.end = rfl(a.segStart[c0 + 1]); st.sg.cls = c0;
+      st.sg.start = rfl(a.segStartT[c0]); st.sg.end = rfl(a.segStartT[c0 + 1]); st.sg.cls = c0;
       if (st.sg.start != st.sg.end) {
         const int ks[4] = {t[0].s, t[1].s, t[2].s, t[3].s}, ke[4] = {t[0].e, t[1].e, t[2].e, t[3].e};
-        const int *top = STRICT ? a.topS : a.topE;
+        const int *top = a.topT;
         int ps, pe;
         rank_pair(st.sg, st.Ws, top, wave_min(min_of<4>(ks)), st.We, top, wave_min(min_of<4>(ke)), lane, ps, pe);
         st.Ws.place(st.sg, ps, lane); st.We.place(st.sg, pe, lane);
@@ -1210,7 +1208,7 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
   }
   if (st.vs) st.Ws.flush(st.sg, lane);
   if (st.ve) st.We.flush(st.sg, lane);
-  if (!STRICT && lane == 0) {
+  if (lane == 0) {
     if (st.nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)st.nNoClass);
     if (st.nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)st.nDegen); atomicMin((i64 *)&a.info->first_degenerate, st.firstDegen + a.indexBase); }
   }
@@ -1391,17 +1389,17 @@ __global__ __launch_bounds__(256) void gather_coverage_kernel(CoverGather g, i64
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < nTiles) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) g.part[q][k] = 0;
+    for (int q = 0; q < 4; q++) g.part[q][k] = 0;
   }
   if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; nextInfo->n_unplaced = 0; }
   if (k >= m) return;
-  const int pe = g.posE[k];
+  const int pe = g.posTE[k];
   u64 c = 0;
   if (pe >= 0 && g.refE[k] >= g.refS[k]) {          // zero-length regions: coverage 0
-    const int ps = g.posS[k], cb = g.classBase[k];
+    const int ps = g.posTS[k], cb = g.classBaseT[k];
     u64 v[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) { const u64 *p = g.pref[q]; v[q] = p[q < 4 ? pe : ps] - (cb >= 0 ? p[cb] : 0); }
+    for (int q = 0; q < 4; q++) { const u64 *p = g.pref[q]; const u64 b = cb >= 0 ? p[cb] : 0; v[q] = p[pe] - b; v[4 + q] = p[ps] - b; }
     // v: 0 Ws(E) 1 Fs(E) 2 We(E) 3 Fe(E) 4 Ws(S-1) 5 Fs(S-1) 6 We(S-1) 7 Fe(S-1)
     const u64 E = (u64)(i64)g.refE[k], S = (u64)(i64)g.refS[k];
     c = v[3] - v[7] + E * (v[0] - v[2]) - v[1] + v[5] - S * (v[4] - v[6]) + v[0] - v[6];
@@ -1666,21 +1664,15 @@ hipError_t launch_coverage(const void *reads, const void *weights, i64 n, const 
   const i64 nChunks = (n + 63) >> 6;
   const i64 waves = (nChunks + a.chunksPerWave - 1) / a.chunksPerWave;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  // one pass per boundary array (see CovState)
-  if (weights) {
-    coverage_walk_kernel<true, false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-    coverage_walk_kernel<true, true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-  } else {
-    coverage_walk_kernel<false, false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-    coverage_walk_kernel<false, true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-  }
+  if (weights) coverage_walk_kernel<true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  else coverage_walk_kernel<false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   return hipGetLastError();
 }
 
 hipError_t launch_coverage_finalize(const CoverArgs &a, i64 histLen, const CoverGather &g, i64 m, u64 *cov, DevInfo *nextInfo, hipStream_t st)
 {
   const int nb = scan_tiles(histLen);
-  for (int q = 0; q < 8 && nb > 0; q += 2)
+  for (int q = 0; q < 4 && nb > 0; q += 2)
     finalize_scan_kernel<<<dim3(nb, 2), 256, 0, st>>>(a.hist[q], a.hist[q + 1], histLen, a.part[q], a.part[q + 1], g.pref[q], g.pref[q + 1]);
   const i64 work = (m > nb ? m : nb) > 0 ? (m > nb ? m : nb) : 1;
   gather_coverage_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(g, m, cov, nb, nextInfo);
