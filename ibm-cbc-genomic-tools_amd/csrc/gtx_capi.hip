@@ -34,7 +34,7 @@ struct gtx_ctx {
   // unsorted reads, bucket path (gtx_bucket.hip): table built with the references, scratch sized by the largest call
   int *d_bkt = nullptr; int nB = 0;                  // posHi | eLo | eHi | sLo | sHi | cls (nB each) | clsStart (nClasses+1)
   unsigned *d_bktCnt = nullptr;                      // count | offset (nB+1) | cursor
-  unsigned short *d_bktIds = nullptr; void *d_bktReads = nullptr; int *d_bktWeights = nullptr; size_t capBkt = 0;
+  void *d_bktReads = nullptr; int *d_bktWeights = nullptr; size_t capBkt = 0;
   int64_t bucketMinReads = 1 << 18;                  // below this the per-read search kernel is used (GTX_BUCKET_MIN_READS)
   int *d_posE = nullptr, *d_posS = nullptr, *d_classBase = nullptr;
   u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr, *d_prefA = nullptr, *d_prefB = nullptr;
@@ -147,7 +147,7 @@ void gtx_destroy(gtx_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
-  dfree(c->d_bktIds); dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_bktCnt);
+  dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_bktCnt);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   for (int k = 0; k < 2; k++) {
@@ -311,7 +311,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
     }
     clsStart[nClasses] = (int32_t)posHi.size();
     c->nB = (int)posHi.size();
-    if (c->nB > 8192) c->nB = 0;                                   // too many buckets for the LDS tables: the search kernel serves
+    if (c->nB > 6144) c->nB = 0;                                   // too many buckets for the LDS tables of the split kernel (16 B per bucket): the search kernel serves
     if (c->nB > 0) {
       std::vector<int32_t> all;
       for (auto *v : {&posHi, &eLo, &eHi, &sLo, &sHi, &cls, &clsStart}) all.insert(all.end(), v->begin(), v->end());
@@ -396,8 +396,7 @@ static int launch_unsorted(gtx_ctx *c, const void *d_reads, const void *d_weight
     return GTX_OK;
   }
   if ((size_t)n > c->capBkt) {
-    dfree(c->d_bktIds); dfree(c->d_bktReads); dfree(c->d_bktWeights); c->capBkt = 0;
-    HIPCHK(c, hipMalloc(&c->d_bktIds, sizeof(unsigned short) * (size_t)n));
+    dfree(c->d_bktReads); dfree(c->d_bktWeights); c->capBkt = 0;
     HIPCHK(c, hipMalloc(&c->d_bktReads, 8 * (size_t)n));
     HIPCHK(c, hipMalloc(&c->d_bktWeights, 4 * (size_t)n));
     c->capBkt = (size_t)n;
@@ -408,7 +407,7 @@ static int launch_unsorted(gtx_ctx *c, const void *d_reads, const void *d_weight
   t.cls = c->d_bkt + 5 * nB; t.clsStart = c->d_bkt + 6 * nB; t.nB = nB;
   gtx::BucketWork w;
   w.count = c->d_bktCnt; w.offset = c->d_bktCnt + nB; w.cursor = c->d_bktCnt + 2 * nB + 1;
-  w.ids = c->d_bktIds; w.tmpReads = c->d_bktReads; w.tmpWeights = c->d_bktWeights;
+  w.tmpReads = c->d_bktReads; w.tmpWeights = c->d_bktWeights;
   HIPCHK(c, gtx::launch_count_bucketed(d_reads, d_weights, n, a, t, w, c->stream));
   return GTX_OK;
 }

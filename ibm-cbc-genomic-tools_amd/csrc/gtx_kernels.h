@@ -90,7 +90,6 @@ struct BucketWork {                // scratch of one call
   unsigned *count;                 // [nB] reads per bucket (zero between calls)
   unsigned *offset;                // [nB+1]
   unsigned *cursor;                // [nB]
-  unsigned short *ids;             // [n] bucket of every read, 0xFFFF = not counted
   void *tmpReads; int *tmpWeights; // [n] the reads grouped by bucket
 };
 int bucket_e_size();

@@ -111,3 +111,17 @@ def test_streamed_unsorted_batches_add_up(beng):
     beng.set_refs(refs, synth.n_classes())
     got, _ = beng.count_stream([(b, None) for b in np.array_split(reads, 7)], 0)
     np.testing.assert_array_equal(got, orc.count(refs, reads, algo=orc.BIN_INDEX))
+
+
+def test_thousands_of_buckets_and_extreme_ends(beng):
+    """5 M regions: ~2500 buckets (the split kernel's per-bucket LDS tables grow, its tile shrinks), weighted and not; reads that
+    end at the top of the coordinate range (rank = everything: no padding value may be mistaken for a boundary)."""
+    rng = np.random.default_rng(11)
+    refs = synth.genome_intervals(5_000_000, 12, 50, 1500)
+    reads = synth.genome_intervals(600_000, 13, 30, 5000)
+    top = 2**31 - 3
+    reads[rng.integers(0, len(reads), size=50), 2] = top
+    reads = reads[rng.permutation(len(reads))]
+    w = rng.integers(0, 4, size=len(reads)).astype(np.int32)
+    check(beng, refs, reads, synth.n_classes())
+    check(beng, refs, reads, synth.n_classes(), w)
