@@ -88,6 +88,21 @@ int GenomicInterval::CalcDirection(GenomicInterval *i, bool sorted_by_strand)
 }
 void GenomicInterval::PrintInterval(FILE *f) { fprintf(f, "%s %c %ld %ld", CHROMOSOME, STRAND, START, STOP); }
 
+bool GenomicInterval::OverlapsWith(GenomicInterval *i, bool ignore_strand)
+{
+  if (strcmp(CHROMOSOME, i->CHROMOSOME) != 0) return false;
+  if (!ignore_strand && STRAND != i->STRAND) return false;
+  return !(START > i->STOP || STOP < i->START);
+}
+
+long int GenomicInterval::CalcOverlap(GenomicInterval *i, bool ignore_strand)
+{
+  if (strcmp(CHROMOSOME, i->CHROMOSOME) != 0) return 0;
+  if (!ignore_strand && STRAND != i->STRAND) return 0;
+  const long int y = std::min(STOP, i->STOP) - std::max(START, i->START) + 1;
+  return y > 0 ? y : 0;
+}
+
 GenomicRegion::GenomicRegion() : n_line(0), LABEL(NULL) {}
 
 GenomicRegion::~GenomicRegion()
@@ -121,6 +136,41 @@ bool GenomicRegion::IsBefore(GenomicRegion *r, bool sorted_by_strand)
   return a->START < b->START;
 }
 
+bool GenomicRegion::IsCompatibleSortedAndNonoverlapping()
+{
+  for (size_t k = 1; k < I.size(); k++) {
+    if (strcmp(I[0]->CHROMOSOME, I[k]->CHROMOSOME) != 0 || I[0]->STRAND != I[k]->STRAND) return false;
+    if (I[k]->START < I[k - 1]->START) return false;
+  }
+  for (size_t k = 1; k < I.size(); k++) if (I[k]->START <= I[k - 1]->STOP) return false;
+  return true;
+}
+
+bool GenomicRegion::OverlapsWith(GenomicRegion *r, bool ignore_strand)
+{
+  for (size_t a = 0; a < I.size(); a++)
+    for (size_t b = 0; b < r->I.size(); b++) if (I[a]->OverlapsWith(r->I[b], ignore_strand)) return true;
+  return false;
+}
+
+long int GenomicRegion::CalcOverlap(GenomicRegion *r, bool ignore_strand)
+{
+  long int y = 0;
+  for (size_t a = 0; a < I.size(); a++)
+    for (size_t b = 0; b < r->I.size(); b++) y += I[a]->CalcOverlap(r->I[b], ignore_strand);
+  return y;
+}
+
+int GenomicRegion::CalcDirection(GenomicRegion *r, bool sorted_by_strand)
+{
+  const int by_chrom = strcmp(I.front()->CHROMOSOME, r->I.front()->CHROMOSOME);
+  if (by_chrom != 0) return by_chrom;
+  if (sorted_by_strand && I.front()->STRAND != r->I.front()->STRAND) return I.front()->STRAND - r->I.front()->STRAND;
+  if (r->I.back()->STOP < I.front()->START) return 1;
+  if (I.back()->STOP < r->I.front()->START) return -1;
+  return 0;
+}
+
 GenomicRegionBED::GenomicRegionBED(char *inp, long int n_line)
 {
   this->n_line = n_line;
@@ -129,9 +179,11 @@ GenomicRegionBED::GenomicRegionBED(char *inp, long int n_line)
   if (st == gtxhost::BED_TOO_FEW_TOKENS) PrintError("number of tokens should be at least 3 for BED format!");
   if (st == gtxhost::BED_BAD_STRAND) { fflush(stdout); std::cerr << "Error: invalid strand '" << bad << "'!\n"; exit(1); }
   n_tokens = f.n_tokens;
-  if (n_tokens == 12) PrintError("multi-interval (BED12) regions are outside the MI355X counting path!");
   LABEL = CopyString(f.label ? f.label : "_");
-  I.push_back(new GenomicInterval(f.chrom, f.strand, f.start, f.stop, n_line));
+  if (n_tokens != 12) { I.push_back(new GenomicInterval(f.chrom, f.strand, f.start, f.stop, n_line)); return; }
+  std::vector<long> iv; gtxhost::BedBlocks(f, &iv);                                     // :2174-2181
+  for (size_t k = 0; k + 1 < iv.size(); k += 2) I.push_back(new GenomicInterval(f.chrom, f.strand, iv[k], iv[k + 1], n_line));
+  if (I.empty()) PrintError("BED12 line without blocks!");
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -139,10 +191,22 @@ GenomicRegionBED::GenomicRegionBED(char *inp, long int n_line)
 // ---------------------------------------------------------------------------------------------------
 GenomicRegionSet::GenomicRegionSet(char *file, unsigned long int buffer_size, bool verbose, bool load_in_memory, bool hide_header)
 {
-  this->file = file == NULL ? NULL : CopyString(file);
+  this->file = file == NULL ? NULL : CopyString(file); this->file_ptr = NULL;
   this->buffer_size = buffer_size;
   this->verbose = verbose;
   this->from_stdin = file == NULL;
+  this->load_in_memory = from_stdin ? false : load_in_memory;
+  this->hide_header = hide_header;
+  this->src = NULL; this->packed = NULL; this->R = NULL; this->n_regions = 0; this->r_index = 0;
+  Init();
+}
+
+GenomicRegionSet::GenomicRegionSet(FILE *file_ptr, unsigned long int buffer_size, bool verbose, bool load_in_memory, bool hide_header)
+{
+  this->file = NULL; this->file_ptr = file_ptr;
+  this->buffer_size = buffer_size;
+  this->verbose = verbose;
+  this->from_stdin = file_ptr == stdin;
   this->load_in_memory = from_stdin ? false : load_in_memory;
   this->hide_header = hide_header;
   this->src = NULL; this->packed = NULL; this->R = NULL; this->n_regions = 0; this->r_index = 0;
@@ -194,7 +258,7 @@ void GenomicRegionSet::Init()
   if (getenv("GTX_NO_WARMUP") == NULL) GtxWarmUp();
   Mark(load_in_memory ? "GenomicRegionSet (in memory): open" : "GenomicRegionSet (stream): open");
   std::string err;
-  if (gtxhost::GtxView::IsGtx(file)) {
+  if (file_ptr == NULL && gtxhost::GtxView::IsGtx(file)) {
     // a packed region file: no text to tokenise; regions are made from its records on demand
     packed = gtxhost::GtxView::Open(file, &err);
     if (!packed) { fprintf(stderr, "%s\n", err.c_str()); exit(1); }
@@ -211,7 +275,7 @@ void GenomicRegionSet::Init()
     }
     return;
   }
-  src = LineSource::Open(file, &err);
+  src = file_ptr ? LineSource::FromFile(file_ptr) : LineSource::Open(file, &err);
   if (!src) { fprintf(stderr, "%s\n", err.c_str()); exit(1); }
   char *line = src->Next();
   while (line && (strncmp(line, "browser ", 8) == 0 || strncmp(line, "track ", 6) == 0)) {
@@ -248,6 +312,7 @@ void GenomicRegionSet::Init()
 void GenomicRegionSet::Reset()
 {
   if (from_stdin) PrintError("stdin cannot be reset!\n");
+  if (file_ptr && !load_in_memory) { if (fseek(file_ptr, 0, SEEK_SET) != 0) PrintError("the stream cannot be reset!\n"); }
   if (load_in_memory) { r_index = 0; return; }
   if (R) { delete R[0]; delete[] R; R = NULL; }
   delete src; src = NULL;
@@ -410,9 +475,13 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
   std::string text;
   for (GenomicRegion *r = set->Get(); r != NULL; r = set->Next()) {
     GenomicInterval *i = r->I.front();
+    if (r->I.size() > 1) {                                  // a multi-interval region: its envelope under -gaps, else outside the path
+      if (!opt.match_gaps) r->PrintError("multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps)!");
+      if (!r->IsCompatibleSortedAndNonoverlapping()) r->PrintError("query regions should be compatible, sorted and non-overlapping!");
+    }
     char buf[64];
     text += i->CHROMOSOME; text += '\t';
-    snprintf(buf, sizeof buf, "%ld\t%ld\t", i->START - 1, i->STOP); text += buf;
+    snprintf(buf, sizeof buf, "%ld\t%ld\t", i->START - 1, r->I.back()->STOP); text += buf;
     text += r->LABEL; text += "\t0\t"; text += i->STRAND; text += '\n';
   }
   BedPacker packer((LineSource *)NULL, opt);
@@ -488,7 +557,7 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
     guard.by_strand = by_strand;
     for (long int k = 0; k < v; k++) {
       GenomicInterval *i = IndexSet->R[k]->I.front();
-      guard.chrom.push_back(i->CHROMOSOME); guard.strand.push_back(i->STRAND); guard.start.push_back(i->START); guard.stop.push_back(i->STOP);
+      guard.chrom.push_back(i->CHROMOSOME); guard.strand.push_back(i->STRAND); guard.start.push_back(i->START); guard.stop.push_back(IndexSet->R[k]->I.back()->STOP);
     }
     char buf[160];
     snprintf(buf, sizeof buf, "\nError: Line %ld: index regions are not sorted (sorted-by-strand = %s)!", v, by_strand ? "true" : "false");
@@ -497,8 +566,15 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   ChromTable chroms;
   const char *last_name = NULL;                                                     // region files repeat a chromosome many times in a row
   for (long int k = 0; k < v; k++) {
-    GenomicInterval *i = IndexSet->R[k]->I.front();
-    if (!sorted && (i->START > i->STOP || i->STOP <= 0)) continue;                 // :5609, :5659
+    GenomicRegion *r = IndexSet->R[k];
+    GenomicInterval *i = r->I.front();
+    if (r->I.size() > 1) {
+      // a multi-interval (BED12) region: with -gaps it is matched on its envelope (:5226, :5752, :5278) -- what the device computes;
+      // without, an overlap needs an interval pair (:1167-1172): outside the path
+      if (!match_gaps) r->PrintError("multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps)!");
+      if (!r->IsCompatibleSortedAndNonoverlapping()) r->PrintError("index regions should be compatible, sorted and non-overlapping!");   // :5607, :5853
+    }
+    if (!sorted && (i->START > r->I.back()->STOP || r->I.back()->STOP <= 0)) continue;   // :5609, :5659
     if (last_name && strcmp(last_name, i->CHROMOSOME) == 0) continue;
     chroms.Add(i->CHROMOSOME); last_name = i->CHROMOSOME;
   }
@@ -512,14 +588,15 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
     GenomicRegion *r = IndexSet->R[k];
     GenomicInterval *i = r->I.front();
     if (k >= v) { refs[3 * k] = -1; refs[3 * k + 1] = 1; refs[3 * k + 2] = 0; continue; }   // behind the out-of-order spot: a placeholder
-    if (sorted && i->START == i->STOP + 1) zero_length_refs = true;
-    if (i->START >= INT_MAX - 1 || i->STOP >= INT_MAX - 1 || i->START <= INT_MIN + 1 || i->STOP <= INT_MIN + 1)
+    const long int STOP = r->I.back()->STOP;                                       // the envelope's end (single interval: its own)
+    if (sorted && i->START == STOP + 1) zero_length_refs = true;
+    if (i->START >= INT_MAX - 1 || STOP >= INT_MAX - 1 || i->START <= INT_MIN + 1 || STOP <= INT_MIN + 1)
       r->PrintError("coordinate does not fit the packed 32-bit representation of the MI355X path!");
     if (!last_name || strcmp(last_name, i->CHROMOSOME) != 0) { last_name = i->CHROMOSOME; last_id = chroms.Find(i->CHROMOSOME); }
     const int id = last_id;
     if (id < 0) { refs[3 * k] = -1; refs[3 * k + 1] = 1; refs[3 * k + 2] = 0; continue; }  // invalid region: never matches
     refs[3 * k] = id + ((strand_aware && i->STRAND == '-') ? n_chrom : 0);
-    refs[3 * k + 1] = (int32_t)i->START; refs[3 * k + 2] = (int32_t)i->STOP;
+    refs[3 * k + 1] = (int32_t)i->START; refs[3 * k + 2] = (int32_t)STOP;
   }
   Mark("index packed");
   gtx_group *grp = Devices();
@@ -533,6 +610,7 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   opt.mode = sorted ? gtxhost::PACK_OVERLAPS_SORTED : gtxhost::PACK_OVERLAPS_UNSORTED;
   opt.chroms = &chroms; opt.strand_aware = strand_aware; opt.sorted_by_strand = by_strand;
   opt.max_label_value = max_label_value; opt.collect_zero_length = !coverage && sorted && zero_length_refs;
+  opt.match_gaps = match_gaps;
   if (v < M) opt.guard = &guard;
   std::vector<int32_t> zero_len;
   unsigned long int *hits = new unsigned long int[M > 0 ? M : 1];
@@ -581,47 +659,236 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   return hits;
 }
 
-static void NoEnumeration()
+// ---- per-query iteration (host side, like the reference's: these calls hand out GenomicRegion pointers) -------------------
+GenomicRegion *GenomicRegionSetOverlaps::GetOverlap(bool match_gaps, bool ignore_strand)
 {
-  fflush(stdout);
-  fprintf(stderr, "\nError: per-pair overlap enumeration (GetMatch/NextMatch) is outside the MI355X counting path!\n");
-  exit(1);
+  for (GenomicRegion *r = GetMatch(); r != NULL; r = NextMatch())
+    if (match_gaps || current_qreg->OverlapsWith(r, ignore_strand)) {
+      if (ignore_strand) return r;
+      if (current_qreg->I.front()->STRAND == r->I.front()->STRAND) return r;
+    }
+  return NULL;
 }
+
+GenomicRegion *GenomicRegionSetOverlaps::NextOverlap(bool match_gaps, bool ignore_strand)
+{
+  for (GenomicRegion *r = NextMatch(); r != NULL; r = NextMatch())
+    if (match_gaps || current_qreg->OverlapsWith(r, ignore_strand)) {
+      if (ignore_strand) return r;
+      if (current_qreg->I.front()->STRAND == r->I.front()->STRAND) return r;
+    }
+  return NULL;
+}
+
+unsigned long int GenomicRegionSetOverlaps::CalcQueryCoverage(bool match_gaps, bool ignore_strand, long int max_label_value)
+{
+  unsigned long int c = 0;
+  for (GenomicRegion *r = GetOverlap(match_gaps, ignore_strand); r != NULL; r = NextOverlap(match_gaps, ignore_strand)) {
+    long int cc = match_gaps ? std::min(r->I.back()->STOP, current_qreg->I.back()->STOP) - std::max(r->I.front()->START, current_qreg->I.front()->START) + 1
+                             : current_qreg->CalcOverlap(r, ignore_strand);
+    cc *= r->GetLabelValue(max_label_value);
+    c += cc;
+  }
+  return c;
+}
+
+unsigned long int GenomicRegionSetOverlaps::CountQueryOverlaps(bool match_gaps, bool ignore_strand, long int max_label_value)
+{
+  unsigned long int c = 0;
+  for (GenomicRegion *r = GetOverlap(match_gaps, ignore_strand); r != NULL; r = NextOverlap(match_gaps, ignore_strand)) c += r->GetLabelValue(max_label_value);
+  return c;
+}
+
+// The bin index of UnsortedGenomicRegionSetOverlaps (genomic_intervals.cpp:5593-5675) for GetMatch/NextMatch: a region lives at the
+// lowest level where its (clamped) start and its stop fall into one bin; a bin keeps its regions in the order they came.
+struct UnsortedGenomicRegionSetOverlaps::MatchIndex {
+  std::vector<int> bits;
+  struct Chrom { std::vector<long int> n_bins; std::vector<std::vector<std::vector<long int> > > bins; };   // [level][bin] -> region ordinals
+  std::map<std::string, Chrom> chrom;
+  // cursor of the walk for the current query (:5729-5764)
+  Chrom *cur; long int start, stop, b, b_stop; int l; long int at;          // `at` counts down inside the bin: last inserted first
+};
 
 UnsortedGenomicRegionSetOverlaps::UnsortedGenomicRegionSetOverlaps(GenomicRegionSet *QuerySet, GenomicRegionSet *IndexSet, const char *bin_bits)
     : GenomicRegionSetOverlaps(QuerySet, IndexSet)
 {
-  (void)bin_bits;     // -B tunes the reference's bin index; the rank structure on the device has no bins
+  // -B tunes the reference's bin index; the rank structure on the device has no bins, the host-side iteration (GetMatch) does
+  match = NULL; bin_bits_ = bin_bits ? bin_bits : "";
   if (IndexSet->load_in_memory == false) { fprintf(stderr, "Error: [UnsortedGenomicRegionSetOverlaps] index regions must be loaded in memory!\n"); exit(1); }
 }
-UnsortedGenomicRegionSetOverlaps::~UnsortedGenomicRegionSetOverlaps() {}
-GenomicRegion *UnsortedGenomicRegionSetOverlaps::GetQuery() { return current_qreg = QuerySet->Get(); }
-GenomicRegion *UnsortedGenomicRegionSetOverlaps::NextQuery() { return current_qreg = QuerySet->Next(); }
-GenomicRegion *UnsortedGenomicRegionSetOverlaps::GetMatch() { NoEnumeration(); return NULL; }
-GenomicRegion *UnsortedGenomicRegionSetOverlaps::NextMatch() { NoEnumeration(); return NULL; }
+UnsortedGenomicRegionSetOverlaps::~UnsortedGenomicRegionSetOverlaps() { delete match; }
+GenomicRegion *UnsortedGenomicRegionSetOverlaps::GetQuery()
+{
+  current_qreg = QuerySet->Get();
+  if (current_qreg && !current_qreg->IsCompatibleSortedAndNonoverlapping()) current_qreg->PrintError("query regions should be compatible, sorted and non-overlapping!");
+  return current_qreg;
+}
+GenomicRegion *UnsortedGenomicRegionSetOverlaps::NextQuery()
+{
+  current_qreg = QuerySet->Next();
+  if (current_qreg && !current_qreg->IsCompatibleSortedAndNonoverlapping()) current_qreg->PrintError("query regions should be compatible, sorted and non-overlapping!");
+  return current_qreg;
+}
+
+GenomicRegion *UnsortedGenomicRegionSetOverlaps::GetMatch()
+{
+  if (!match) {
+    match = new MatchIndex;
+    MatchIndex &mx = *match;
+    // levels: the listed shift widths, the last one forced to 60 bits = one bin (:5619-5636)
+    if (bin_bits_.empty()) mx.bits = {17, 20, 23, 26, 60};
+    else {
+      size_t p = 0;
+      for (;;) { size_t q = bin_bits_.find(',', p); mx.bits.push_back(atoi(bin_bits_.substr(p, q == std::string::npos ? q : q - p).c_str())); if (q == std::string::npos) break; p = q + 1; }
+      mx.bits.push_back(60);
+    }
+    const int L = (int)mx.bits.size();
+    std::map<std::string, long int> chrom_size;
+    for (long int k = 0; k < IndexSet->n_regions; k++) {
+      GenomicRegion *r = IndexSet->R[k];
+      if (!r->IsCompatibleSortedAndNonoverlapping()) r->PrintError("index regions should be compatible, sorted and non-overlapping!");
+      const long int start = r->I.front()->START, stop = r->I.back()->STOP;
+      if (start > stop || stop <= 0) continue;
+      std::map<std::string, long int>::iterator it = chrom_size.find(r->I.front()->CHROMOSOME);
+      if (it == chrom_size.end()) chrom_size[r->I.front()->CHROMOSOME] = stop; else it->second = std::max(it->second, stop);
+    }
+    for (std::map<std::string, long int>::iterator it = chrom_size.begin(); it != chrom_size.end(); it++) {
+      MatchIndex::Chrom &c = mx.chrom[it->first];
+      c.n_bins.resize(L); c.bins.resize(L);
+      for (int l = 0; l < L; l++) { c.n_bins[l] = (it->second >> mx.bits[l]) + 1; c.bins[l].resize((size_t)c.n_bins[l]); }
+    }
+    for (long int k = 0; k < IndexSet->n_regions; k++) {
+      GenomicRegion *r = IndexSet->R[k];
+      long int start = r->I.front()->START; const long int stop = r->I.back()->STOP;
+      if (start > stop || stop <= 0) continue;                                     // :5659
+      if (start <= 0) start = 1;
+      MatchIndex::Chrom &c = mx.chrom[r->I.front()->CHROMOSOME];
+      for (int l = 0; l < L; l++) if ((start >> mx.bits[l]) == (stop >> mx.bits[l])) { c.bins[l][(size_t)(start >> mx.bits[l])].push_back(k); break; }
+    }
+  }
+  MatchIndex &mx = *match;
+  std::map<std::string, MatchIndex::Chrom>::iterator it = mx.chrom.find(current_qreg->I.front()->CHROMOSOME);
+  mx.cur = it == mx.chrom.end() ? NULL : &it->second;
+  if (mx.cur == NULL) return current_ireg = NULL;
+  mx.l = 0;
+  mx.start = current_qreg->I.front()->START; mx.stop = current_qreg->I.back()->STOP;
+  if (mx.stop <= 0) current_qreg->PrintError("stop position must be positive!");
+  if (mx.start > mx.stop) current_qreg->PrintError("start position cannot be greater than stop position!");
+  if (mx.start <= 0) mx.start = 1;
+  mx.b = mx.start >> mx.bits[0];
+  mx.b_stop = std::min(mx.stop >> mx.bits[0], mx.cur->n_bins[0] - 1);
+  if (mx.b >= mx.cur->n_bins[0]) { mx.cur = NULL; return current_ireg = NULL; }
+  mx.at = (long int)mx.cur->bins[0][(size_t)mx.b].size();
+  return NextMatch();
+}
+
+GenomicRegion *UnsortedGenomicRegionSetOverlaps::NextMatch()
+{
+  if (!match || match->cur == NULL) return current_ireg = NULL;
+  MatchIndex &mx = *match;
+  const int L = (int)mx.bits.size();
+  for (;;) {
+    if (mx.l < L && mx.b <= mx.b_stop && mx.b < mx.cur->n_bins[mx.l]) {
+      const std::vector<long int> &bin = mx.cur->bins[mx.l][(size_t)mx.b];
+      while (mx.at > 0) {
+        GenomicRegion *r = IndexSet->R[bin[(size_t)--mx.at]];
+        if (mx.start <= r->I.back()->STOP && mx.stop >= r->I.front()->START) return current_ireg = r;
+      }
+    }
+    mx.b++;
+    if (mx.l >= L || mx.b > mx.b_stop) {
+      mx.l++;
+      if (mx.l >= L) break;
+      mx.b = mx.start >> mx.bits[mx.l];
+      mx.b_stop = std::min(mx.stop >> mx.bits[mx.l], mx.cur->n_bins[mx.l] - 1);
+    }
+    mx.at = (mx.b <= mx.b_stop && mx.b < mx.cur->n_bins[mx.l]) ? (long int)mx.cur->bins[mx.l][(size_t)mx.b].size() : 0;
+  }
+  mx.cur = NULL;
+  return current_ireg = NULL;
+}
 bool UnsortedGenomicRegionSetOverlaps::Done() { return current_qreg == NULL; }
 
 SortedGenomicRegionSetOverlaps::SortedGenomicRegionSetOverlaps(GenomicRegionSet *QuerySet, GenomicRegionSet *IndexSet, bool sorted_by_strand)
     : GenomicRegionSetOverlaps(QuerySet, IndexSet)
 {
   this->sorted_by_strand = sorted_by_strand;
+  buffer_at_ = 0; index_at_ = 0; have_union_ = false; union_strand_ = '+'; union_start_ = union_stop_ = 0;
   current_qreg = QuerySet->Get();
   current_ireg = IndexSet->Get();
 }
 SortedGenomicRegionSetOverlaps::~SortedGenomicRegionSetOverlaps() {}
-GenomicRegion *SortedGenomicRegionSetOverlaps::GetQuery() { return current_qreg = QuerySet->Get(); }
+
+// LoadIndexBuffer (genomic_intervals.cpp:5844-5873): drop the buffer when the query has passed its union interval, then pull index
+// regions while the query is not before them, keeping the ones it meets; the order of the index set is checked as it is pulled
+void SortedGenomicRegionSetOverlaps::LoadIndexBuffer()
+{
+  if (current_qreg == NULL) return;
+  if (!IndexSet->load_in_memory) { fprintf(stderr, "Error: [SortedGenomicRegionSetOverlaps] per-query iteration needs the index set loaded in memory in this build!\n"); exit(1); }
+  if (!buffer_.empty() && have_union_) {
+    GenomicInterval u(union_chrom_.c_str(), union_strand_, union_start_, union_stop_);
+    GenomicInterval q(current_qreg->I.front()->CHROMOSOME, current_qreg->I.front()->STRAND, current_qreg->I.front()->START, current_qreg->I.back()->STOP);
+    if (q.CalcDirection(&u, sorted_by_strand) > 0) { buffer_.clear(); have_union_ = false; }
+  }
+  while (index_at_ < IndexSet->n_regions) {
+    GenomicRegion *r = IndexSet->R[index_at_];
+    if (!r->IsCompatibleSortedAndNonoverlapping()) r->PrintError("index regions should be compatible, sorted and non-overlapping!");
+    const int d = current_qreg->CalcDirection(r, sorted_by_strand);
+    if (d < 0) break;
+    if (d == 0) {
+      if (buffer_.empty()) { union_chrom_ = r->I.front()->CHROMOSOME; union_strand_ = r->I.front()->STRAND; union_start_ = r->I.front()->START; union_stop_ = r->I.back()->STOP; have_union_ = true; }
+      else { union_start_ = std::min(union_start_, r->I.front()->START); union_stop_ = std::max(union_stop_, r->I.back()->STOP); }
+      buffer_.push_back(index_at_);
+    }
+    index_at_++;
+    if (index_at_ < IndexSet->n_regions && IndexSet->R[index_at_]->IsBefore(r, sorted_by_strand))
+      IndexSet->R[index_at_]->PrintError(std::string("index regions are not sorted (sorted-by-strand = ") + (sorted_by_strand ? "true" : "false") + ")!");
+  }
+  buffer_at_ = 0;
+  current_ireg = buffer_.empty() ? NULL : IndexSet->R[buffer_[0]];
+}
+
+GenomicRegion *SortedGenomicRegionSetOverlaps::GetQuery()
+{
+  current_qreg = QuerySet->Get();
+  if (current_qreg && !current_qreg->IsCompatibleSortedAndNonoverlapping()) current_qreg->PrintError("query regions should be compatible, sorted and non-overlapping!");
+  LoadIndexBuffer();
+  return current_qreg;
+}
 GenomicRegion *SortedGenomicRegionSetOverlaps::NextQuery()
 {
   GenomicRegion *prev = QuerySet->Get();
   GenomicRegion *next = QuerySet->Next(true);
+  if (next != NULL && !next->IsCompatibleSortedAndNonoverlapping()) next->PrintError("query regions should be compatible, sorted and non-overlapping!");
   if (next != NULL && prev != NULL && next->IsBefore(prev, sorted_by_strand))
     next->PrintError(std::string("query regions are not sorted (sorted-by-strand = ") + (sorted_by_strand ? "true" : "false") + ")!");
   if (!QuerySet->load_in_memory && next != NULL) delete prev;
-  return current_qreg = next;
+  current_qreg = next;
+  LoadIndexBuffer();
+  return current_qreg;
 }
-GenomicRegion *SortedGenomicRegionSetOverlaps::GetMatch() { NoEnumeration(); return NULL; }
-GenomicRegion *SortedGenomicRegionSetOverlaps::NextMatch() { NoEnumeration(); return NULL; }
-bool SortedGenomicRegionSetOverlaps::Done() { return current_qreg == NULL; }
+// :5903-5918: buffered regions the query has passed are dropped, the first one ahead of it ends the walk
+GenomicRegion *SortedGenomicRegionSetOverlaps::GetMatch()
+{
+  if (current_qreg == NULL || current_ireg == NULL) return NULL;
+  for (;;) {
+    const int d = current_qreg->CalcDirection(current_ireg, sorted_by_strand);
+    if (d > 0) {
+      buffer_.erase(buffer_.begin() + (long)buffer_at_);
+      if (buffer_at_ >= buffer_.size()) return current_ireg = NULL;
+      current_ireg = IndexSet->R[buffer_[buffer_at_]];
+    } else if (d < 0) return NULL;
+    else return current_ireg;
+  }
+}
+GenomicRegion *SortedGenomicRegionSetOverlaps::NextMatch()
+{
+  buffer_at_++;
+  current_ireg = buffer_at_ >= buffer_.size() ? NULL : IndexSet->R[buffer_[buffer_at_]];
+  if (current_ireg == NULL) return NULL;
+  return GetMatch();
+}
+bool SortedGenomicRegionSetOverlaps::Done() { return current_qreg == NULL || (index_at_ >= IndexSet->n_regions && buffer_.empty()); }
 
 // ---------------------------------------------------------------------------------------------------
 // scanners

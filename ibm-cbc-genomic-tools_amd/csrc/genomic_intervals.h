@@ -39,6 +39,8 @@ class GenomicInterval
   void PrintInterval(FILE *file_ptr);
   size_t GetSize() { return (size_t)(STOP - START + 1); }
   int CalcDirection(GenomicInterval *i, bool sorted_by_strand);   // <0 before i, 0 overlapping, >0 after (genomic_intervals.cpp:448-459)
+  bool OverlapsWith(GenomicInterval *i, bool ignore_strand);      // :624-630
+  long int CalcOverlap(GenomicInterval *i, bool ignore_strand);   // :427-432
 
   char *CHROMOSOME;
   char STRAND;
@@ -59,6 +61,10 @@ class GenomicRegion
   size_t GetSize(bool skip_gaps);                                 // genomic_intervals.cpp:1049-1058
   long int GetLabelValue(long int max_label_value);               // :1081-1085
   bool IsBefore(GenomicRegion *r, bool sorted_by_strand);         // :1177-1180
+  bool IsCompatibleSortedAndNonoverlapping();                     // :1153-1161 (intervals of one region: same chromosome and strand, start-sorted, disjoint)
+  bool OverlapsWith(GenomicRegion *r, bool ignore_strand);        // :1167-1172 (any interval pair)
+  long int CalcOverlap(GenomicRegion *r, bool ignore_strand);     // :1196-1202 (sum over interval pairs)
+  int CalcDirection(GenomicRegion *r, bool sorted_by_strand);     // :1225-1236 (on the envelopes)
 
   long int n_line;
   char *LABEL;
@@ -68,7 +74,8 @@ class GenomicRegion
 class GenomicRegionBED : public GenomicRegion
 {
  public:
-  // parses one BED line (the line is modified); genomic_intervals.cpp:2157-2182
+  // parses one BED line (the line is modified); genomic_intervals.cpp:2157-2182.  A 12-column line becomes a region of several
+  // intervals (its blocks, :2174-2181)
   GenomicRegionBED(char *inp, long int n_line);
   long int n_tokens;
 };
@@ -78,6 +85,8 @@ class GenomicRegionSet
 {
  public:
   GenomicRegionSet(char *file, unsigned long int buffer_size, bool verbose, bool load_in_memory, bool hide_header = true);
+  // the same from an open stream (genomic_intervals.h:1836, .cpp:3685-3696); stdin is never loaded in memory
+  GenomicRegionSet(FILE *file_ptr, unsigned long int buffer_size, bool verbose, bool load_in_memory, bool hide_header = true);
   ~GenomicRegionSet();
 
   GenomicRegion *Get();                                           // genomic_intervals.cpp:3845-3849
@@ -93,6 +102,7 @@ class GenomicRegionSet
   const gtxhost::GtxView *DetachPacked(long int *current_record);
 
   char *file;
+  FILE *file_ptr;                                                  // the FILE* constructor's stream (NULL otherwise)
   unsigned long int buffer_size;
   bool verbose, load_in_memory, from_stdin, hide_header;
   long int n_regions;
@@ -122,6 +132,14 @@ class GenomicRegionSetOverlaps
   virtual GenomicRegion *NextMatch() = 0;
   virtual bool Done() = 0;
 
+  // Per-query iteration, on the host like the reference's (it hands out GenomicRegion pointers): the index regions that overlap the
+  // current query after the gap / strand filter (genomic_intervals.cpp:5224-5248), and the two per-query sums over them --
+  // label values (:5291-5296) and overlap lengths x label values of the INDEX regions (:5254-5263).
+  GenomicRegion *GetOverlap(bool match_gaps, bool ignore_strand);
+  GenomicRegion *NextOverlap(bool match_gaps, bool ignore_strand);
+  unsigned long int CalcQueryCoverage(bool match_gaps, bool ignore_strand, long int max_label_value);
+  unsigned long int CountQueryOverlaps(bool match_gaps, bool ignore_strand, long int max_label_value);
+
   // hits[k] = sum over query regions q of w_q * [q overlaps index region k], index FILE order;
   // a new[] array the caller releases (genomic_intervals.cpp:5304-5317).  Runs on the GPU.
   unsigned long int *CountIndexOverlaps(bool match_gaps, bool ignore_strand, long int max_label_value);
@@ -150,11 +168,17 @@ class UnsortedGenomicRegionSetOverlaps : public GenomicRegionSetOverlaps
   ~UnsortedGenomicRegionSetOverlaps();
   GenomicRegion *GetQuery();
   GenomicRegion *NextQuery();
+  // candidates whose envelope meets the current query's, in the reference's order: bin level by bin level, bins in ascending order,
+  // inside a bin the region inserted last first (genomic_intervals.cpp:5717-5764).  A host-side bin index, built at the first call.
   GenomicRegion *GetMatch();
   GenomicRegion *NextMatch();
   bool Done();
  protected:
   bool UsesSortedMerge() const { return false; }
+ private:
+  struct MatchIndex;
+  MatchIndex *match;
+  std::string bin_bits_;
 };
 
 // genomic_intervals.h:2733 -- rules of the sorted merge (both sets sorted by chromosome[, strand],
@@ -166,6 +190,8 @@ class SortedGenomicRegionSetOverlaps : public GenomicRegionSetOverlaps
   ~SortedGenomicRegionSetOverlaps();
   GenomicRegion *GetQuery();
   GenomicRegion *NextQuery();
+  // the merge's buffer of index regions around the current query (LoadIndexBuffer :5844-5873, GetMatch :5903-5918), on the host;
+  // the index set must be loaded in memory
   GenomicRegion *GetMatch();
   GenomicRegion *NextMatch();
   bool Done();
@@ -173,6 +199,12 @@ class SortedGenomicRegionSetOverlaps : public GenomicRegionSetOverlaps
   bool UsesSortedMerge() const { return true; }
   bool SortedByStrand() const { return sorted_by_strand; }
   bool sorted_by_strand;
+ private:
+  void LoadIndexBuffer();
+  std::vector<long int> buffer_;                                   // ordinals of the buffered index regions
+  size_t buffer_at_;
+  long int index_at_;                                              // next index region to pull
+  bool have_union_; std::string union_chrom_; char union_strand_; long int union_start_, union_stop_;
 };
 
 // ---- GenomicRegionSetIndex (genomic_intervals.h:2505) -- only what the scanners' reference filter uses ---

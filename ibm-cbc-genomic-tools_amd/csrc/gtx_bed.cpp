@@ -39,6 +39,14 @@ LineSource *LineSource::Open(const char *path, std::string *err)
   return s;
 }
 
+LineSource *LineSource::FromFile(FILE *fp)
+{
+  LineSource *s = new LineSource();
+  s->buf_.resize(1u << 20);
+  s->fp_ = fp; s->is_stdin_ = true;                       // never closed here: the caller owns the stream
+  return s;
+}
+
 LineSource::~LineSource()
 {
   if (gz_) gzclose(gz_);
@@ -196,7 +204,25 @@ BedStatus ParseBedLine(char *line, BedFields *o, char **bad)
     else if (!strcmp(t, "-1") || !strcmp(t, "-")) o->strand = '-';
     else { *bad = t; return BED_BAD_STRAND; }
   }
+  o->block_sizes = o->block_starts = nullptr; o->n_blocks = 0;
+  if (o->n_tokens == 12) {                                  // thickStart, thickEnd, itemRgb, blockCount, blockSizes, blockStarts
+    (void)TakeToken(&cur, sep); (void)TakeToken(&cur, sep); (void)TakeToken(&cur, sep);
+    o->n_blocks = FastAtol(TakeToken(&cur, sep));
+    o->block_sizes = TakeToken(&cur, sep);
+    o->block_starts = TakeToken(&cur, sep);
+  }
   return BED_OK;
+}
+
+void BedBlocks(const BedFields &f, std::vector<long> *iv)
+{
+  iv->clear();
+  char *sz = f.block_sizes, *st = f.block_starts;
+  for (long k = 0; k < f.n_blocks; k++) {
+    const long size = FastAtol(TakeToken(&sz, ',')), off = FastAtol(TakeToken(&st, ','));
+    const long a = f.start + off;
+    iv->push_back(a); iv->push_back(size + a - 1);
+  }
 }
 
 // One pass over a line of the common shape -- TAB-separated, no blanks anywhere, 3..11 columns, a plain strand
@@ -522,11 +548,22 @@ void ParsePiece(Piece *p, const PackOptions &o)
     }
     if (st == BED_TOO_FEW_TOKENS) { SetErr(&p->err, line_no, "number of tokens should be at least 3 for BED format!"); break; }
     if (st == BED_BAD_STRAND) { SetErr(&p->err, line_no, std::string("Error: invalid strand '") + bad + "'!", true); break; }
-    if (f.n_tokens == 12) { SetErr(&p->err, line_no, "multi-interval (BED12) regions are outside the MI355X counting path!"); break; }
+    const long label_value = f.label ? FastAtol(f.label) : 0;      // (before the block lists are cut into tokens)
+    if (f.n_tokens == 12) {
+      // a multi-interval region: under -gaps it is matched on its envelope [first interval's start, last interval's stop]
+      // (genomic_intervals.cpp:5226, :5752, :5278); its intervals must be sorted and disjoint (:1153-1161, checked at :5709, :5880)
+      const bool overlaps = o.mode == PACK_OVERLAPS_SORTED || o.mode == PACK_OVERLAPS_UNSORTED;
+      if (!overlaps || !o.match_gaps || f.n_blocks < 1) { SetErr(&p->err, line_no, "multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps)!"); break; }
+      std::vector<long> iv; BedBlocks(f, &iv);
+      bool ok = true;
+      for (size_t k = 2; k < iv.size(); k += 2) if (iv[k] < iv[k - 2] || iv[k] <= iv[k - 1]) ok = false;
+      if (!ok) { SetErr(&p->err, line_no, "query regions should be compatible, sorted and non-overlapping!"); break; }
+      f.start = iv.front(); f.stop = iv.back();
+    }
     if (f.start >= INT_MAX - 1 || f.stop >= INT_MAX - 1 || f.start <= INT_MIN + 1 || f.stop <= INT_MIN + 1) {
       SetErr(&p->err, line_no, "coordinate does not fit the packed 32-bit representation of the MI355X path!"); break;
     }
-    if (!HandleRecord(p, o, f, f.label ? FastAtol(f.label) : 0, line_no, cc)) break;
+    if (!HandleRecord(p, o, f, label_value, line_no, cc)) break;
   }
   p->n_lines = line_no - (p->first_line - 1);
 }

@@ -26,6 +26,7 @@ class LineSource {
  public:
   // path == NULL reads stdin.  On failure returns NULL and sets *err to the reference's message.
   static LineSource *Open(const char *path, std::string *err);
+  static LineSource *FromFile(FILE *fp);        // an already open stream (the FILE* constructor of GenomicRegionSet, genomic_intervals.h:1836)
   ~LineSource();
 
   // Next complete line as a mutable NUL-terminated string (valid until the next call), or NULL at
@@ -60,7 +61,12 @@ struct BedFields {
   long start, stop;                  // 1-based inclusive
   char strand;
   int n_tokens;
+  // BED12 (n_tokens == 12, genomic_intervals.cpp:2174-2181): the blocks become the region's intervals
+  char *block_sizes = nullptr, *block_starts = nullptr; long n_blocks = 0;
 };
+// the intervals of a 12-column line, as the reference computes them: interval k = [start + off_k, start + off_k + size_k - 1]
+// (missing list entries read as 0, like atol of an empty token).  iv receives 2 * n_blocks longs.
+void BedBlocks(const BedFields &f, std::vector<long> *iv);
 enum BedStatus { BED_OK = 0, BED_TOO_FEW_TOKENS, BED_BAD_STRAND };
 // Parses in place (the line is cut into tokens).  On BED_BAD_STRAND *bad points at the strand token.
 BedStatus ParseBedLine(char *line, BedFields *out, char **bad);
@@ -125,6 +131,8 @@ struct PackOptions {
   bool sorted_by_strand = false;     // order check uses (chrom, strand, start) instead of (chrom, start)
   long max_label_value = 1;          // > 1: emit weights = min(max, atol(label))
   bool collect_zero_length = false;  // keep (class, start, weight) of zero-length reads (sorted mode correction)
+  bool match_gaps = false;           // overlaps: multi-interval (BED12) regions are matched on their envelope -- what -gaps means
+                                     // (genomic_intervals.cpp:5226, :5752); without it they are outside the path
   int threads = 0;                   // 0 = hardware concurrency
   IndexGuard *guard = nullptr;       // PACK_OVERLAPS_SORTED with an out-of-order index set (forces one thread)
 };

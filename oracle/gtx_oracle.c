@@ -34,6 +34,12 @@
 /* a message buffer + status code; the CLI main() turns them back into stderr + exit(1).      */
 /* ------------------------------------------------------------------------------------------ */
 static char g_err[1024];
+/* per-query iteration instead of the per-index-region sums (GetOverlap/NextOverlap loop of a caller, genomic_intervals.cpp:5224-5248;
+ * CountQueryOverlaps :5291-5296, CalcQueryCoverage :5254-5263): 0 = off, 1 = print every accepted (query line, index label) pair in
+ * the order the reference's iterators deliver them, 2 = print per query the two sums over its overlaps (label values of the INDEX
+ * regions; overlap length x label value) */
+static int g_pairs_mode;
+static unsigned long g_q_count, g_q_cover;
 static int  g_failed;
 #define FAIL(...) do { if (!g_failed) { snprintf(g_err, sizeof g_err, __VA_ARGS__); g_failed = 1; } } while (0)
 
@@ -306,6 +312,18 @@ static uint64_t pair_value(const orc_chroms *c, const orc_region *q, const orc_r
   return (uint64_t)cc;
 }
 
+static void per_query_pair(const orc_chroms *c, const orc_region *q, const orc_region *r, int match_gaps, int ignore_strand, long max_label_value)
+{
+  if (g_pairs_mode == 1) { printf("%ld\t%s\n", q->n_line, r->label ? r->label : "_"); return; }
+  long lv = label_value(r, max_label_value);
+  long cc;
+  if (match_gaps) {
+    long lo = front_start(q) > front_start(r) ? front_start(q) : front_start(r), hi = back_stop(q) < back_stop(r) ? back_stop(q) : back_stop(r);
+    cc = hi - lo + 1;
+  } else cc = region_calc_overlap(c, q, r, ignore_strand);
+  g_q_count += (unsigned long)lv; g_q_cover += (unsigned long)(cc * lv);
+}
+
 /* genomic_intervals.cpp:5224-5248: filter applied to every candidate */
 static int accept_overlap(const orc_chroms *c, const orc_region *q, const orc_region *r, int match_gaps, int ignore_strand)
 {
@@ -482,13 +500,16 @@ static int count_with_binindex(orc_chroms *chroms, const orc_set *set, const orc
             for (long b = b0; b <= b1; b++)
               for (long z = bx->head[q.chrom][l][b]; z != -1; z = bx->next[z]) {
                 const orc_region *r = &set->R[z];
-                if (s <= back_stop(r) && e >= front_start(r) && accept_overlap(chroms, &q, r, match_gaps, ignore_strand))
-                  hits[z] += pair_value(chroms, &q, r, coverage, match_gaps, ignore_strand, w);   /* :5312 / :5280 */
+                if (s <= back_stop(r) && e >= front_start(r) && accept_overlap(chroms, &q, r, match_gaps, ignore_strand)) {
+                  if (g_pairs_mode) per_query_pair(chroms, &q, r, match_gaps, ignore_strand, max_label_value);
+                  else hits[z] += pair_value(chroms, &q, r, coverage, match_gaps, ignore_strand, w);   /* :5312 / :5280 */
+                }
               }
           }
         }
       }
     }
+    if (g_pairs_mode == 2 && !rc) { printf("%ld\t%lu\t%lu\n", q.n_line, g_q_count, g_q_cover); g_q_count = g_q_cover = 0; }
     region_free(&q);
     if (rc) return -1;
   }
@@ -517,7 +538,8 @@ static int count_with_merge(orc_chroms *chroms, const orc_set *set, orc_source *
     while (ip < set->n) {
       const orc_region *r = &set->R[ip];
       /* n_line of index regions was overwritten with their ordinal at :5309 */
-      if (!region_sorted_nonoverlapping(r)) { FAIL("\nError: Line %ld: index regions should be compatible, sorted and non-overlapping!", ip); rc = -1; break; }
+      /* (a caller that only iterates never overwrites them: then they are the file's line numbers) */
+      if (!region_sorted_nonoverlapping(r)) { FAIL("\nError: Line %ld: index regions should be compatible, sorted and non-overlapping!", g_pairs_mode ? r->n_line : ip); rc = -1; break; }
       int d = region_direction(chroms, &q, r->chrom, r->strand, front_start(r), back_stop(r), by_strand);
       if (d < 0) break;
       if (d == 0) {
@@ -527,7 +549,7 @@ static int count_with_merge(orc_chroms *chroms, const orc_set *set, orc_source *
       }
       ip++;
       if (ip < set->n && region_is_before(chroms, &set->R[ip], r, by_strand)) {  /* :5868 */
-        FAIL("\nError: Line %ld: index regions are not sorted (sorted-by-strand = %s)!", ip, by_strand ? "true" : "false"); rc = -1; break;
+        FAIL("\nError: Line %ld: index regions are not sorted (sorted-by-strand = %s)!", g_pairs_mode ? set->R[ip].n_line : ip, by_strand ? "true" : "false"); rc = -1; break;
       }
     }
     if (rc) break;
@@ -539,9 +561,13 @@ static int count_with_merge(orc_chroms *chroms, const orc_set *set, orc_source *
       int d = region_direction(chroms, &q, r->chrom, r->strand, front_start(r), back_stop(r), by_strand);
       if (d > 0) { memmove(buf + j, buf + j + 1, sizeof(long) * (nbuf - j - 1)); nbuf--; continue; }   /* erase, stay */
       if (d < 0) break;
-      if (accept_overlap(chroms, &q, r, match_gaps, ignore_strand)) hits[buf[j]] += pair_value(chroms, &q, r, coverage, match_gaps, ignore_strand, w);
+      if (accept_overlap(chroms, &q, r, match_gaps, ignore_strand)) {
+        if (g_pairs_mode) per_query_pair(chroms, &q, r, match_gaps, ignore_strand, max_label_value);
+        else hits[buf[j]] += pair_value(chroms, &q, r, coverage, match_gaps, ignore_strand, w);
+      }
       j++;
     }
+    if (g_pairs_mode == 2) { printf("%ld\t%lu\t%lu\n", q.n_line, g_q_count, g_q_cover); g_q_count = g_q_cover = 0; }
     if (have_prev) region_free(&prev);
     prev = q; have_prev = 1;
     memset(&q, 0, sizeof q);
@@ -1054,7 +1080,9 @@ int main(int argc, char **argv)
   const char *method = "binomial"; int norm = 0, cmp = 0; double pval_cut = 1.0, qval_cut = 0.05;
   int is_cov = !strcmp(op, "coverage") || !strcmp(op, "density");
   double min_density = 0.0;
-  if (strcmp(op, "count") && strcmp(op, "rpkm") && !is_cov && !is_scan) { fprintf(stderr, "Unknown operation '%s'!\n", op); return 1; }
+  if (!strcmp(op, "pairs")) g_pairs_mode = 1;                                         /* checker-only operations: the iterator API */
+  if (!strcmp(op, "qstats")) g_pairs_mode = 2;
+  if (strcmp(op, "count") && strcmp(op, "rpkm") && !is_cov && !is_scan && !g_pairs_mode) { fprintf(stderr, "Unknown operation '%s'!\n", op); return 1; }
   int a = 2;
   for (; a < argc && argv[a][0] == '-'; a++) {                                     /* core.cpp:2420-2436 */
     const char *o = argv[a];
@@ -1095,7 +1123,8 @@ int main(int argc, char **argv)
     int rc;
     if (sorted) rc = count_with_merge(&ch, &ref, &src, by_strand, gaps, ign, mlv, hits, is_cov);
     else { orc_binindex bx; rc = binindex_build(&ch, &ref, bits, &bx); if (!rc) rc = count_with_binindex(&ch, &ref, &bx, &src, gaps, ign, mlv, hits, is_cov); }
-    if (rc) die();
+    if (rc) { fflush(stdout); die(); }
+    if (g_pairs_mode) return 0;
     if (!strcmp(op, "density")) {                                                  /* genomic_overlaps.cpp:477-486 */
       for (long k = 0; k < ref.n; k++) {
         const orc_region *r = &ref.R[k];

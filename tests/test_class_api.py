@@ -1,0 +1,122 @@
+"""The iteration members of the class API (GetQuery/NextQuery, GetMatch/NextMatch through GetOverlap/NextOverlap,
+CountQueryOverlaps, CalcQueryCoverage, the FILE* constructor), exercised by a caller written like the reference's own tools
+(tests/tools/api_caller.cpp, compiled against csrc/genomic_intervals.h) and compared -- pair by pair, IN ORDER -- with the oracle's
+restatement of the reference iterators.  These members are host-side iterators in the reference and here: no GPU is involved, so this
+runs in the CPU suite."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CALLER = os.path.join(ROOT, "ibm-cbc-genomic-tools_amd", "csrc", "api_caller")
+NAMES = ["chr1", "chr10", "chr2", "chrX"]
+
+
+def run_caller(args, cwd):
+    env = dict(os.environ, GTX_NO_WARMUP="1")                      # no device is needed for iteration: do not even try to open one
+    r = subprocess.run([CALLER] + args, capture_output=True, cwd=cwd, env=env)
+    return r.returncode, r.stdout.decode(), r.stderr.decode()
+
+
+def bed6(path, rows):
+    with open(path, "w") as f:
+        for r in rows:
+            f.write("\t".join(str(x) for x in r) + "\n")
+
+
+def make_regions(rng, n, span, maxlen, bed12_frac=0.0, sort=True):
+    rows = []
+    c = rng.integers(0, len(NAMES), size=n); s = rng.integers(0, span, size=n)
+    if sort:
+        o = np.lexsort((s, np.array([NAMES[i] for i in c])))
+        c, s = c[o], s[o]
+    for i in range(n):
+        ln = int(rng.integers(1, maxlen))
+        strand = "+-"[int(rng.integers(0, 2))]
+        lab = int(rng.integers(0, 7))
+        if rng.random() < bed12_frac:
+            nb = int(rng.integers(2, 5))
+            sizes, starts, at = [], [], 0
+            for _ in range(nb):
+                starts.append(at); sz = int(rng.integers(1, 40)); sizes.append(sz); at += sz + int(rng.integers(1, 60))
+            end = int(s[i]) + starts[-1] + sizes[-1]
+            rows.append([NAMES[c[i]], int(s[i]), end, lab, 0, strand, int(s[i]), end, 0, nb, ",".join(map(str, sizes)) + ",", ",".join(map(str, starts)) + ","])
+        else:
+            rows.append([NAMES[c[i]], int(s[i]), int(s[i]) + ln, lab, 0, strand])
+    return rows
+
+
+@pytest.fixture(scope="module")
+def api_beds(tmp_path_factory):
+    d = tmp_path_factory.mktemp("api")
+    rng = np.random.default_rng(41)
+    bed6(d / "refs.bed", [r[:3] + ["g%d_%s" % (i, r[3])] + r[4:] for i, r in enumerate(make_regions(rng, 600, 300_000, 4000))])
+    bed6(d / "refs_wide.bed", [r[:3] + ["w%d" % i] + r[4:] for i, r in enumerate(make_regions(rng, 400, 3_000_000, 600_000))])   # regions on several bin levels
+    bed6(d / "refs12.bed", make_regions(rng, 300, 300_000, 3000, bed12_frac=0.4))
+    bed6(d / "reads.bed", make_regions(rng, 1500, 300_000, 500))
+    bed6(d / "reads_wide.bed", make_regions(rng, 500, 3_000_000, 200_000))
+    bed6(d / "reads12.bed", make_regions(rng, 800, 300_000, 500, bed12_frac=0.3))
+    bed6(d / "reads_shuffled.bed", make_regions(rng, 800, 300_000, 500, sort=False))
+    # strand-sorted variants for -S -s
+    def by_strand(rows):
+        return sorted(rows, key=lambda r: (r[0], r[5], r[1]))
+    bed6(d / "refs_strand.bed", by_strand([r[:3] + ["s%d" % i] + r[4:] for i, r in enumerate(make_regions(rng, 500, 300_000, 4000))]))
+    bed6(d / "reads_strand.bed", by_strand(make_regions(rng, 1200, 300_000, 500)))
+    bed6(d / "reads_bad.bed", [["chr1", 100, 200, 1, 0, "+"], ["chr1", 500, 400, 1, 0, "+"]])          # start > stop: the bin index's error
+    return d
+
+
+RUNS = [
+    ["pairs", "-i", "refs.bed", "reads.bed"],
+    ["pairs", "refs.bed", "reads.bed"],
+    ["pairs", "-i", "refs_wide.bed", "reads_wide.bed"],                       # several bin levels: level by level, bin by bin, last inserted first
+    ["pairs", "-i", "-B", "10,14,18", "refs_wide.bed", "reads_wide.bed"],
+    ["pairs", "-i", "refs.bed", "reads_shuffled.bed"],
+    ["pairs", "-S", "-i", "refs.bed", "reads.bed"],
+    ["pairs", "-S", "refs.bed", "reads.bed"],
+    ["pairs", "-S", "-s", "refs_strand.bed", "reads_strand.bed"],
+    ["pairs", "-S", "-i", "refs_wide.bed", "reads_wide.bed"],
+    ["pairs", "-i", "refs12.bed", "reads12.bed"],                             # multi-interval regions: an overlap needs an interval pair
+    ["pairs", "-i", "-gaps", "refs12.bed", "reads12.bed"],                    # ... or just the envelopes
+    ["pairs", "-S", "-i", "refs12.bed", "reads12.bed"],
+    ["pairs", "-S", "-gaps", "refs12.bed", "reads12.bed"],
+    ["qstats", "-i", "--max-label-value", "5", "refs.bed", "reads.bed"],
+    ["qstats", "--max-label-value", "3", "refs12.bed", "reads12.bed"],
+    ["qstats", "-i", "-gaps", "--max-label-value", "4", "refs12.bed", "reads12.bed"],
+    ["qstats", "-S", "-i", "--max-label-value", "5", "refs.bed", "reads.bed"],
+    ["qstats", "-S", "-gaps", "refs12.bed", "reads12.bed"],
+    ["pairs", "-S", "-i", "refs.bed", "reads_shuffled.bed"],                  # unsorted queries: the merge's error, after the pairs before it
+    ["pairs", "-S", "-i", "reads_shuffled.bed", "reads.bed"],                 # unsorted index: noticed when the merge pulls it
+    ["pairs", "-i", "refs.bed", "reads_bad.bed"],                             # invalid query: the bin index's error
+]
+
+
+@pytest.mark.parametrize("args", RUNS, ids=[" ".join(a) for a in RUNS])
+def test_iteration_api_equals_the_restated_reference(api_beds, args):
+    assert os.path.exists(CALLER), "build the package first (python __graft_entry__.py)"
+    want = subprocess.run([orc.CLI] + args, capture_output=True, cwd=api_beds)
+    if args[0] == "pairs":
+        got = run_caller(args, api_beds)
+        assert got[0] == want.returncode, got[2]
+        assert got[1] == want.stdout.decode()
+        if want.returncode != 0:
+            assert got[2].strip() == want.stderr.decode().strip()
+        return
+    # qstats: the oracle prints "line count coverage"; the caller makes ONE walk per query (qcount or qcover)
+    rows = [l.split("\t") for l in want.stdout.decode().splitlines()]
+    for mode, col in (("qcount", 1), ("qcover", 2)):
+        got = run_caller([mode] + args[1:], api_beds)
+        assert got[0] == want.returncode == 0, got[2]
+        assert got[1] == "".join("%s\t%s\n" % (r[0], r[col]) for r in rows)
+
+
+def test_the_fixture_is_not_vacuous(api_beds):
+    out = subprocess.run([orc.CLI, "pairs", "-i", "refs_wide.bed", "reads_wide.bed"], capture_output=True, cwd=api_beds).stdout.decode().splitlines()
+    assert len(out) > 2000
+    out12 = subprocess.run([orc.CLI, "pairs", "-i", "refs12.bed", "reads12.bed"], capture_output=True, cwd=api_beds).stdout.decode().splitlines()
+    gaps12 = subprocess.run([orc.CLI, "pairs", "-i", "-gaps", "refs12.bed", "reads12.bed"], capture_output=True, cwd=api_beds).stdout.decode().splitlines()
+    assert len(gaps12) > len(out12) > 50                                       # -gaps matches pairs that only meet in a gap

@@ -505,3 +505,50 @@ def test_sorted_merge_cli_cases_are_what_they_claim(merge_beds):
     assert rc == 1 and "query regions are not sorted" in err
     rc, out, err = oracle(["count", "-S", "-i", "refs_inverted.bed", "reads_inverted.bed"], cwd=merge_beds)
     assert rc == 0 and len(out.splitlines()) == 300
+
+
+# ---- multi-interval (BED12) regions: matched on their envelopes under -gaps (genomic_intervals.cpp:5226, :5752, :5278) -----------
+@pytest.fixture(scope="module")
+def bed12(tmp_path_factory):
+    from test_class_api import bed6, make_regions
+    d = tmp_path_factory.mktemp("bed12")
+    rng = np.random.default_rng(43)
+    bed6(d / "refs12.bed", [r[:3] + ["b%d" % i] + r[4:] for i, r in enumerate(make_regions(rng, 2000, 2_000_000, 3000, bed12_frac=0.4))])
+    bed6(d / "reads12.bed", make_regions(rng, 60000, 2_000_000, 400, bed12_frac=0.3))
+    bed6(d / "reads12_shuffled.bed", make_regions(rng, 30000, 2_000_000, 400, bed12_frac=0.3, sort=False))
+    bad = make_regions(rng, 50, 2_000_000, 400, bed12_frac=1.0)
+    bad[20][10], bad[20][11] = "30,30,", "0,10,"                                   # blocks overlap: the region check fails
+    bed6(d / "reads12_bad.bed", bad)
+    return d
+
+
+BED12_RUNS = [
+    ["count", "-i", "-gaps", "refs12.bed", "reads12.bed"],
+    ["count", "-gaps", "refs12.bed", "reads12_shuffled.bed"],
+    ["count", "-S", "-i", "-gaps", "refs12.bed", "reads12.bed"],
+    ["count", "-S", "-gaps", "--max-label-value", "4", "refs12.bed", "reads12.bed"],
+    ["coverage", "-i", "-gaps", "refs12.bed", "reads12.bed"],
+    ["coverage", "-S", "-gaps", "--max-label-value", "3", "refs12.bed", "reads12.bed"],
+    ["density", "-i", "-gaps", "refs12.bed", "reads12.bed"],
+    ["rpkm", "-S", "-i", "-gaps", "refs12.bed", "reads12.bed"],
+    ["count", "-i", "-gaps", "refs12.bed", "reads12_bad.bed"],                 # a region whose blocks overlap: the reference's error
+    ["count", "-S", "-i", "-gaps", "refs12.bed", "reads12_bad.bed"],
+]
+
+
+@pytest.mark.parametrize("args", BED12_RUNS, ids=[" ".join(a) for a in BED12_RUNS])
+def test_bed12_under_gaps_equals_oracle_cli(bed12, args):
+    want = oracle(args, cwd=bed12)
+    got = product("overlaps", args, cwd=bed12)
+    assert got[0] == want[0], (got[2], want[2])
+    assert got[1] == want[1]
+    if want[0] != 0:
+        assert got[2].strip() == want[2].strip()
+
+
+def test_bed12_without_gaps_is_refused_loudly(bed12):
+    """Without -gaps an overlap of multi-interval regions needs an interval pair (genomic_intervals.cpp:1167-1172): not what the
+    device computes -- the tool says so instead of printing envelope counts."""
+    for args in (["count", "-i", "refs12.bed", "reads12.bed"], ["count", "-S", "-i", "refs12.bed", "reads12.bed"]):
+        rc, out, err = product("overlaps", args, cwd=bed12)
+        assert rc == 1 and out == "" and "multi-interval" in err

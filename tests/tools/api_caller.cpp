@@ -1,0 +1,43 @@
+// api_caller -- a caller written the way the reference's own tools use the class API of gtools/genomic_intervals.h (the iteration
+// loops of genomic_overlaps.cpp: e.g. `overlap` :630-660, `subset` :797-811), compiled against this package's
+// csrc/genomic_intervals.h.  It exercises the members SURVEY 8(b) lists beyond the two reductions: the FILE* constructor,
+// GetQuery/NextQuery, GetOverlap/NextOverlap, CountQueryOverlaps, CalcQueryCoverage, Done.
+//   api_caller pairs|qcount|qcover [-S] [-s] [-i] [-gaps] [-B bits] [--max-label-value N] REF QUERY
+// pairs:  "<query line>\t<index label>" per overlap, in iteration order;  qcount / qcover: "<query line>\t<value>" per query
+// (one walk per query: a second GetOverlap walk of the same query finds the merge's buffer already consumed, in the reference too)
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "genomic_intervals.h"
+
+int main(int argc, char **argv)
+{
+  if (argc < 4) { fprintf(stderr, "usage: api_caller pairs|qcount|qcover [OPTIONS] REF QUERY\n"); return 2; }
+  const bool pairs = !strcmp(argv[1], "pairs"), cover = !strcmp(argv[1], "qcover");
+  bool sorted = false, by_strand = false, ignore_strand = false, gaps = false; const char *bits = "17,20,23,26"; long mlv = 1;
+  int a = 2;
+  for (; a < argc && argv[a][0] == '-'; a++) {
+    if (!strcmp(argv[a], "-S")) sorted = true; else if (!strcmp(argv[a], "-s")) by_strand = true; else if (!strcmp(argv[a], "-i")) ignore_strand = true;
+    else if (!strcmp(argv[a], "-gaps")) gaps = true; else if (!strcmp(argv[a], "-B")) bits = argv[++a]; else if (!strcmp(argv[a], "--max-label-value")) mlv = atol(argv[++a]);
+    else { fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
+  }
+  GenomicRegionSet RefRegSet(argv[a], 10000, false, true, true);
+  FILE *qf = fopen(argv[a + 1], "r");                                   // the FILE* constructor (genomic_intervals.h:1836)
+  if (!qf) { fprintf(stderr, "cannot open %s\n", argv[a + 1]); return 2; }
+  GenomicRegionSet TestRegSet(qf, 10000, false, false, true);
+  GenomicRegionSetOverlaps *overlaps;
+  if (sorted) overlaps = new SortedGenomicRegionSetOverlaps(&TestRegSet, &RefRegSet, by_strand);
+  else overlaps = new UnsortedGenomicRegionSetOverlaps(&TestRegSet, &RefRegSet, bits);
+  for (GenomicRegion *qreg = overlaps->GetQuery(); qreg != NULL; qreg = overlaps->NextQuery()) {
+    if (pairs) {
+      for (GenomicRegion *ireg = overlaps->GetOverlap(gaps, ignore_strand); ireg != NULL; ireg = overlaps->NextOverlap(gaps, ignore_strand))
+        printf("%ld\t%s\n", qreg->n_line, ireg->LABEL);
+    } else {
+      const unsigned long v = cover ? overlaps->CalcQueryCoverage(gaps, ignore_strand, mlv) : overlaps->CountQueryOverlaps(gaps, ignore_strand, mlv);
+      printf("%ld\t%lu\n", qreg->n_line, v);
+    }
+  }
+  delete overlaps;
+  fclose(qf);
+  return 0;
+}
