@@ -182,7 +182,7 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads,
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
-        eng.scan_device(reads.data_ptr(), n, synth.CHROM_LEN, step_bp, size_bp, out.data_ptr())
+        eng.scan_device(reads.data_ptr(), n, synth.CHROM_LEN, step_bp, size_bp, out.data_ptr(), flags=gtx.READS_SORTED)
         if DIST_ON:
             if rehearse:
                 h = out.cpu(); dist.all_reduce(h, op=dist.ReduceOp.SUM); out.copy_(h)
@@ -217,15 +217,14 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads,
         t1 = time.perf_counter()
         want, _ = orc.scan(sample, synth.CHROM_LEN, step_bp, size_bp, algo=1)
         cpu_s = time.perf_counter() - t1
-        eng.scan_device(reads.data_ptr(), ns, synth.CHROM_LEN, step_bp, size_bp, out.data_ptr())
+        eng.scan_device(reads.data_ptr(), ns, synth.CHROM_LEN, step_bp, size_bp, out.data_ptr(), flags=gtx.READS_SORTED)
         eng.sync()
         if not np.array_equal(out.cpu().numpy().view(np.uint64), want):
             sys.exit("PARITY FAILURE: GPU window counts differ from the CPU oracle on the %d-read sample" % ns)
         cpu = {"value": ns / cpu_s, "unit": "reads/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
                "sample": "first %d reads, sorted-scanner restatement (oracle/gtx_oracle.c) on packed triples; windows bit-equal to the GPU's" % ns}
     if rank == 0:
-        n_micro = int((synth.CHROM_LEN // step_bp).sum())
-        alg = 12.0 * n + 4.0 * n_micro
+        alg = 12.0 * n + 8.0 * tot                                          # the reads once + the 8-byte window sums once
         emit(({
             "metric": "window-counted reads/sec, genomic_scans counts 1 kb windows (BASELINE config 4)",
             "value": total_reads * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

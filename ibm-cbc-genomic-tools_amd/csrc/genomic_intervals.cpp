@@ -508,6 +508,18 @@ static bool LooksSorted(const gtxhost::RawVec &tri)
   return true;
 }
 
+static bool LooksSortedVec(const std::vector<int32_t> &tri)
+{
+  const size_t n = tri.size() / 3;
+  if (n < 2) return true;
+  const size_t stride = n > 4096 ? n / 4096 : 1;
+  for (size_t i = 0; i + 1 < n; i += stride) {
+    const int32_t *a = &tri[3 * i], *b = a + 3;
+    if (b[0] < a[0] || (b[0] == a[0] && b[1] < a[1])) return false;
+  }
+  return true;                                            // (a hint: the device verifies it and falls back by itself)
+}
+
 // ---------------------------------------------------------------------------------------------------
 // GenomicRegionSetOverlaps
 // ---------------------------------------------------------------------------------------------------
@@ -950,7 +962,7 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
   gtx_group *grp = Devices();
   const char prep = (preprocess == 'c' && !sorted_rules) ? 'c' : '1';
   CheckGrp(grp, gtx_group_scan(grp, tri.data(), w.empty() ? NULL : w.data(), (int64_t)(tri.size() / 3), class_len.data(), n_chrom * ns,
-                               (int32_t)win_step, (int32_t)win_size, prep, sorted_rules ? GTX_ZERO_LENGTH_OK : 0,
+                               (int32_t)win_step, (int32_t)win_size, prep, (sorted_rules ? GTX_ZERO_LENGTH_OK : 0u) | (LooksSortedVec(tri) ? GTX_READS_SORTED : 0u),
                                (uint64_t *)values.data(), class_off.data()));
 }
 

@@ -74,6 +74,10 @@ struct gtx_ctx {
   long long *d_scanTab = nullptr; size_t capScanTab = 0;
   std::vector<long long> scanKey;       // geometry the tables on the device were built for
   int64_t scanTotalWindows = 0, scanTotalMicro = 0, scanTotalTiles = 0;
+  // owner-computes scan of sorted reads (gtx_scanown.hip): block table for the current tile, bounds scratch, give-up flag;
+  // reads of a host-buffer call held resident for its single launch
+  int64_t scanOwnBlocks = 0; long long *d_scanBounds = nullptr; size_t capScanBounds = 0; int *d_scanFlag = nullptr;
+  void *d_resReads = nullptr; int *d_resWeights = nullptr; size_t capRes = 0, capResW = 0; hipEvent_t evRes[2] = {nullptr, nullptr};
 
   // measurement
   static constexpr int kProfSlots = 64;   // ring: the last 64 profiled calls can be read back
@@ -127,7 +131,8 @@ gtx_ctx *gtx_create(int device_id)
   for (auto &slot : c->evRing) for (auto &ev : slot) if (hipEventCreate(&ev) != hipSuccess) { g_create_error = "gtx_create: hipEventCreate failed"; delete c; return nullptr; }
   if (hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "gtx_create: hipStreamCreate failed"; delete c; return nullptr; }
   for (int k = 0; k < 2; k++)
-    if (hipEventCreateWithFlags(&c->evCopied[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evConsumed[k], hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&c->evCopied[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evConsumed[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evRes[k], hipEventDisableTiming) != hipSuccess) {
       g_create_error = "gtx_create: hipEventCreate failed"; delete c; return nullptr;
     }
   { unsigned hc = std::thread::hardware_concurrency(); c->copyThreads = (int)std::max(1u, std::min(hc ? hc : 4u, 8u));
@@ -155,9 +160,10 @@ void gtx_destroy(gtx_ctx *c)
     if (c->h_pin[k]) (void)hipHostFree(c->h_pin[k]);
     if (c->evCopied[k]) (void)hipEventDestroy(c->evCopied[k]);
     if (c->evConsumed[k]) (void)hipEventDestroy(c->evConsumed[k]);
+    if (c->evRes[k]) (void)hipEventDestroy(c->evRes[k]);
   }
   if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
-  dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab);
+  dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab); dfree(c->d_scanBounds); dfree(c->d_scanFlag); dfree(c->d_resReads); dfree(c->d_resWeights);
   for (auto &p : c->d_cov) dfree(p);
   dfree(c->d_sortedT); dfree(c->d_segT); dfree(c->d_topT); dfree(c->d_posTE); dfree(c->d_posTS); dfree(c->d_classBaseT);
   dfree(c->d_refS); dfree(c->d_refE); dfree(c->d_refC); dfree(c->d_specialRefs); dfree(c->d_specialIdx); dfree(c->d_specialOut); dfree(c->d_side); dfree(c->d_sideCount);
@@ -915,30 +921,35 @@ int64_t gtx_scan_n_windows(int64_t len, int64_t step, int64_t size)
   return n < comb ? 0 : n - comb + 1;
 }
 
-static int scan_prepare(gtx_ctx *c, const int32_t *classLen, int nClasses, int step, int size, const int64_t *classOff, gtx::ScanArgs *out)
+// ownTile > 0: also lay out the blocks of the owner-computes pass (ownTile windows each); *own receives its table
+static int scan_prepare(gtx_ctx *c, const int32_t *classLen, int nClasses, int step, int size, const int64_t *classOff, gtx::ScanArgs *out,
+                        int ownTile = 0, gtx::ScanOwn *own = nullptr)
 {
   if (nClasses < 1 || !classLen || !classOff) return fail(c, GTX_E_ARG, "gtx_scan: bad class table");
   if (step <= 0 || size <= 0 || size % step) return fail(c, GTX_E_ARG, "gtx_scan: window size must be a positive multiple of window step");
   std::vector<long long> key;
-  key.push_back(nClasses); key.push_back(step); key.push_back(size);
+  key.push_back(nClasses); key.push_back(step); key.push_back(size); key.push_back(ownTile);
   for (int i = 0; i < nClasses; i++) { key.push_back(classLen[i]); key.push_back(classOff[i]); }
-  const size_t tabLen = (size_t)5 * nClasses + 2;
+  const size_t tabLen = (size_t)6 * nClasses + 3;
   if (key != c->scanKey) {
     std::vector<long long> tab(tabLen);
     long long *microOff = tab.data(), *nMicro = microOff + nClasses, *winOff = nMicro + nClasses, *outOff = winOff + nClasses + 1,
-              *tileOff = outOff + nClasses;
-    long long mo = 0, wo = 0, to = 0;
+              *tileOff = outOff + nClasses, *blkOff = tileOff + nClasses + 1;
+    long long mo = 0, wo = 0, to = 0, bo = 0;
     const long long tile = gtx::scan_window_tile();
     for (int i = 0; i < nClasses; i++) {
       long long nm = classLen[i] < 0 ? 0 : classLen[i] / step;
       long long nw = gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size);
-      microOff[i] = mo; nMicro[i] = nm; winOff[i] = wo; outOff[i] = classOff[i]; tileOff[i] = to;
+      microOff[i] = mo; nMicro[i] = nm; winOff[i] = wo; outOff[i] = classOff[i]; tileOff[i] = to; blkOff[i] = bo;
       mo += nm; wo += nw; to += (nw + tile - 1) / tile;
+      if (ownTile > 0) bo += (nw + ownTile - 1) / ownTile;
     }
-    winOff[nClasses] = wo; tileOff[nClasses] = to;
-    c->scanTotalTiles = to;
+    winOff[nClasses] = wo; tileOff[nClasses] = to; blkOff[nClasses] = bo;
+    c->scanTotalTiles = to; c->scanOwnBlocks = bo;
     if (tabLen > c->capScanTab) { dfree(c->d_scanTab); c->capScanTab = 0; HIPCHK(c, hipMalloc(&c->d_scanTab, tabLen * sizeof(long long))); c->capScanTab = tabLen; }
-    if ((size_t)mo + 1 > c->capMicro) { dfree(c->d_micro); c->capMicro = 0; HIPCHK(c, hipMalloc(&c->d_micro, ((size_t)mo + 1) * sizeof(u64))); c->capMicro = (size_t)mo + 1; }
+    if ((size_t)mo + 1 > c->capMicro) { dfree(c->d_micro); c->capMicro = 0; HIPCHK(c, hipMalloc(&c->d_micro, ((size_t)mo + 3) * sizeof(u64))); c->capMicro = (size_t)mo + 1; }
+    if ((size_t)(2 * bo + 2) > c->capScanBounds) { dfree(c->d_scanBounds); c->capScanBounds = 0; HIPCHK(c, hipMalloc(&c->d_scanBounds, (size_t)(2 * bo + 2) * sizeof(long long))); c->capScanBounds = (size_t)(2 * bo + 2); }
+    if (!c->d_scanFlag) HIPCHK(c, hipMalloc(&c->d_scanFlag, sizeof(int)));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->d_scanTab, tab.data(), tabLen * sizeof(long long), hipMemcpyHostToDevice));
     c->scanKey = key; c->scanTotalMicro = mo; c->scanTotalWindows = wo;
@@ -947,6 +958,84 @@ static int scan_prepare(gtx_ctx *c, const int32_t *classLen, int nClasses, int s
   out->winOff = c->d_scanTab + 2 * nClasses; out->outOff = c->d_scanTab + 3 * nClasses + 1; out->tileOff = c->d_scanTab + 4 * nClasses + 1;
   out->nClasses = nClasses; out->winStep = step; out->comb = size / step;
   out->winStepInv = step > 1 ? (unsigned)((1ull << 32) / (unsigned)step) : 0;
+  if (own) { own->blkOff = c->d_scanTab + 5 * nClasses + 2; own->tile = ownTile; own->totalBlocks = c->scanOwnBlocks; own->bounds = c->d_scanBounds; own->flag = c->d_scanFlag; }
+  return GTX_OK;
+}
+
+// the scan of reads resident in HBM, enqueued: owner-computes when the caller says the reads are sorted (checked on the device; the
+// general kernels follow as conditional launches and run only if the check fails), the general kernels otherwise
+static int scan_launch(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, const int32_t *classLen, int32_t nClasses, int32_t step,
+                       int32_t size, char prep, uint32_t flags, const int64_t *classOff, void *d_out, bool profile)
+{
+  static const bool ownOff = getenv("GTX_SCAN_OWN") && atoi(getenv("GTX_SCAN_OWN")) == 0;
+  int64_t totalMicro = 0;
+  for (int i = 0; i < nClasses; i++) totalMicro += classLen[i] < 0 ? 0 : classLen[i] / step;
+  const int tile = ((flags & GTX_READS_SORTED) && prep == '1' && !ownOff && n > 0) ? gtx::scan_own_tile(n, totalMicro, size / step) : 0;
+  gtx::ScanArgs a; gtx::ScanOwn own;
+  int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a, tile, &own); if (rc) return rc;
+  a.center = prep == 'c'; a.sortedRule = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
+  if (c->scanTotalWindows > 0 && !d_out) return fail(c, GTX_E_ARG, "gtx_scan: null output");
+  const bool micro64 = d_weights != nullptr;
+  const size_t microBytes = (size_t)c->scanTotalMicro * (micro64 ? 8 : 4);
+  const int *runIf = nullptr;
+  if (tile > 0 && own.totalBlocks > 0) {
+    HIPCHK(c, hipMemsetAsync(c->d_scanFlag, 0, sizeof(int), c->stream));
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, gtx::launch_scan_own(d_reads, d_weights, n, a, own, (u64 *)d_out, c->stream));
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    runIf = c->d_scanFlag;
+    if (microBytes) HIPCHK(c, gtx::launch_scan_zero(c->d_micro, (long long)microBytes, runIf, c->stream));
+    HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream, runIf));
+  } else {
+    if (microBytes) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, microBytes, c->stream));
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream));
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  }
+  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, (u64 *)d_out, c->stream, runIf));
+  return GTX_OK;
+}
+
+// a host-buffer call's reads brought into ONE device buffer (pageable memory through the page-locked slots), so that the
+// owner-computes scan can be a single launch over all of them
+static int stage_resident(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, void **dR, int **dW)
+{
+  if (c->directPending) { HIPCHK(c, hipStreamSynchronize(c->copyStream)); c->directPending = false; }
+  if ((size_t)n > c->capRes || (weights && (size_t)n > c->capResW)) {
+    HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->copyStream));
+    if ((size_t)n > c->capRes) { dfree(c->d_resReads); c->capRes = 0; HIPCHK(c, hipMalloc(&c->d_resReads, (size_t)n * 12)); c->capRes = (size_t)n; }
+    if (weights && (size_t)n > c->capResW) { dfree(c->d_resWeights); c->capResW = 0; HIPCHK(c, hipMalloc(&c->d_resWeights, (size_t)n * 4)); c->capResW = (size_t)n; }
+  }
+  const bool direct = is_pinned(reads) && (!weights || is_pinned(weights));
+  const int64_t batch = c->batchReads;
+  const size_t slotBytes = (size_t)std::min<int64_t>(n, batch) * 16;
+  if (!direct && slotBytes > c->capPin) {
+    HIPCHK(c, hipStreamSynchronize(c->copyStream));
+    for (int k = 0; k < 2; k++) { if (c->h_pin[k]) { (void)hipHostFree(c->h_pin[k]); c->h_pin[k] = nullptr; } HIPCHK(c, hipHostMalloc((void **)&c->h_pin[k], slotBytes)); }
+    c->capPin = slotBytes; c->slotBusy[0] = c->slotBusy[1] = false;
+  }
+  // the kernels of the previous call (the context's stream) may still be reading the resident buffer
+  HIPCHK(c, hipEventRecord(c->evRes[0], c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->copyStream, c->evRes[0], 0));
+  for (int64_t off = 0; off < n; off += batch) {
+    const int64_t cnt = std::min(batch, n - off);
+    const char *srcR = (const char *)(reads + 3 * off), *srcW = (const char *)(weights ? weights + off : nullptr);
+    int slot = -1;
+    if (!direct) {
+      slot = (int)(c->stageSeq++ & 1);
+      if (c->slotBusy[slot]) HIPCHK(c, hipEventSynchronize(c->evCopied[slot]));      // the DMA out of this page-locked slot is done
+      parallel_copy(c->h_pin[slot], srcR, (size_t)cnt * 12, c->copyThreads);
+      if (weights) parallel_copy(c->h_pin[slot] + (size_t)cnt * 12, srcW, (size_t)cnt * 4, c->copyThreads);
+      srcR = c->h_pin[slot]; srcW = c->h_pin[slot] + (size_t)cnt * 12;
+    }
+    HIPCHK(c, hipMemcpyAsync((char *)c->d_resReads + (size_t)off * 12, srcR, (size_t)cnt * 12, hipMemcpyHostToDevice, c->copyStream));
+    if (weights) HIPCHK(c, hipMemcpyAsync(c->d_resWeights + off, srcW, (size_t)cnt * 4, hipMemcpyHostToDevice, c->copyStream));
+    if (slot >= 0) { HIPCHK(c, hipEventRecord(c->evCopied[slot], c->copyStream)); c->slotBusy[slot] = true; }
+  }
+  c->directPending = direct;
+  HIPCHK(c, hipEventRecord(c->evRes[1], c->copyStream));                              // everything has arrived before the scan starts
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->evRes[1], 0));
+  *dR = c->d_resReads; *dW = weights ? c->d_resWeights : nullptr;
   return GTX_OK;
 }
 
@@ -958,17 +1047,9 @@ int gtx_scan_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int6
   if (prep != '1' && prep != 'c') return fail(c, GTX_E_ARG, "gtx_scan_device: preprocess operator must be '1' or 'c'");
   if (!d_weights && n >= (1ll << 32)) return fail(c, GTX_E_ARG, "gtx_scan_device: unweighted scans count in 32 bits per micro-window: at most 2^32-1 reads per call");
   HIPCHK(c, hipSetDevice(c->device));
-  gtx::ScanArgs a;
-  int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
-  a.center = prep == 'c'; a.sortedRule = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
-  if (c->scanTotalWindows > 0 && !d_out) return fail(c, GTX_E_ARG, "gtx_scan_device: null output");
-  const bool micro64 = d_weights != nullptr;
-  if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (micro64 ? 8 : 4), c->stream));
   c->profThis = c->prof && (c->profEvery <= 1 || (c->profSeq++ % c->profEvery) == 0);
-  if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
-  HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream));
-  if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, (u64 *)d_out, c->stream));
+  if (c->profThis) c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots];
+  int rc = scan_launch(c, d_reads, d_weights, n, classLen, nClasses, step, size, prep, flags, classOff, d_out, c->profThis); if (rc) return rc;
   if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   return GTX_OK;
 }
@@ -980,23 +1061,32 @@ int gtxi_scan_enqueue(gtx_ctx *c, const int32_t *reads, const int32_t *weights, 
   if (n < 0 || (n > 0 && !reads)) return fail(c, GTX_E_ARG, "gtx_scan: bad argument");
   if (prep != '1' && prep != 'c') return fail(c, GTX_E_ARG, "gtx_scan: preprocess operator must be '1' or 'c'");
   if (!weights && n >= (1ll << 32)) return fail(c, GTX_E_ARG, "gtx_scan: unweighted scans count in 32 bits per micro-window: at most 2^32-1 reads per call");
+  if (nClasses < 1 || !classLen || !classOff) return fail(c, GTX_E_ARG, "gtx_scan: bad class table");
+  if (step <= 0 || size <= 0 || size % step) return fail(c, GTX_E_ARG, "gtx_scan: window size must be a positive multiple of window step");
   HIPCHK(c, hipSetDevice(c->device));
-  gtx::ScanArgs a;
-  int rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
-  a.center = prep == 'c'; a.sortedRule = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   // output layout in the caller's buffer is given by class_offsets: find its extent
   int64_t extent = 0;
   for (int i = 0; i < nClasses; i++) extent = std::max<int64_t>(extent, classOff[i] + gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size));
-  rc = ensure_out(c, (size_t)extent); if (rc) return rc;
-  const bool micro64 = weights != nullptr;
-  if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (micro64 ? 8 : 4), c->stream));
-  rc = stage_batches(c, reads, weights, n, [&](const void *dR, const int *dW, int64_t cnt, int64_t) -> int {
-    HIPCHK(c, gtx::launch_scan_hist(dR, dW, cnt, a, c->stream));
-    return GTX_OK;
-  });
-  if (rc) return rc;
+  int rc = ensure_out(c, (size_t)extent); if (rc) return rc;
   if (extent > 0) HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)extent * sizeof(u64), c->stream));
-  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, c->d_out, c->stream));
+  if ((flags & GTX_READS_SORTED) && prep == '1' && n > 0) {
+    // sorted reads: all of them resident, one owner-computes launch (gtx_scanown.hip)
+    void *dR = nullptr; int *dW = nullptr;
+    rc = stage_resident(c, reads, weights, n, &dR, &dW); if (rc) return rc;
+    rc = scan_launch(c, dR, dW, n, classLen, nClasses, step, size, prep, flags, classOff, c->d_out, false); if (rc) return rc;
+  } else {
+    gtx::ScanArgs a;
+    rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &a); if (rc) return rc;
+    a.center = prep == 'c'; a.sortedRule = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
+    const bool micro64 = weights != nullptr;
+    if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (micro64 ? 8 : 4), c->stream));
+    rc = stage_batches(c, reads, weights, n, [&](const void *dR, const int *dW, int64_t cnt, int64_t) -> int {
+      HIPCHK(c, gtx::launch_scan_hist(dR, dW, cnt, a, c->stream));
+      return GTX_OK;
+    });
+    if (rc) return rc;
+    HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, c->d_out, c->stream));
+  }
   *d_out = c->d_out; *extent_out = extent;
   return GTX_OK;
 }

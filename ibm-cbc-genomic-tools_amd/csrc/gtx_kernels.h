@@ -121,9 +121,23 @@ hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB,
 hipError_t launch_coverage(const void *reads, const void *weights, long long n, const CoverArgs &a, hipStream_t st);
 hipError_t launch_coverage_finalize(const CoverArgs &a, long long histLen, const CoverGather &g, long long m,
                                     unsigned long long *cov, DevInfo *nextInfo, hipStream_t st);
-hipError_t launch_scan_hist(const void *reads, const void *weights, long long n, const ScanArgs &a, hipStream_t st);
+// runIf (may be NULL): device flag; the kernels leave at once when it is 0 -- the general scan as the fallback of the owner-computes pass
+hipError_t launch_scan_zero(void *micro, long long bytes, const int *runIf, hipStream_t st);
+hipError_t launch_scan_hist(const void *reads, const void *weights, long long n, const ScanArgs &a, hipStream_t st, const int *runIf = nullptr);
 int scan_window_tile();
 hipError_t launch_scan_windows(const void *micro, bool micro64, const ScanArgs &a, long long totalTiles,
-                               unsigned long long *out, hipStream_t st);
+                               unsigned long long *out, hipStream_t st, const int *runIf = nullptr);
+
+// ---- genomic_scans counts on reads sorted by (class, start): every block OWNS a range of windows (gtx_scanown.hip) ----
+struct ScanOwn {
+  const long long *blkOff;       // [nClasses+1] prefix of blocks per class (tile windows each)
+  int tile;                      // windows per block
+  long long totalBlocks;
+  long long *bounds;             // [2 * totalBlocks + 2] scratch: first read of each block's own range | end of its reads
+  int *flag;                     // set to 1 when the reads turn out not to be in order (the caller falls back to the general kernels)
+};
+int scan_own_tile(long long nReads, long long totalMicro, int comb);   // windows per block, 0 = the owner pass does not apply
+hipError_t launch_scan_own(const void *reads, const void *weights, long long n, const ScanArgs &a, const ScanOwn &o,
+                           unsigned long long *out, hipStream_t st);
 
 } // namespace gtx

@@ -1496,8 +1496,9 @@ __device__ __forceinline__ void scan_add64(const Tri &t, int w, bool in_range, c
 // genomic_scans counts, histogram pass: like the count kernel a wave takes 4 x 64 reads per step
 // (four coalesced non-temporal 768-byte requests in flight), spans are dealt to waves contiguously.
 template <bool WEIGHTED>
-__global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, ScanArgs a)
+__global__ __launch_bounds__(256) void scan_hist_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, ScanArgs a, const int *__restrict__ runIf)
 {
+  if (runIf && *runIf == 0) return;                  // fallback of the owner-computes pass (gtx_scanown.hip): only when it gave up
   constexpr int R = 4;
   __shared__ typename ScanTile<WEIGHTED>::ct tiles[4][kScanTile];
   const int lane = threadIdx.x & 63;
@@ -1550,8 +1551,9 @@ static constexpr int kWinTile = 256 * kWinPer;
 static constexpr int kWinMaxComb = 2048;           // LDS: (kWinTile + kWinMaxComb) * 9/8 * 8 B = 36 KB
 
 template <class MT>
-__global__ __launch_bounds__(256) void scan_window_kernel(const MT *__restrict__ micro, ScanArgs a, u64 *__restrict__ out)
+__global__ __launch_bounds__(256) void scan_window_kernel(const MT *__restrict__ micro, ScanArgs a, u64 *__restrict__ out, const int *__restrict__ runIf)
 {
+  if (runIf && *runIf == 0) return;
   __shared__ u64 lds[(kWinTile + kWinMaxComb) / 8 * 9 + 8];
   // class of this tile (tileOff is a prefix over classes; few dozen entries)
   int c = 0;
@@ -1679,22 +1681,37 @@ hipError_t launch_coverage_finalize(const CoverArgs &a, i64 histLen, const Cover
   return hipGetLastError();
 }
 
-hipError_t launch_scan_hist(const void *reads, const void *weights, i64 n, const ScanArgs &a, hipStream_t st)
+__global__ __launch_bounds__(256) void scan_zero_kernel(uint4 *__restrict__ p, i64 n16, const int *__restrict__ runIf)
+{
+  if (runIf && *runIf == 0) return;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (i64)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
+}
+
+hipError_t launch_scan_zero(void *micro, i64 bytes, const int *runIf, hipStream_t st)
+{
+  const i64 n16 = (bytes + 15) / 16;                       // (the buffer is allocated with room for the round-up)
+  if (n16 <= 0) return hipSuccess;
+  i64 blocks = (n16 + 255) / 256; if (blocks > 4096) blocks = 4096;
+  scan_zero_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint4 *)micro, n16, runIf);
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_hist(const void *reads, const void *weights, i64 n, const ScanArgs &a, hipStream_t st, const int *runIf)
 {
   if (n <= 0) return hipSuccess;
   i64 blocks = (n + 4095) / 4096; if (blocks > 256 * 16) blocks = 256 * 16;      // >= 4 steps per wave, <= 16 blocks per CU
-  if (weights) scan_hist_kernel<true><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
-  else scan_hist_kernel<false><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  if (weights) scan_hist_kernel<true><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a, runIf);
+  else scan_hist_kernel<false><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a, runIf);
   return hipGetLastError();
 }
 
 int scan_window_tile() { return kWinTile; }
 
-hipError_t launch_scan_windows(const void *micro, bool micro64, const ScanArgs &a, i64 totalTiles, u64 *out, hipStream_t st)
+hipError_t launch_scan_windows(const void *micro, bool micro64, const ScanArgs &a, i64 totalTiles, u64 *out, hipStream_t st, const int *runIf)
 {
   if (totalTiles <= 0) return hipSuccess;
-  if (micro64) scan_window_kernel<u64><<<(unsigned)totalTiles, 256, 0, st>>>((const u64 *)micro, a, out);
-  else scan_window_kernel<unsigned><<<(unsigned)totalTiles, 256, 0, st>>>((const unsigned *)micro, a, out);
+  if (micro64) scan_window_kernel<u64><<<(unsigned)totalTiles, 256, 0, st>>>((const u64 *)micro, a, out, runIf);
+  else scan_window_kernel<unsigned><<<(unsigned)totalTiles, 256, 0, st>>>((const unsigned *)micro, a, out, runIf);
   return hipGetLastError();
 }
 

@@ -101,3 +101,104 @@ def test_scan_total_is_preserved_full_size_property(engine):
         s = reads[reads[:, 0] == c, 1].astype(np.int64)
         inside += int(((s - 1) // 1000 < ln // 1000).sum())
     assert int(got.sum()) == inside
+
+
+# ---- owner-computes pass for reads in (class, start) order (gtx_scanown.hip), selected by GTX_READS_SORTED ----------------------
+SORTED = 1   # gtx.READS_SORTED
+
+
+@pytest.fixture(autouse=True)
+def owner_pass_on_any_geometry(monkeypatch):
+    # the library takes the owner pass only where it pays (few reads per micro-window); the tests want it everywhere the hint is given
+    monkeypatch.setenv("GTX_SCAN_OWN_ALWAYS", "1")
+
+
+@pytest.mark.parametrize("step,size", [(1000, 1000), (25, 500), (100, 300), (1, 7), (5000, 20000), (25, 25 * 1500)])
+def test_sorted_hint_takes_the_owner_pass(engine, step, size):
+    """Sorted reads with the hint: every block owns a range of windows.  Same numbers as both restated scanners, with the
+    unsorted scanner's rules and with the sorted scanner's (GTX_ZERO_LENGTH_OK), weighted and not, through the host entry
+    (reads made resident, one launch) -- including window steps of 1 bp and windows of 1500 steps."""
+    rng = np.random.default_rng(step + size)
+    small = (np.asarray(synth.CHROM_LEN) // 200).astype(np.int64)          # a genome of ~15 Mb keeps the 1-bp case small
+    reads = synth.genome_intervals(200_000, 5 + step, 30, 120)
+    reads[:, 1:] = reads[:, 1:] // 200 + 1
+    reads[:, 2] = reads[:, 1] + rng.integers(0, 90, size=len(reads))
+    reads = reads[np.lexsort((reads[:, 1], reads[:, 0]))]
+    reads[7, 2] = reads[7, 1] - 1                                          # a zero-length read
+    reads[9, 1] = -4                                                       # start below 1 (first read region of chr1 anyway)
+    reads = reads[np.lexsort((reads[:, 1], reads[:, 0]))]
+    w = rng.integers(-1, 5, size=len(reads)).astype(np.int32)
+    for ww in (None, w):
+        for fl, algo in ((SORTED, 0), (SORTED | gtx.ZERO_LENGTH_OK, 1)):
+            got, _ = engine.scan(reads, small, step, size, "1", ww, fl)
+            want, _ = orc.scan(reads, small, step, size, "1", ww, algo=algo)
+            np.testing.assert_array_equal(got, want)
+
+
+def test_sorted_hint_on_unsorted_reads_falls_back(engine):
+    """The hint is checked on the device: reads that are NOT in order (shuffled; one swap far into the stream; two sorted halves;
+    classes interleaved) give the general kernels' numbers -- exactly -- through the conditional fallback."""
+    rng = np.random.default_rng(77)
+    reads = synth.genome_intervals(400_000, 78, 50, 51)
+    want, _ = orc.scan(reads, synth.CHROM_LEN, 25, 500)
+    variants = [reads[rng.permutation(len(reads))]]
+    one = reads.copy(); one[[300_000, 300_001]] = one[[300_001, 300_000]]
+    if one[300_000, 1] == one[300_001, 1]:
+        one[300_001, 1] -= 1
+    variants.append(one)
+    variants.append(np.concatenate([reads[200_000:], reads[:200_000]]))
+    variants.append(reads[np.lexsort((reads[:, 0], reads[:, 1]))])         # by start only: classes interleave
+    for v in variants:
+        got, _ = engine.scan(v, synth.CHROM_LEN, 25, 500, "1", None, SORTED)
+        np.testing.assert_array_equal(got, want)
+    got, _ = engine.scan(reads, synth.CHROM_LEN, 25, 500, "1", None, SORTED)     # and a sorted call right after a fallback
+    np.testing.assert_array_equal(got, want)
+
+
+def test_owner_pass_class_edge_cases(engine):
+    """Classes without windows (shorter than one window), without reads, reads beyond a class's last micro-window, unknown and
+    negative class ids around the known ones, a single read, no reads at all."""
+    lens = np.array([5000, 300, 0, 100_000, 999, 40_000], dtype=np.int32)
+    rng = np.random.default_rng(79)
+    parts = []
+    for c, ln in ((-2, 1000), (0, 5000), (1, 300), (3, 100_000), (3, 140_000), (4, 999), (5, 40_000), (9, 1000)):
+        k = 3000 if ln > 1000 else 50
+        s = np.sort(rng.integers(1, max(ln, 2), size=k))
+        parts.append(np.stack([np.full(k, c), s, s + rng.integers(0, 60, size=k)], axis=1))
+    reads = np.concatenate(parts).astype(np.int32)
+    reads = reads[np.lexsort((reads[:, 1], reads[:, 0]))]
+    known = (reads[:, 0] >= 0) & (reads[:, 0] < len(lens))
+    for step, size in ((25, 500), (1000, 1000), (100, 1000)):
+        got, _ = engine.scan(reads, lens, step, size, "1", None, SORTED)
+        want, _ = orc.scan(reads[known], lens, step, size)
+        np.testing.assert_array_equal(got, want)
+    for sub in (reads[:0], reads[known][:1]):
+        got, _ = engine.scan(sub, lens, 25, 500, "1", None, SORTED)
+        want, _ = orc.scan(sub, lens, 25, 500)
+        np.testing.assert_array_equal(got, want)
+
+
+def test_owner_pass_device_entry_at_scale(engine):
+    """5 M reads resident in HBM, default window geometry, device entry: owner pass == general kernels (no hint) == oracle sample."""
+    torch = pytest.importorskip("torch")
+    reads = synth.genome_intervals(5_000_000, 81, 50, 51)
+    d = torch.from_numpy(reads).cuda()
+    off, tot = gtx.scan_layout(synth.CHROM_LEN, 25, 500)
+    a = torch.zeros(tot, dtype=torch.int64, device="cuda"); b = torch.zeros_like(a)
+    engine.set_stream(torch.cuda.current_stream().cuda_stream)
+    engine.scan_device(d.data_ptr(), len(reads), synth.CHROM_LEN, 25, 500, a.data_ptr(), flags=SORTED)
+    engine.scan_device(d.data_ptr(), len(reads), synth.CHROM_LEN, 25, 500, b.data_ptr(), flags=0)
+    engine.sync(); engine.set_stream(0)
+    assert torch.equal(a, b)
+    assert int(a.sum().item()) > 20 * 4_000_000
+
+
+def test_owner_pass_is_chosen_by_geometry(engine, monkeypatch):
+    """Without the test override: coarse steps (many reads per micro-window) keep the general kernels, fine steps take the owner
+    pass -- either way the numbers are the oracle's."""
+    monkeypatch.delenv("GTX_SCAN_OWN_ALWAYS")
+    reads = reads_scaled(300000, 49)
+    for step, size in ((5000, 5000), (10, 200)):
+        got, _ = engine.scan(reads, LENS, step, size, "1", None, SORTED)
+        want, _ = orc.scan(reads, LENS, step, size, "1")
+        np.testing.assert_array_equal(got, want)
