@@ -23,7 +23,10 @@
 // Compiled with -ffp-contract=off: the reference's host compiler does not fuse a*b+c on x86-64, and
 // results are compared with >=.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "gtx.h"
@@ -125,13 +128,16 @@ struct StatConsts { double Vsum, VsumZ, Vsum2, VtotalSum; i64 nRows; i64 tAll; i
 
 template <int STAT, bool TOTALS> struct Acc;
 
+// (kWords: the leading 8-byte words that make up the running state -- what travels between the row-range launches)
 template <bool TOTALS> struct Acc<GTX_STAT_SUM, TOTALS> {                      // :487-520
+  static constexpr int kWords = TOTALS ? 2 : 1;
   double y = 0, yt = 0;
   __device__ void add(float v, float vt) { y += v; if (TOTALS) yt += vt; }
   __device__ double finish(i64 nc, const StatConsts &k) const { double r = TOTALS ? y / yt : y / nc; return k.under ? -r : r; }
 };
 
 template <int STAT, bool TOTALS> struct AccCount {                              // :341-413
+  static constexpr int kWords = 1;
   i64 kk = 0; int under;
   __device__ void add(float v, float) { kk += under ? v < 0 : v > 0; }
   __device__ double finish(i64 nc, const StatConsts &k) const
@@ -144,6 +150,7 @@ template <bool TOTALS> struct Acc<GTX_STAT_SENS, TOTALS> : AccCount<GTX_STAT_SEN
 template <bool TOTALS> struct Acc<GTX_STAT_SPEC, TOTALS> : AccCount<GTX_STAT_SPEC, TOTALS> {};
 
 template <int STAT> struct AccMoments {                                          // no totals: :288-307, :430-447
+  static constexpr int kWords = 2;
   double m1 = 0, v1 = 0;
   __device__ void add(float v, float) { m1 += v; v1 += v * v; }                  // float product, as in the reference
   __device__ double finish(i64 nc, const StatConsts &k) const
@@ -161,6 +168,7 @@ template <> struct Acc<GTX_STAT_RATIO, false> : AccMoments<GTX_STAT_RATIO> {};
 template <> struct Acc<GTX_STAT_T, false> : AccMoments<GTX_STAT_T> {};
 
 template <> struct Acc<GTX_STAT_RATIO, true> {                                   // :449-470
+  static constexpr int kWords = 2;
   double s1 = 0, t1 = 0;
   __device__ void add(float v, float vt) { s1 += v; t1 += vt; }
   __device__ double finish(i64, const StatConsts &k) const
@@ -172,6 +180,7 @@ template <> struct Acc<GTX_STAT_RATIO, true> {                                  
 };
 
 template <> struct Acc<GTX_STAT_T, true> {                                       // :309-329
+  static constexpr int kWords = 4;
   double s1 = 0, t1 = 0, z1 = 0, q1 = 0;
   __device__ void add(float v, float vt)
   {
@@ -191,6 +200,7 @@ template <> struct Acc<GTX_STAT_T, true> {                                      
 };
 
 template <bool TOTALS> struct Acc<GTX_STAT_CORR, TOTALS> {                       // :527-545, core.cpp:1535-1558
+  static constexpr int kWords = 6;
   double Ex = 0, Ey = 0, Ex2 = 0, Ey2 = 0, Exy = 0; u64 C = 0;
   __device__ void add(float v, float vt)
   {
@@ -218,6 +228,10 @@ struct StatArgs {
   u64 *counts;
   const i64 *tabPtr; const double *tab; const double *sortedY;   // MODE_RANK
   i64 colBlocks;                  // blocks per slab tile
+  // row-range parts (see perm_stat_kernel): this launch adds the members with rows in part `part` of `nParts`
+  int part, nParts;
+  const i64 *colSplit;            // [(nParts + 1) * nCols]: colSplit[q * nCols + c] = first member of c with row >= part q's first row
+  u64 *accBuf;                    // accumulators between the parts: [tile][c][word][lane]
 };
 
 constexpr int kWavesPerBlock = 4;
@@ -236,7 +250,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void perm_stat_kernel(StatArgs
   if (c >= a.nCols) return;
   const i64 j = tile * 64 + lane;
   const bool valid = j < a.nPerm;
-  const i64 z0 = a.colPtr[c], z1 = a.colPtr[c + 1];
+  // Row-range parts.  A 64-permutation tile is n_rows x 256 B; when that exceeds what an XCD's L2 keeps (4 MiB; 20 k rows are
+  // 5.1 MB: hit rate 0.69, every tile fetched from the fabric many times over), the rows are cut into nParts ranges of <= ~2.7 MB
+  // and each range is ONE launch over all tiles and categories -- the working set of an XCD is then one range of one tile.
+  // Membership lists are in ascending row order (permutation_test.cpp:120-186 appends rows as it reads them), so a range is a
+  // contiguous piece [zs, ze) of every list; the accumulators travel from launch to launch through accBuf, and a category's
+  // members are still added in list order: the sums, hence every statistic and every >= decision, are bit for bit the same.
+  const i64 z0 = a.nParts > 1 ? a.colSplit[(i64)a.part * a.nCols + c] : a.colPtr[c];
+  const i64 z1 = a.nParts > 1 ? a.colSplit[(i64)(a.part + 1) * a.nCols + c] : a.colPtr[c + 1];
   // byte offset of (row r, this lane) inside the tile: 32 bits (n_rows < 2^24), so that a gather is one
   // v_lshl_add_u32 + one global_load with a scalar base.  MODE_STAT reads the unpermuted vectors: row r at r * 4.
   constexpr int kRowShift = MODE == MODE_STAT ? 2 : 8;
@@ -245,6 +266,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void perm_stat_kernel(StatArgs
   const char *__restrict__ vtp = HASVT ? (const char *)(a.Vtp + (MODE == MODE_STAT ? 0 : (size_t)tile * a.k.nRows * 64)) : nullptr;
   Acc<STAT, TOTALS> acc;
   if constexpr (STAT == GTX_STAT_N || STAT == GTX_STAT_SENS || STAT == GTX_STAT_SPEC) acc.under = a.k.under;
+  constexpr int kAccWords = Acc<STAT, TOTALS>::kWords;
+  static_assert(sizeof(acc) >= 8 * kAccWords, "the running state is the leading words of the accumulator");
+  u64 *accAt = a.nParts > 1 ? a.accBuf + ((size_t)(tile * a.nCols + c) * kAccWords) * 64 + lane : nullptr;
+  if (a.nParts > 1 && a.part > 0) {
+    u64 w[kAccWords];
+#pragma unroll
+    for (int f = 0; f < kAccWords; f++) w[f] = accAt[(size_t)f * 64];
+    __builtin_memcpy((void *)&acc, w, 8 * kAccWords);
+  }
   i64 z = z0;
   // 8 gathers in flight, accumulated in list order
   for (; z + 8 <= z1; z += 8) {
@@ -261,7 +291,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void perm_stat_kernel(StatArgs
     const uint32_t off = ((uint32_t)a.rows[z] << kRowShift) + laneOff;
     acc.add(*(const float *)(vp + off), HASVT ? *(const float *)(vtp + off) : 1.0f);
   }
-  const i64 nc = z1 - z0;
+  if (a.nParts > 1 && a.part + 1 < a.nParts) {                     // not the last range: hand the accumulators on
+    u64 w[kAccWords];
+    __builtin_memcpy(w, (const void *)&acc, 8 * kAccWords);
+#pragma unroll
+    for (int f = 0; f < kAccWords; f++) accAt[(size_t)f * 64] = w[f];
+    return;
+  }
+  const i64 nc = a.colPtr[c + 1] - a.colPtr[c];
   if constexpr (MODE == MODE_RANK) {
     // approximate p-value by table, then its lower bound among the sorted observed ones
     const double val = a.tab[a.tabPtr[c] + acc.kk];
@@ -335,6 +372,8 @@ struct gtx_perm {
   i64 tPos = 0, tNeg = 0;
   float *d_V = nullptr, *d_Vt = nullptr; i64 *d_colPtr = nullptr; int32_t *d_rows = nullptr;
   float *d_Vp = nullptr, *d_Vtp = nullptr; size_t capSlab = 0;     // floats per slab
+  int nParts = 1; i64 *d_colSplit = nullptr; u64 *d_accBuf = nullptr; size_t capAcc = 0;   // row-range parts of the stat kernel
+  bool rowsAscending = true; std::vector<i64> h_colPtr; std::vector<int32_t> h_rows; int splitParts = 0;
   double *d_Y = nullptr; u64 *d_counts = nullptr;
   i64 *d_tabPtr = nullptr; double *d_tab = nullptr, *d_sortedY = nullptr; size_t capTab = 0;
   hipEvent_t ev[3] = {};
@@ -368,7 +407,7 @@ void gtx_perm_destroy(gtx_perm *p)
   if (!p) return;
   (void)hipSetDevice(p->device);
   dfree(p->d_V); dfree(p->d_Vt); dfree(p->d_colPtr); dfree(p->d_rows); dfree(p->d_Vp); dfree(p->d_Vtp);
-  dfree(p->d_Y); dfree(p->d_counts); dfree(p->d_tabPtr); dfree(p->d_tab); dfree(p->d_sortedY);
+  dfree(p->d_Y); dfree(p->d_counts); dfree(p->d_tabPtr); dfree(p->d_tab); dfree(p->d_sortedY); dfree(p->d_colSplit); dfree(p->d_accBuf);
   for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
   delete p;
 }
@@ -401,6 +440,10 @@ int gtx_perm_set_table(gtx_perm *p, int64_t n_rows, int64_t n_cols, const int64_
   p->tPos = p->tNeg = 0;
   for (int64_t r = 0; r < n_rows; r++) { p->tPos += V[r] > 0; p->tNeg += V[r] < 0; }       // t of :343-344, permutation invariant
   for (int i = 0; i < 4; i++) p->sums[i] = sums[i];
+  p->h_colPtr.assign(col_ptr, col_ptr + n_cols + 1); p->h_rows.assign(rows, rows + nnz);
+  p->rowsAscending = true; p->splitParts = 0;
+  for (int64_t c = 0; c < n_cols && p->rowsAscending; c++)
+    for (i64 z = col_ptr[c] + 1; z < col_ptr[c + 1]; z++) if (rows[z] < rows[z - 1]) { p->rowsAscending = false; break; }
   p->useTotals = (flags & GTX_PERM_USE_TOTALS) != 0;
   p->nRows = n_rows; p->nCols = n_cols; p->nnz = nnz;
   return GTX_OK;
@@ -431,7 +474,7 @@ int gtx_perm_statistic(gtx_perm *p, int stat, int under, double *Y)
   if (p->nCols == 0) return GTX_OK;
   PCHK(p, hipSetDevice(p->device));
   StatArgs a = base_args(p, under);
-  a.Vp = p->d_V; a.Vtp = p->d_Vt; a.nPerm = 1; a.Yout = p->d_Y;
+  a.Vp = p->d_V; a.Vtp = p->d_Vt; a.nPerm = 1; a.Yout = p->d_Y; a.nParts = 1; a.part = 0;
   PCHK(p, launch_stat(stat, MODE_STAT, p->useTotals, p->hasVt, a, p->stream));
   PCHK(p, hipMemcpyAsync(Y, p->d_Y, sizeof(double) * p->nCols, hipMemcpyDeviceToHost, p->stream));
   PCHK(p, hipStreamSynchronize(p->stream));
@@ -457,6 +500,33 @@ static int run_batches(gtx_perm *p, int stat, int mode, StatArgs a, bool needVt,
     if (p->hasVt) PCHK(p, hipMalloc(&p->d_Vtp, sizeof(float) * need));
     p->capSlab = need;
   }
+  // row-range parts of the stat kernel: the rows one launch gathers from must fit an XCD's L2 next to the lists (see perm_stat_kernel)
+  int nParts = 1;
+  {
+    const char *lim = getenv("GTX_PERM_L2_MB");                      // (tests shrink it to cut small tables into many ranges)
+    const double budget = (lim ? atof(lim) : 2.75) * 1024 * 1024;
+    const double tileBytes = (double)p->nRows * 256.0 * (needVt ? 2 : 1);
+    if (p->rowsAscending && budget > 0 && tileBytes > budget) nParts = (int)std::min<double>(16.0, ceil(tileBytes / budget));
+  }
+  if (nParts > 1) {
+    if (p->splitParts != nParts) {
+      std::vector<i64> split((size_t)(nParts + 1) * p->nCols);
+      for (int q = 0; q <= nParts; q++) {
+        const int32_t firstRow = (int32_t)((i64)p->nRows * q / nParts);
+        for (i64 c = 0; c < p->nCols; c++)
+          split[(size_t)q * p->nCols + c] = q == nParts ? p->h_colPtr[c + 1]
+                                                         : std::lower_bound(p->h_rows.begin() + p->h_colPtr[c], p->h_rows.begin() + p->h_colPtr[c + 1], firstRow) - p->h_rows.begin();
+      }
+      dfree(p->d_colSplit);
+      PCHK(p, hipMalloc(&p->d_colSplit, sizeof(i64) * split.size()));
+      PCHK(p, hipMemcpy(p->d_colSplit, split.data(), sizeof(i64) * split.size(), hipMemcpyHostToDevice));
+      p->splitParts = nParts;
+    }
+    const int words = stat == GTX_STAT_CORR ? 6 : (stat == GTX_STAT_T && p->useTotals) ? 4 : (stat == GTX_STAT_N || stat == GTX_STAT_SENS || stat == GTX_STAT_SPEC) ? 1
+                      : (stat == GTX_STAT_SUM ? 2 : 2);
+    const size_t needAcc = (size_t)((pb + 63) / 64) * (size_t)p->nCols * (size_t)words * 64;
+    if (needAcc > p->capAcc) { dfree(p->d_accBuf); p->capAcc = 0; PCHK(p, hipMalloc(&p->d_accBuf, sizeof(u64) * needAcc)); p->capAcc = needAcc; }
+  }
   const PermGeom g = perm_geom((uint32_t)p->nRows);
   p->applyMs = p->statMs = 0;
   for (i64 done = 0; done < n_perm; done += pb) {
@@ -470,7 +540,8 @@ static int run_batches(gtx_perm *p, int stat, int mode, StatArgs a, bool needVt,
     PCHK(p, hipGetLastError());
     PCHK(p, hipEventRecord(p->ev[1], p->stream));
     a.Vp = p->d_Vp; a.Vtp = needVt ? p->d_Vtp : nullptr; a.nPerm = cnt;
-    PCHK(p, launch_stat(stat, mode, p->useTotals, needVt, a, p->stream));
+    a.nParts = nParts; a.colSplit = p->d_colSplit; a.accBuf = p->d_accBuf;
+    for (int part = 0; part < nParts; part++) { a.part = part; PCHK(p, launch_stat(stat, mode, p->useTotals, needVt, a, p->stream)); }
     PCHK(p, hipEventRecord(p->ev[2], p->stream));
     PCHK(p, hipEventSynchronize(p->ev[2]));
     float t0 = 0, t1 = 0;

@@ -219,3 +219,37 @@ def test_cli_no_category_passes_the_support_filter():
     a, b = run_both(["-kmin", "100000", "-S", "sum", "-p", "10", "-h", os.path.join(GOLD, "perm_go.txt")], seed=1)
     assert a.returncode == 0 and b.returncode == 0
     assert a.stdout == b.stdout == b"CATEGORY\tCATEGORY-SIZE\tQ-VALUE\tP-VALUE\tSTATISTIC\n"
+
+
+@pytest.mark.parametrize("l2_mb", ["0.05", "0.3", "100"])
+def test_row_range_parts_keep_every_bit(pe, monkeypatch, l2_mb):
+    """perm_stat_kernel cuts the rows of a slab tile into L2-sized ranges, one launch per range, the accumulators travelling between
+    the launches: the members of a category are still added in list order, so exceed-counts and the rank histogram are bit for
+    bit what one launch gives (and what the oracle gives) -- for every statistic, with and without totals, for 2 to 16 ranges
+    (GTX_PERM_L2_MB shrinks the budget so that small tables are cut too), and for tables whose lists are NOT in ascending row
+    order (no ranges then)."""
+    monkeypatch.setenv("GTX_PERM_L2_MB", l2_mb)
+    for name, t in tables():
+        pe.set_table(t)
+        for stat in STATS:
+            if stat == "corr" and not t.use_totals:
+                continue
+            Y = porc.statistic(t, stat, False)
+            got = pe.count_ge(stat, Y, seed=7, first_perm=3, n_perm=200)
+            np.testing.assert_array_equal(got, porc.count_ge(t, stat, Y, 7, 3, 200), err_msg="%s %s" % (name, stat))
+    # lists in descending row order: the ranges do not apply, the result is the same
+    t = perm.PermTable.synthetic(3000, 150, 40, seed=11, values="gamma")
+    rows = t.rows.copy()
+    for c in range(len(t.col_ptr) - 1):
+        rows[t.col_ptr[c]:t.col_ptr[c + 1]] = rows[t.col_ptr[c]:t.col_ptr[c + 1]][::-1]
+    t2 = perm.PermTable(t.n_rows, t.col_ptr, rows, t.V, None)
+    pe.set_table(t2)
+    Y = porc.statistic(t2, "t", False)
+    np.testing.assert_array_equal(pe.count_ge("t", Y, 7, 0, 128), porc.count_ge(t2, "t", Y, 7, 0, 128))
+    # the approximate (rank histogram) mode goes through the same kernel
+    t3 = perm.PermTable.synthetic(3000, 180, 30, seed=11, values="signed")
+    pe.set_table(t3)
+    tab_ptr, tab = porc.hypergeom_table(t3, False)
+    k = porc.statistic(t3, "n", False).astype(np.int64)
+    sorted_y = np.sort(tab[tab_ptr[:-1] + k], kind="stable")
+    np.testing.assert_array_equal(pe.count_rank(tab_ptr, tab, sorted_y, 17, 0, 300, False), porc.count_rank(t3, tab_ptr, tab, sorted_y, 17, 0, 300, False))
