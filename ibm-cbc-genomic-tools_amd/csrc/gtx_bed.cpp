@@ -98,7 +98,8 @@ size_t LineSource::NextBlockView(std::vector<char> &block, char **view, size_t t
     const size_t want = std::min(left, target);
     block.resize(want);
     // parallel pread: the kernel-to-user copy is the cost of reading a cached file, so split it
-    const int K = (int)std::min<size_t>(8, want / (4u << 20) + 1);
+    static const int maxReaders = getenv("GTX_READ_THREADS") && atoi(getenv("GTX_READ_THREADS")) > 0 ? atoi(getenv("GTX_READ_THREADS")) : 8;
+    const int K = (int)std::min<size_t>((size_t)maxReaders, want / (4u << 20) + 1);
     std::vector<std::thread> th;
     auto rd = [&](int k) {
       size_t b0 = want * (size_t)k / K, b1 = want * (size_t)(k + 1) / K;
@@ -580,12 +581,14 @@ long CountLines(const char *b, const char *e)
 BedPacker::BedPacker(LineSource *src, const PackOptions &opt) : src_(src), opt_(opt)
 {
   if (opt_.guard) opt_.threads = 1;
+  if (opt_.threads <= 0) { const char *e = getenv("GTX_PACK_THREADS"); if (e && atoi(e) > 0) opt_.threads = atoi(e); }
   if (opt_.threads <= 0) { unsigned hc = std::thread::hardware_concurrency(); opt_.threads = hc ? (int)std::min(hc, 64u) : 4; }
 }
 
 BedPacker::BedPacker(const GtxView *packed, const PackOptions &opt) : src_(nullptr), opt_(opt)
 {
   if (opt_.guard) opt_.threads = 1;
+  if (opt_.threads <= 0) { const char *e = getenv("GTX_PACK_THREADS"); if (e && atoi(e) > 0) opt_.threads = atoi(e); }
   if (opt_.threads <= 0) { unsigned hc = std::thread::hardware_concurrency(); opt_.threads = hc ? (int)std::min(hc, 64u) : 4; }
   gtx_ = packed;
 }
@@ -736,7 +739,7 @@ bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
   }
   if (!src_ || exhausted_) return false;
   // the next block is read (and inflated, for .gz) while the current one is parsed
-  const size_t block_bytes = 64u << 20;
+  const size_t block_bytes = (getenv("GTX_PACK_BLOCK_MB") && atoi(getenv("GTX_PACK_BLOCK_MB")) > 0 ? (size_t)atoi(getenv("GTX_PACK_BLOCK_MB")) : 64u) << 20;
   auto read_block = [this, block_bytes](int buf) { Ahead a; long fl = 0; a.buf = buf; a.got = src_->NextBlockView(blocks_[buf], &a.view, block_bytes, &fl); return a; };
   if (!ahead_.valid()) { ahead_ = std::async(std::launch::async, read_block, next_buf_); next_buf_ ^= 1; }
   while (out->tri.size() / 3 < target_reads) {

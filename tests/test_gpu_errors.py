@@ -49,7 +49,7 @@ def test_reference_data_out_of_range():
     lib = gtx.load()
     ctx = lib.gtx_create(0)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    for bad, msg in (([[0, 5, 2**31 - 2]], "coordinate"), ([[-1, 5, 10]], "negative class"), ([[3, 5, 10]], "class id >= n_classes")):
+    for bad, msg in (([[0, 5, 2**31 - 2]], "coordinate"), ([[-2, 5, 10]], "negative class"), ([[3, 5, 10]], "class id >= n_classes")):
         refs = np.array(bad, dtype=np.int32)
         assert lib.gtx_set_refs(ctx, p(refs), 1, 2) == E_RANGE and msg in last(lib, ctx)
     # after a rejected set, counting must refuse or work -- not crash:
