@@ -12,6 +12,12 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build once -- hipcc cross-compiles without a GPU
+    need = [os.path.join(PKG, "csrc", f) for f in ("libgtx.so", "genomic_overlaps", "genomic_scans", "permutation_test", "gtx_packtool", "api_caller")]
+    need += [os.path.join(ROOT, "oracle", f) for f in ("libgtx_oracle.so", "gtx_oracle", "libperm_oracle.so", "perm_oracle")]
+    if not all(os.path.exists(f) for f in need):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
