@@ -402,6 +402,26 @@ static int g_ngpu = 0;                                   // 0 = not set: GTX_NGP
 
 void GtxSetDevices(int n) { g_ngpu = n; }
 
+// Page-locked batch buffers for the bulk packer (gtxhost::BatchArena): two of them, filled in turn by DrainSet -- the packer
+// threads write the packed triples where the DMA engine reads them (gtx_host_alloc memory skips the library's staging copy, and
+// the call returns with the copy in flight: the contract of include/gtx.h is "untouched until the NEXT call has returned", which
+// two alternating buffers satisfy).  Made by the start-up thread behind the loading of the reference set.
+static const size_t kBatchReads = getenv("GTX_HOST_BATCH_READS") && atol(getenv("GTX_HOST_BATCH_READS")) > 0 ? (size_t)atol(getenv("GTX_HOST_BATCH_READS")) : (8u << 20);   // reads per batch handed to the device
+static const size_t kPoolBytes = (kBatchReads * 3 + (24u << 20)) * sizeof(int32_t);   // what BedPacker::NextBatch reserves for it
+static struct { void *buf[2]; bool used[2]; gtx_ctx *owner; } g_pool = {{NULL, NULL}, {false, false}, NULL};
+
+static void *PoolTake(size_t bytes)
+{
+  if (bytes > kPoolBytes || bytes < kPoolBytes / 2) return NULL;               // the triples of a batch, nothing else
+  for (int k = 0; k < 2; k++) if (g_pool.buf[k] && !g_pool.used[k]) { g_pool.used[k] = true; return g_pool.buf[k]; }
+  return NULL;
+}
+static bool PoolGive(void *p)
+{
+  for (int k = 0; k < 2; k++) if (p && g_pool.buf[k] == p) { g_pool.used[k] = false; return true; }
+  return false;
+}
+
 static gtx_group *CreateGroup()
 {
   int n = g_ngpu;
@@ -413,7 +433,12 @@ static gtx_group *CreateGroup()
   const char *rh = getenv("GTX_GROUP_REHEARSE");           // test mode of the library: all members on one device
   for (int i = 0; i < n; i++) ids[i] = first + ((rh && atoi(rh)) ? 0 : i);
   gtx_group *g = gtx_group_create(n, ids.data());
-  if (!g) g_ctx_error = gtx_group_last_error(NULL);      // thread-local in the library: copy it out on this thread
+  if (!g) { g_ctx_error = gtx_group_last_error(NULL); return g; }   // thread-local in the library: copy it out on this thread
+  if (getenv("GTX_NO_PINNED_BATCHES") == NULL) {
+    g_pool.owner = gtx_group_ctx(g, 0);
+    for (int k = 0; k < 2; k++) g_pool.buf[k] = gtx_host_alloc(g_pool.owner, kPoolBytes);      // (NULL: the heap serves)
+    gtxhost::BatchArena::take = PoolTake; gtxhost::BatchArena::give = PoolGive;
+  }
   return g;
 }
 
@@ -443,19 +468,27 @@ static void CheckGrp(gtx_group *g, int rc)
 template <class Sink>
 static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
 {
-  const size_t batch_reads = 24u << 20;
-  PackedBatch batch; PackError err;
+  const size_t batch_reads = kBatchReads;
+  PackedBatch two[2]; int cur = 0; PackError err;           // two batches in turn: one is packed while the device still reads the other
+  auto pump = [&](BedPacker &packer) {
+    for (;;) {
+      PackedBatch &batch = two[cur];
+      bool more = packer.NextBatch(&batch, batch_reads, &err);
+      if (err.set) DiePack(err);
+      if (!batch.tri.empty()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        sink(batch); cur ^= 1;
+        if (getenv("GTX_PACK_TRACE")) fprintf(stderr, "[sink] %zu reads handed over in %.1f ms\n", batch.tri.size() / 3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      }
+      if (!more) break;
+    }
+  };
   if (!set->load_in_memory && set->format == "GTX") {
     long int at = 0;
     const gtxhost::GtxView *view = set->DetachPacked(&at);
     BedPacker packer(view, opt);
     packer.SkipRecords((uint64_t)at);
-    for (;;) {
-      bool more = packer.NextBatch(&batch, batch_reads, &err);
-      if (err.set) DiePack(err);
-      if (!batch.tri.empty()) sink(batch);
-      if (!more) break;
-    }
+    pump(packer);
     return;
   }
   if (!set->load_in_memory) {
@@ -463,12 +496,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
     LineSource *src = set->DetachStream(&first, &first_no);
     BedPacker packer(src, opt);
     if (first_no > 0) packer.Prime(first, first_no);
-    for (;;) {
-      bool more = packer.NextBatch(&batch, batch_reads, &err);
-      if (err.set) DiePack(err);
-      if (!batch.tri.empty()) sink(batch);
-      if (!more) break;
-    }
+    pump(packer);
     return;
   }
   // in-memory set: re-emit its regions as lines through the same packer rules
@@ -486,12 +514,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
   }
   BedPacker packer((LineSource *)NULL, opt);
   packer.PrimeBlock(text, 1);
-  for (;;) {
-    bool more = packer.NextBatch(&batch, batch_reads, &err);
-    if (err.set) DiePack(err);
-    if (!batch.tri.empty()) sink(batch);
-    if (!more) break;
-  }
+  pump(packer);
 }
 
 // quick order hint for the kernel choice (a wrong hint only costs speed): sample adjacent pairs

@@ -1,6 +1,7 @@
 // gtx_bed.cpp -- see gtx_bed.h
 #include "gtx_bed.h"
 
+#include <emmintrin.h>
 #include <fcntl.h>
 #include <limits.h>
 #include <stdlib.h>
@@ -11,8 +12,68 @@
 #include <algorithm>
 #include <future>
 #include <thread>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 
 namespace gtxhost {
+void *(*BatchArena::take)(size_t) = nullptr;
+bool (*BatchArena::give)(void *) = nullptr;
+static double NowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static const bool kTrace = getenv("GTX_PACK_TRACE") != nullptr;
+
+
+// ---------------------------------------------------------------------------------------------------
+// worker pool: the packer runs two short parallel phases per 64 MB block; threads made once, not 128 per block
+// ---------------------------------------------------------------------------------------------------
+namespace {
+class Pool {
+ public:
+  // fn(t) for t in [0, n): t = 0 on the caller, the rest on pool threads; returns when all are done
+  static void Run(int n, const std::function<void(int)> &fn)
+  {
+    if (n <= 1) { if (n == 1) fn(0); return; }
+    static Pool pool;
+    pool.Go(n, fn);
+  }
+ private:
+  std::vector<std::thread> workers_;
+  std::mutex m_; std::condition_variable wake_, done_;
+  const std::function<void(int)> *fn_ = nullptr; int n_ = 0, next_ = 0, left_ = 0; unsigned long gen_ = 0; bool stop_ = false;
+  void Grow(int want)
+  {
+    while ((int)workers_.size() < want) workers_.emplace_back([this] {
+      unsigned long seen = 0;
+      std::unique_lock<std::mutex> lk(m_);
+      for (;;) {
+        wake_.wait(lk, [&] { return stop_ || (gen_ != seen && next_ < n_); });
+        if (stop_) return;
+        while (next_ < n_) {
+          const int t = next_++;
+          const std::function<void(int)> *f = fn_;
+          lk.unlock(); (*f)(t); lk.lock();
+          if (--left_ == 0) done_.notify_all();
+        }
+        seen = gen_;
+      }
+    });
+  }
+  void Go(int n, const std::function<void(int)> &fn)
+  {
+    std::unique_lock<std::mutex> lk(m_);
+    Grow(n - 1);
+    fn_ = &fn; n_ = n; next_ = 1; left_ = n - 1; gen_++;
+    wake_.notify_all();
+    lk.unlock();
+    fn(0);
+    lk.lock();
+    done_.wait(lk, [&] { return left_ == 0; });
+    fn_ = nullptr; n_ = 0; next_ = 0;
+  }
+  ~Pool() { { std::lock_guard<std::mutex> lk(m_); stop_ = true; } wake_.notify_all(); for (auto &w : workers_) w.join(); }
+};
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------------
 // LineSource
@@ -187,6 +248,32 @@ static inline long FastAtolTo(const char *p, const char *end)
   return neg ? -(long)v : (long)v;
 }
 
+// The same for the common case -- nothing but 1..10 digits -- without a loop over the digits: the last (up to) eight go through
+// one 8-byte load (padded with '0' in front) and three multiplications; anything else (sign, blank, letters, longer) takes
+// FastAtolTo.  `safe_end`: bytes before it may be read.
+static inline long FastDigitsTo(const char *p, const char *end, const char *safe_end)
+{
+  const long L = end - p;
+  if (L >= 1 && L <= 10) {
+    const char *q = L > 8 ? end - 8 : p;
+    if (q + 8 <= safe_end) {
+      long head = 0; bool ok = true;
+      for (const char *h = p; h < q; h++) { const unsigned d = (unsigned)(*h - '0'); ok &= d <= 9; head = head * 10 + (long)d; }
+      const int l8 = L > 8 ? 8 : (int)L;
+      uint64_t x; memcpy(&x, q, 8);
+      if (l8 < 8) { x <<= (8 - l8) * 8; x |= 0x3030303030303030ull >> (l8 * 8); }
+      ok &= (((x & 0xF0F0F0F0F0F0F0F0ull) | (((x + 0x0606060606060606ull) & 0xF0F0F0F0F0F0F0F0ull) >> 4)) == 0x3333333333333333ull);
+      if (ok) {
+        x -= 0x3030303030303030ull;
+        x = (x * 10) + (x >> 8);
+        x = (((x & 0x000000FF000000FFull) * 0x000F424000000064ull) + (((x >> 16) & 0x000000FF000000FFull) * 0x0000271000000001ull)) >> 32;
+        return head * 100000000L + (long)x;
+      }
+    }
+  }
+  return FastAtolTo(p, end);
+}
+
 BedStatus ParseBedLine(char *line, BedFields *o, char **bad)
 {
   const char sep = strchr(line, '\t') ? '\t' : ' ';
@@ -230,17 +317,38 @@ void BedBlocks(const BedFields &f, std::vector<long> *iv)
 // column -- doing what ParseBedLine does for it (the tokenizer rules only differ from a plain split when blanks
 // are involved).  Returns the character after the line's '\n', or NULL when the line is not of that shape (the
 // line is left untouched and goes through ParseBedLine) or the block ends without a '\n'.
-static inline char *ParseTabbedLine(char *line, char *end, BedFields *o)
+static inline char *ParseTabbedLine(char *line, char *end, BedFields *o, size_t *chrom_len)
 {
+  // the line's TABs, its '\n' and any blank, 16 bytes at a time (a BED3..BED6 read line is 20-40 bytes)
   char *tab[6]; int nt = 0;
-  char *p = line, *last_tab = nullptr;
-  for (; p < end; p++) {
-    const char ch = *p;
-    if (ch == '\n') break;
-    if (ch == ' ') return nullptr;
-    if (ch == '\t') { if (nt < 6) tab[nt] = p; nt++; last_tab = p; }
+  char *p = line, *last_tab = nullptr, *nl = nullptr;
+  const __m128i vt = _mm_set1_epi8('\t'), vn = _mm_set1_epi8('\n'), vs = _mm_set1_epi8(' ');
+  while (!nl) {
+    if (end - p >= 16) {
+      const __m128i x = _mm_loadu_si128((const __m128i *)p);
+      unsigned m = (unsigned)_mm_movemask_epi8(_mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(x, vt), _mm_cmpeq_epi8(x, vn)), _mm_cmpeq_epi8(x, vs)));
+      while (m) {
+        char *q = p + __builtin_ctz(m);
+        m &= m - 1;
+        const char ch = *q;
+        if (ch == '\n') { nl = q; break; }
+        if (ch == ' ') return nullptr;
+        if (nt < 6) tab[nt] = q;
+        nt++; last_tab = q;
+      }
+      p += 16;
+    } else {
+      for (; p < end; p++) {
+        const char ch = *p;
+        if (ch == '\n') { nl = p; break; }
+        if (ch == ' ') return nullptr;
+        if (ch == '\t') { if (nt < 6) tab[nt] = p; nt++; last_tab = p; }
+      }
+      if (!nl) return nullptr;                                     // the block ends without a '\n'
+    }
   }
-  if (p >= end || nt < 2) return nullptr;
+  p = nl;
+  if (nt < 2) return nullptr;
   // tokens as CountTokens sees them: one per TAB, plus the piece after the last TAB unless it is empty
   const int n_tokens = nt + (p > last_tab + 1 ? 1 : 0);
   if (n_tokens < 3 || n_tokens > 11) return nullptr;
@@ -253,9 +361,9 @@ static inline char *ParseTabbedLine(char *line, char *end, BedFields *o)
     else return nullptr;                                        // the general path words the error
   }
   o->n_tokens = n_tokens;
-  o->chrom = line; *tab[0] = 0;
-  o->start = FastAtolTo(tab[0] + 1, tab[1]) + 1;
-  o->stop = FastAtolTo(tab[1] + 1, nt >= 3 ? tab[2] : p);
+  o->chrom = line; *tab[0] = 0; *chrom_len = (size_t)(tab[0] - line);
+  o->start = FastDigitsTo(tab[0] + 1, tab[1], end) + 1;
+  o->stop = FastDigitsTo(tab[1] + 1, nt >= 3 ? tab[2] : p, end);
   o->strand = strand;
   o->label = nullptr;
   if (n_tokens >= 4) { o->label = tab[2] + 1; if (nt >= 4) *tab[3] = 0; else *p = 0; }
@@ -411,6 +519,7 @@ struct Piece {                       // one thread's share of a block
   int64_t label_sum = 0;
   // order-check context of the regions in this piece
   bool any = false;
+  const char *prev_chrom = nullptr; size_t prev_chrom_len = 0; int prev_id = -2;   // the line before (text still in the block) and its class lookup
   std::string first_chrom, last_chrom; char first_strand = '+', last_strand = '+';
   long first_start = 0, last_start = 0, first_region_line = 0;
 };
@@ -453,23 +562,25 @@ static inline bool GuardStep(IndexGuard *g, const BedFields &f)
 
 // What happens to one parsed region (the same for a text line and for a record of a packed file): order check,
 // chromosome lookup, the mode's validity rules, output.  Returns false when an error was recorded.
-struct ChromCache { std::string name; int id = -2; };
-static inline bool HandleRecord(Piece *p, const PackOptions &o, const BedFields &f, long label_value, long line_no, ChromCache &cc)
+// (sorted input repeats a chromosome millions of times in a row: the name of the line before is compared first -- by address for the
+//  records of a packed file -- and its order key, class id and strcmp are reused)
+static inline bool HandleRecord(Piece *p, const PackOptions &o, const BedFields &f, size_t chrom_len, long label_value, long line_no)
 {
   const bool sorted_mode = o.mode == PACK_OVERLAPS_SORTED || o.mode == PACK_SCAN_SORTED;
   const bool weighted = o.max_label_value > 1;
   const int n_chrom = o.chroms->size();
+    const bool same = p->prev_chrom && chrom_len == p->prev_chrom_len && (f.chrom == p->prev_chrom || memcmp(f.chrom, p->prev_chrom, chrom_len) == 0);
     if (sorted_mode) {
-      if (p->any && SortsBefore(f.chrom, f.strand, f.start, p->last_chrom.c_str(), p->last_strand, p->last_start, o.sorted_by_strand)) {
-        SetErr(&p->err, line_no, NotSortedMsg(o)); return false;
-      }
-      if (!p->any) { p->first_chrom = f.chrom; p->first_strand = f.strand; p->first_start = f.start; p->first_region_line = line_no; }
-      if (p->last_chrom != f.chrom) p->last_chrom = f.chrom;
+      if (p->any) {
+        const bool before = same ? ((o.sorted_by_strand && f.strand != p->last_strand) ? f.strand < p->last_strand : f.start < p->last_start)
+                                 : SortsBefore(f.chrom, f.strand, f.start, p->prev_chrom, p->last_strand, p->last_start, o.sorted_by_strand);
+        if (before) { SetErr(&p->err, line_no, NotSortedMsg(o)); return false; }
+      } else { p->first_chrom = f.chrom; p->first_strand = f.strand; p->first_start = f.start; p->first_region_line = line_no; }
       p->last_strand = f.strand; p->last_start = f.start; p->any = true;
     }
     if (o.guard && o.mode == PACK_OVERLAPS_SORTED && !GuardStep(o.guard, f)) { SetErr(&p->err, line_no, o.guard->msg, true); return false; }
-    if (cc.id == -2 || cc.name != f.chrom) { cc.name = f.chrom; cc.id = o.chroms->Find(f.chrom); }
-    const int id = cc.id;
+    if (!same) { p->prev_id = o.chroms->Find(f.chrom); p->prev_chrom = f.chrom; p->prev_chrom_len = chrom_len; }
+    const int id = p->prev_id;
     bool zero_len = false;
     long wv = 1;                                                         // GetLabelValue (genomic_intervals.cpp:1081-1085)
     if (weighted) { const long v = label_value; wv = v < o.max_label_value ? v : o.max_label_value; }
@@ -512,7 +623,6 @@ static inline bool HandleRecord(Piece *p, const PackOptions &o, const BedFields 
 void ParsePiece(Piece *p, const PackOptions &o)
 {
   const bool weighted = o.max_label_value > 1;
-  ChromCache cc;                                             // last chromosome looked up (sorted input repeats it millions of times)
   long line_no = p->first_line - 1;
   if (p->gtx) {                                              // records of a packed file: already tokenised, numbers already read
     const GtxView &g = *p->gtx;
@@ -524,8 +634,9 @@ void ParsePiece(Piece *p, const PackOptions &o)
       f.start = g.start[r]; f.stop = g.stop[r];
       f.strand = (g.minus[r >> 3] >> (r & 7)) & 1 ? '-' : '+';
       f.n_tokens = 6;
-      if (!HandleRecord(p, o, f, g.label ? g.label[r] : 0, line_no, cc)) break;
+      if (!HandleRecord(p, o, f, g.chrom[g.chrom_idx[r]].size(), g.label ? g.label[r] : 0, line_no)) break;
     }
+    if (p->prev_chrom) p->last_chrom = p->prev_chrom;
     p->n_lines = line_no - (p->first_line - 1);
     return;
   }
@@ -536,7 +647,8 @@ void ParsePiece(Piece *p, const PackOptions &o)
     BedFields f; char *bad = nullptr;
     BedStatus st = BED_OK;
     static const bool fast_lines = getenv("GTX_NO_FAST_PARSE") == nullptr;      // (the tests compare both ways)
-    char *next = fast_lines ? ParseTabbedLine(cur, p->end, &f) : nullptr;
+    size_t chrom_len = 0;
+    char *next = fast_lines ? ParseTabbedLine(cur, p->end, &f, &chrom_len) : nullptr;
     if (next) { cur = next; line_no++; }
     else {
       char *nl = (char *)memchr(cur, '\n', (size_t)(p->end - cur));
@@ -546,6 +658,7 @@ void ParsePiece(Piece *p, const PackOptions &o)
       cur = nl + 1;
       line_no++;
       st = ParseBedLine(line, &f, &bad);
+      if (st == BED_OK) chrom_len = strlen(f.chrom);
     }
     if (st == BED_TOO_FEW_TOKENS) { SetErr(&p->err, line_no, "number of tokens should be at least 3 for BED format!"); break; }
     if (st == BED_BAD_STRAND) { SetErr(&p->err, line_no, std::string("Error: invalid strand '") + bad + "'!", true); break; }
@@ -564,15 +677,24 @@ void ParsePiece(Piece *p, const PackOptions &o)
     if (f.start >= INT_MAX - 1 || f.stop >= INT_MAX - 1 || f.start <= INT_MIN + 1 || f.stop <= INT_MIN + 1) {
       SetErr(&p->err, line_no, "coordinate does not fit the packed 32-bit representation of the MI355X path!"); break;
     }
-    if (!HandleRecord(p, o, f, label_value, line_no, cc)) break;
+    if (!HandleRecord(p, o, f, chrom_len, label_value, line_no)) break;
   }
+  if (p->prev_chrom) p->last_chrom = p->prev_chrom;            // (a copy: the seam check of the next block outlives this one's text)
   p->n_lines = line_no - (p->first_line - 1);
 }
 
 long CountLines(const char *b, const char *e)
 {
   long n = 0;
-  while (b < e) { const char *nl = (const char *)memchr(b, '\n', (size_t)(e - b)); if (!nl) break; n++; b = nl + 1; }
+  const __m128i vn = _mm_set1_epi8('\n');
+  for (; e - b >= 64; b += 64) {                              // 64 bytes per turn: four compares, one population count
+    const unsigned long long m = (unsigned long long)(unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)b), vn)) |
+                                 ((unsigned long long)(unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(b + 16)), vn)) << 16) |
+                                 ((unsigned long long)(unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(b + 32)), vn)) << 32) |
+                                 ((unsigned long long)(unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(b + 48)), vn)) << 48);
+    n += __builtin_popcountll(m);
+  }
+  for (; b < e; b++) n += *b == '\n';
   return n;
 }
 
@@ -618,12 +740,9 @@ bool BedPacker::PackBlock(char *block, size_t got, long first_line, PackedBatch 
     pieces[t].begin = b; pieces[t].end = pe; b = pe;
   }
   // line numbers: count in parallel, prefix, then parse in parallel
-  {
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back([&pieces, t] { pieces[t].n_lines = CountLines(pieces[t].begin, pieces[t].end); });
-    pieces[0].n_lines = CountLines(pieces[0].begin, pieces[0].end);
-    for (auto &x : th) x.join();
-  }
+  const double tc = NowMs();
+  Pool::Run(T, [&pieces](int t) { pieces[t].n_lines = CountLines(pieces[t].begin, pieces[t].end); });
+  if (kTrace) fprintf(stderr, "[pack]   lines counted in %.1f ms (%d pieces)\n", NowMs() - tc, T);
   return PackPieces(&pieces, first_line, out, err);
 }
 
@@ -649,12 +768,9 @@ bool BedPacker::PackPieces(void *pieces_ptr, long first_line, PackedBatch *out, 
       before += (size_t)pieces[t].n_lines;
     }
   }
-  {
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back([&pieces, t, this] { ParsePiece(&pieces[t], opt_); });
-    ParsePiece(&pieces[0], opt_);
-    for (auto &x : th) x.join();
-  }
+  const double tp = NowMs();
+  Pool::Run(T, [&pieces, this](int t) { ParsePiece(&pieces[t], opt_); });
+  if (kTrace) fprintf(stderr, "[pack]   parsed in %.1f ms\n", NowMs() - tp);
   // seams and errors in file order; the first error in file order wins
   for (int t = 0; t < T; t++) {
     Piece &p = pieces[t];
@@ -699,10 +815,7 @@ bool BedPacker::PackPieces(void *pieces_ptr, long first_line, PackedBatch *out, 
       if (!pieces[t].tri_minus.empty()) memcpy(out->tri.data() + at_tri[T + t], pieces[t].tri_minus.data(), pieces[t].tri_minus.size() * sizeof(int32_t));
       if (!pieces[t].w_minus.empty()) memcpy(out->w.data() + at_w[T + t], pieces[t].w_minus.data(), pieces[t].w_minus.size() * sizeof(int32_t));
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back(copy_piece, t);
-    copy_piece(0);
-    for (auto &x : th) x.join();
+    Pool::Run(T, copy_piece);
   }
   for (int t = 0; t < T; t++) {
     out->zero_len.insert(out->zero_len.end(), pieces[t].zero_len.begin(), pieces[t].zero_len.end());
@@ -743,12 +856,16 @@ bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
   auto read_block = [this, block_bytes](int buf) { Ahead a; long fl = 0; a.buf = buf; a.got = src_->NextBlockView(blocks_[buf], &a.view, block_bytes, &fl); return a; };
   if (!ahead_.valid()) { ahead_ = std::async(std::launch::async, read_block, next_buf_); next_buf_ ^= 1; }
   while (out->tri.size() / 3 < target_reads) {
+    const double t0 = NowMs();
     Ahead cur = ahead_.get();
+    if (kTrace) fprintf(stderr, "[pack] waited %.1f ms for a block of %zu bytes\n", NowMs() - t0, cur.got);
     if (cur.got == 0) { ahead_ = std::future<Ahead>(); exhausted_ = true; return false; }
     const long first_line = src_->line_no() + 1;
     ahead_ = std::async(std::launch::async, read_block, next_buf_); next_buf_ ^= 1;      // the other buffer: cur's is being parsed
     const int64_t before = out->n_lines;
+    const double t1 = NowMs();
     bool ok = PackBlock(cur.view, cur.got, first_line, out, err);
+    if (kTrace) fprintf(stderr, "[pack] block packed in %.1f ms\n", NowMs() - t1);
     src_->AdvanceLines((long)(out->n_lines - before));
     if (!ok) { ahead_.wait(); return false; }
   }

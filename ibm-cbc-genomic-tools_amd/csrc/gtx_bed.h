@@ -144,12 +144,31 @@ struct PackError {
   std::string msg;                   // what the reference prints after "Error: Line N: "
 };
 
+// Where the big batch arrays live.  By default ordinary heap memory; the GPU-side host code installs a pool of page-locked
+// buffers here (genomic_intervals.cpp), so that the packer threads write the triples straight into memory the DMA engine reads --
+// no staging copy, and no first-touch page faults in the middle of the parse (the pool is filled while the reference set loads).
+// take(bytes) may return NULL (pool empty / request too large): the heap serves.  give(p) returns false for pointers it does not own.
+struct BatchArena {
+  static void *(*take)(size_t bytes);
+  static bool (*give)(void *p);
+};
+
 // std::vector that does not zero-fill on resize(): the packer threads overwrite every element
 template <class T>
 struct NoInitAlloc : std::allocator<T> {
   template <class U> struct rebind { typedef NoInitAlloc<U> other; };
   template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
   template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+  T *allocate(size_t n)
+  {
+    if (BatchArena::take && n * sizeof(T) >= (1u << 20)) { void *p = BatchArena::take(n * sizeof(T)); if (p) return (T *)p; }
+    return (T *)::operator new(n * sizeof(T));
+  }
+  void deallocate(T *p, size_t) noexcept
+  {
+    if (BatchArena::give && BatchArena::give((void *)p)) return;
+    ::operator delete((void *)p);
+  }
 };
 typedef std::vector<int32_t, NoInitAlloc<int32_t>> RawVec;
 

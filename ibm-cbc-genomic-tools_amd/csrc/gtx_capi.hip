@@ -189,7 +189,8 @@ void *gtx_host_alloc(gtx_ctx *c, size_t bytes)
 {
   if (!c) return nullptr;
   void *p = nullptr;
-  if (hipSetDevice(c->device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) { c->err = "gtx_host_alloc: hipHostMalloc failed"; (void)hipGetLastError(); return nullptr; }
+  // (portable: any device of a group may read it)
+  if (hipSetDevice(c->device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { c->err = "gtx_host_alloc: hipHostMalloc failed"; (void)hipGetLastError(); return nullptr; }
   return p;
 }
 

@@ -148,7 +148,13 @@ def test_one_pass_tab_parser_agrees_with_the_general_tokenizer(tmp_path, mode, e
                 if c == 0:
                     cols.append(str(rng.choice(["chr1", "chr2", "chr9", "chrX", ""])))
                 elif c in (1, 2) and rng.random() < 0.85:
-                    cols.append(str(int(rng.integers(-5, 5000))))
+                    kind = int(rng.integers(0, 8))                         # the digit fast path: 1..10 plain digits; everything else the loop
+                    if kind < 3: cols.append(str(int(rng.integers(-5, 5000))))
+                    elif kind == 3: cols.append(str(int(rng.integers(10**6, 10**8))))
+                    elif kind == 4: cols.append(str(int(rng.integers(10**8, 2147483640))))
+                    elif kind == 5: cols.append("0" * int(rng.integers(1, 7)) + str(int(rng.integers(0, 99999))))
+                    elif kind == 6: cols.append(str(rng.choice(["+", "-", ""])) + str(int(rng.integers(0, 10**9))))
+                    else: cols.append(str(int(rng.integers(10**9, 10**12))))
                 elif c == 5 and rng.random() < 0.8:
                     cols.append(str(rng.choice(["+", "-", ".", "1", "-1", "+1", "--", ""])))
                 else:
