@@ -409,6 +409,7 @@ void GtxSetDevices(int n) { g_ngpu = n; }
 static const size_t kBatchReads = getenv("GTX_HOST_BATCH_READS") && atol(getenv("GTX_HOST_BATCH_READS")) > 0 ? (size_t)atol(getenv("GTX_HOST_BATCH_READS")) : (8u << 20);   // reads per batch handed to the device
 static const size_t kPoolBytes = (kBatchReads * 3 + (24u << 20)) * sizeof(int32_t);   // what BedPacker::NextBatch reserves for it
 static struct { void *buf[2]; bool used[2]; gtx_ctx *owner; } g_pool = {{NULL, NULL}, {false, false}, NULL};
+static std::future<void> g_pool_future;
 
 static void *PoolTake(size_t bytes)
 {
@@ -435,9 +436,12 @@ static gtx_group *CreateGroup()
   gtx_group *g = gtx_group_create(n, ids.data());
   if (!g) { g_ctx_error = gtx_group_last_error(NULL); return g; }   // thread-local in the library: copy it out on this thread
   if (getenv("GTX_NO_PINNED_BATCHES") == NULL) {
+    // page-locking 2 x 190 MB takes ~70 ms: on a thread of its own, behind the packing of the index set and gtx_set_refs; DrainSet waits for it
     g_pool.owner = gtx_group_ctx(g, 0);
-    for (int k = 0; k < 2; k++) g_pool.buf[k] = gtx_host_alloc(g_pool.owner, kPoolBytes);      // (NULL: the heap serves)
-    gtxhost::BatchArena::take = PoolTake; gtxhost::BatchArena::give = PoolGive;
+    g_pool_future = std::async(std::launch::async, [] {
+      for (int k = 0; k < 2; k++) g_pool.buf[k] = gtx_host_alloc(g_pool.owner, kPoolBytes);    // (NULL: the heap serves)
+      gtxhost::BatchArena::take = PoolTake; gtxhost::BatchArena::give = PoolGive;
+    });
   }
   return g;
 }
@@ -469,6 +473,7 @@ template <class Sink>
 static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
 {
   const size_t batch_reads = kBatchReads;
+  if (g_pool_future.valid()) g_pool_future.get();             // the page-locked batch buffers are there
   PackedBatch two[2]; int cur = 0; PackError err;           // two batches in turn: one is packed while the device still reads the other
   auto pump = [&](BedPacker &packer) {
     for (;;) {
