@@ -446,9 +446,17 @@ static gtx_group *CreateGroup()
   return g;
 }
 
+// exit() on an input error may come while the start-up threads are still inside the HIP runtime: they are joined before
+// the static destructors (the runtime's own among them) run
+static void JoinStartUp()
+{
+  if (g_group_future.valid()) g_group_future.wait();
+  if (g_pool_future.valid()) g_pool_future.wait();
+}
+
 void GtxWarmUp()
 {
-  if (!g_group_future.valid()) g_group_future = std::async(std::launch::async, CreateGroup);
+  if (!g_group_future.valid()) { atexit(JoinStartUp); g_group_future = std::async(std::launch::async, CreateGroup); }
 }
 
 static gtx_group *Devices()
