@@ -9,22 +9,34 @@
 // CU, the global histograms receive one contiguous flush per block.  A full sort is not needed (counting does
 // not depend on the order inside a bucket), one partition level is enough.
 //
-//   bucket_hist_kernel     one streaming read of the triples: bucket of every read (binary search of the start in an LDS
-//                          copy of the bucket table), per-bucket totals through LDS counters; nothing per read is
-//                          written.  Also counts the reads of unknown class / start > end for gtx_count_info.
-//   bucket_scan_kernel     exclusive prefix of the totals (one block)
-//   bucket_split_kernel    second read of the triples, a tile of 4096 reads per block: bucket again (cheaper than carrying
-//                          2 bytes per read through HBM), rank inside (block, bucket) from the LDS counter, ONE global
-//                          reservation per (block, bucket), the tile regrouped by bucket in LDS and copied out so that
-//                          consecutive lanes write consecutive (start, end) pairs: bursts of tile/buckets pairs
-//                          instead of 8-byte scattered stores (round 1: 1.2-1.35 ms of its 3.0 ms went there)
+// The partition is ONE pass over the triples and takes no global atomic (round 1 and the first half of round 2 read the
+// triples twice -- a histogram pass to size the buckets' regions -- and reserved room per (tile, bucket) with a returning
+// atomic on a per-bucket counter: 25 k tiles adding to one address is a chain of ~50 ns steps, which bounded the pass):
+//
+//   bucket_scatter_kernel  blocks stay and take tiles of 4096 reads in turn (the next tile's loads in flight meanwhile).
+//                          Every block owns an ARENA of the scratch array -- as many pairs as it will see reads, plus a
+//                          chunk per bucket -- and deals it out in chunks of 64 (start, end) pairs, a current chunk per
+//                          bucket.  Per tile: bucket of every read (direct-address table in LDS, no branches), rank inside
+//                          (tile, bucket) from the return value of an LDS counter's atomic, one LDS-only step per bucket
+//                          (room left in its chunk, new chunks from the arena when that does not do; wave prefix sums),
+//                          the tile regrouped by bucket in LDS and copied out so that consecutive lanes store consecutive
+//                          pairs.  A chunk is filled completely before the bucket gets another, so the arena cannot run
+//                          out and nothing is estimated.  Also counts the reads of unknown class / start > end for
+//                          gtx_count_info and sets inverted reads aside (CountArgs::side) -- on a branch of its own.
+//   chunk_rows_kernel, chunk_offsets_kernel   exclusive prefixes over the (bucket, block) matrix of chunk counts: where each
+//                          block's chunks of each bucket go in the bucket-major chunk list
+//   chunk_place_kernel     one block per arena: its directory entries (chunk -> bucket, fill) into the list
 //   bucket_count_kernel    grid = buckets x splits: the bucket's slices of both boundary arrays in LDS with a
-//                          direct-address table over their value range (cell -> first boundary in the cell), so a rank is two
-//                          table reads + a search among the few boundaries of one cell instead of a 12-probe binary
-//                          search whose probes of different lanes fall on one LDS bank; two LDS atomics per read,
-//                          contiguous atomic flush.  A read whose end lies beyond the bucket's slice of the starts array
-//                          (longer than the bucket is wide) falls back to a global search + atomic for histogram B.
-// Traffic per read: 12 B read twice, 8 B (start, end) written and read once: ~3.2 GB for 100 M reads.
+//                          direct-address table over their value range (cell -> the boundaries of the cell), so a rank is one
+//                          table read + a search among the few boundaries of one cell instead of a 12-probe binary
+//                          search whose probes of different lanes fall on one LDS bank; a wave takes a chunk per step (four in
+//                          flight, their ranks step by step together), two LDS atomics per read, contiguous atomic flush.
+//                          A read whose end lies beyond the bucket's slice of the starts array (longer than the bucket is
+//                          wide) falls back to a global search + atomic for histogram B.
+// Traffic per read: 12 B read, 8 B (start, end) written and read once: 2.8 GB for 100 M reads (+ 8 B per chunk of directory and
+// list).  What bounds the scatter pass is not that traffic but instruction issue and LDS round trips between four barriers per
+// tile (cycle counters per phase: DESIGN.md 4.2); storing the pairs straight from the loading threads' registers instead of
+// regrouping costs a 64-byte L2 request per pair and comes out the same.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
@@ -38,7 +50,7 @@ typedef unsigned long long u64;
 typedef long long i64;
 struct __attribute__((packed, aligned(4))) Tri3 { int c, s, e; };
 
-static constexpr int kNoBucket = -1;
+static constexpr int kChunk = 64, kChunkShift = 6;                // pairs per chunk: a wave's load in the counting kernel, 512 B
 
 __device__ __forceinline__ Tri3 load_tri3(const Tri3 *p)
 {
@@ -48,148 +60,250 @@ __device__ __forceinline__ Tri3 load_tri3(const Tri3 *p)
   return t;
 }
 
-// bucket of a countable read (class known, not degenerate): the class's buckets are posHi-sorted, the last takes everything above
-__device__ __forceinline__ int bucket_of(const int *__restrict__ posHi, const int *__restrict__ clsStart, int c, int s)
+// Bucket of a read through the direct-address table (BucketTable::clsCell / cellTab, copies in LDS): the class's entry, the cell
+// of s, the first bucket that can hold a position of that cell, then upwards while s lies above the bucket (the cuts are wider
+// than a cell on average: ~1 comparison).  No branches on the way: a read that is not counted (unknown class, start > end, beyond
+// the input) and a class without reference regions go through a NULL entry -- class index nClasses, cell nCells, bucket nB, which
+// takes any position -- and N reads of a thread go step by step together: three LDS round trips for all of them.
+// LDS copies: clsCell[c] = {first cell, lowest cut, cells - 1, first bucket}, [nClasses] = null; tab[nCells] = 0; posHi[nB] = INT_MAX.
+template <int N>
+__device__ __forceinline__ void bucket_lookup(const int4 *__restrict__ clsCell, const unsigned short *__restrict__ tab, const int *__restrict__ posHi, int sh,
+                                              int nullClass, const bool (&want)[N], const int (&c)[N], const int (&s)[N], int (&id)[N])
 {
-  int lo = clsStart[c], hi = clsStart[c + 1];
-  if (lo >= hi) return kNoBucket;                                  // a class without reference regions
-  hi--;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (s <= posHi[mid]) hi = mid; else lo = mid + 1; }
-  return lo;
-}
-
-template <bool WEIGHTED>
-__global__ __launch_bounds__(1024) void bucket_hist_kernel(const Tri3 *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a, BucketTable t, BucketWork w)
-{
-  extern __shared__ int lds[];
-  int *posHi = lds; unsigned *cnt = (unsigned *)(lds + t.nB); int *clsStart = lds + 2 * t.nB;
-  for (int i = threadIdx.x; i < t.nB; i += blockDim.x) { posHi[i] = t.posHi[i]; cnt[i] = 0; }
-  for (int i = threadIdx.x; i <= a.nClasses; i += blockDim.x) clsStart[i] = t.clsStart[i];
-  __syncthreads();
-  i64 nNoClass = 0, nDegen = 0, firstDegen = INT64_MAX;
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
-    const Tri3 r = load_tri3(reads + i);
-    if ((unsigned)r.c >= (unsigned)a.nClasses) nNoClass++;
-    else if (r.s > r.e + a.zeroLenOk) {
-      nDegen++; if (i < firstDegen) firstDegen = i;
-      if (a.side) { const unsigned k = atomicAdd(a.sideCount, 1u); if (k < (unsigned)a.sideCap) a.side[k] = make_int4(r.c, r.s, r.e, WEIGHTED ? weights[i] : 1); }   // see CountArgs::side
-    } else {
-      const int b = bucket_of(posHi, clsStart, r.c, r.s);
-      if (b >= 0) atomicAdd(&cnt[b], 1u);
-    }
+  int4 cc[N]; int ph[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) cc[k] = clsCell[want[k] ? c[k] : nullClass];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    unsigned cell = ((unsigned)s[k] - (unsigned)cc[k].y) >> sh;
+    cell = cell < (unsigned)cc[k].z ? cell : (unsigned)cc[k].z;
+    cell = s[k] > cc[k].y ? cell : 0u;
+    id[k] = cc[k].w + tab[cc[k].x + cell];
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < t.nB; i += blockDim.x) if (cnt[i]) atomicAdd(&w.count[i], cnt[i]);
-  if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
-  if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, firstDegen + a.indexBase); }
+#pragma unroll
+  for (int k = 0; k < N; k++) ph[k] = posHi[id[k]];
+#pragma unroll
+  for (int k = 0; k < N; k++) while (s[k] > ph[k]) ph[k] = posHi[++id[k]];              // the class's last bucket has posHi = INT_MAX
 }
 
-// offset[b] = reads in buckets < b; cursor = copy for the split's reservations; the totals are zeroed for the next call
-__global__ __launch_bounds__(1024) void bucket_scan_kernel(BucketTable t, BucketWork w)
+// inclusive prefix sum over the 64 lanes by DPP (row shifts, then row broadcasts); call with all lanes active
+__device__ __forceinline__ unsigned wave_prefix(unsigned x)
 {
-  __shared__ unsigned part[1024];
-  const int per = (t.nB + 1023) / 1024, b0 = threadIdx.x * per;
-  unsigned s = 0;
-  for (int k = 0; k < per; k++) if (b0 + k < t.nB) s += w.count[b0 + k];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) { unsigned run = 0; for (int i = 0; i < 1024; i++) { unsigned v = part[i]; part[i] = run; run += v; } }
-  __syncthreads();
-  unsigned run = part[threadIdx.x];
-  for (int k = 0; k < per; k++) if (b0 + k < t.nB) {
-    const unsigned v = w.count[b0 + k];
-    w.offset[b0 + k] = run; w.cursor[b0 + k] = run; w.count[b0 + k] = 0;
-    run += v;
-  }
-  if (threadIdx.x == 1023) w.offset[t.nB] = run;
+  int v = (int)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return (unsigned)v;
 }
 
-// One tile of TB reads per block.  LDS: the bucket table (posHi, clsStart), per bucket {count, first place in the tile,
-// reserved place in the output}, and the tile regrouped by bucket: (start, end), bucket [, weight] per read.
-template <bool WEIGHTED, int TB>
-__global__ __launch_bounds__(1024) void bucket_split_kernel(const Tri3 *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a, BucketTable t, BucketWork w)
+// LDS: the lookup tables (clsCell, posHi, cellTab); per bucket {reads of this tile, next free place of its chunk, chunks so far}
+// and where this tile's reads go {A = place of rank 0 (room = pairs left in that chunk = -A mod 64), B + rank = place of the
+// ranks beyond, L = first place in the staged tile}; the tile regrouped by bucket: (start, end, place in the scratch array,
+// weight) per read, an array each -- neighbours in a bucket are neighbours in LDS and in the scratch array, so the copy out of LDS stores runs of
+// pairs (one 64-byte request per ~8 pairs; storing the pairs straight from the registers of the threads that loaded them is a
+// request per pair, and ~2e11 requests/s is what the L2 takes: 0.75 ms per 100 M reads against 0.4x here).
+template <bool WEIGHTED, int PER>
+__global__ __launch_bounds__(1024, 8) void bucket_scatter_kernel(const Tri3 *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a, BucketTable t, BucketWork w)
 {
-  constexpr int PER = TB / 1024;
-  extern __shared__ int lds[];
+  constexpr int TB = PER * 1024;
+  extern __shared__ int4 lds4[];
   const int nB = t.nB;
-  int *posHi = lds; unsigned *cnt = (unsigned *)(lds + nB), *lstart = cnt + nB, *gbase = lstart + nB; int *clsStart = (int *)(gbase + nB);
-  int2 *stage = (int2 *)(clsStart + ((a.nClasses + 2) & ~1));
-  int *sw = (int *)(stage + TB);                                   // weights of the regrouped tile (WEIGHTED)
-  unsigned short *sid = (unsigned short *)(sw + (WEIGHTED ? TB : 0));
-  __shared__ unsigned wsum[16];
-  for (int i = threadIdx.x; i < nB; i += 1024) { posHi[i] = t.posHi[i]; cnt[i] = 0; }
-  for (int i = threadIdx.x; i <= a.nClasses; i += 1024) clsStart[i] = t.clsStart[i];
-  __syncthreads();
-  const i64 first = (i64)blockIdx.x * TB;
-  int rs[PER], re[PER], rw[PER], id[PER]; unsigned rank[PER];
+  int4 *clsCell = lds4; uint4 *gb = (uint4 *)(clsCell + a.nClasses + 1); int2 *stage = (int2 *)(gb + nB + 1); unsigned *sat = (unsigned *)(stage + TB);
+  int *sw = (int *)(sat + TB); int *posHi = sw + (WEIGHTED ? TB : 0); unsigned *cnt = (unsigned *)(posHi + nB + 1), *next = cnt + nB + 1, *nch = next + nB;
+  unsigned short *tab = (unsigned short *)(nch + nB);
+  __shared__ unsigned arenaCur, tileCur[2];
+  const unsigned arena0 = blockIdx.x * w.arenaPairs;               // this block's part of the scratch array
+  const int4 nullEntry = make_int4(t.nCells, INT_MAX, 0, nB);       // (bucket_lookup)
+  for (int i = threadIdx.x; i < nB; i += 1024) { posHi[i] = t.posHi[i]; cnt[i] = 0; next[i] = 0; nch[i] = 0; }   // next = 0: no chunk yet, no room
+  for (int i = threadIdx.x; i < a.nClasses; i += 1024) { int4 e = t.clsCell[i]; e.z -= 1; clsCell[i] = e.z < 0 ? nullEntry : e; }
+  for (int i = threadIdx.x; i < t.nCells; i += 1024) tab[i] = t.cellTab[i];
+  if (threadIdx.x == 0) { arenaCur = arena0; tileCur[0] = tileCur[1] = 0; clsCell[a.nClasses] = nullEntry; tab[t.nCells] = 0; posHi[nB] = INT_MAX; cnt[nB] = 0; }
+  // (this path takes n < 2^31: 32-bit indices)
+  const unsigned un = (unsigned)n, tiles = (unsigned)((n + TB - 1) / TB);
+  Tri3 nx[PER]; int nw[PER];
+  auto fetch = [&](unsigned tile) {
 #pragma unroll
-  for (int k = 0; k < PER; k++) {
-    const i64 i = first + k * 1024 + threadIdx.x;
-    id[k] = kNoBucket; rs[k] = re[k] = 0; rw[k] = 1; rank[k] = 0;
-    if (i < n) {
-      const Tri3 r = load_tri3(reads + i);
-      rs[k] = r.s; re[k] = r.e;
-      if (WEIGHTED) rw[k] = weights[i];
-      if ((unsigned)r.c < (unsigned)a.nClasses && !(r.s > r.e + a.zeroLenOk)) id[k] = bucket_of(posHi, clsStart, r.c, r.s);
-      if (id[k] >= 0) rank[k] = atomicAdd(&cnt[id[k]], 1u);       // its rank among the tile's reads of that bucket
+    for (int k = 0; k < PER; k++) {
+      const unsigned i = tile * TB + k * 1024 + threadIdx.x;
+      nx[k].c = -1; nx[k].s = nx[k].e = 0; nw[k] = 1;
+      if (tile < tiles && i < un) { nx[k] = load_tri3(reads + i); if (WEIGHTED) nw[k] = __builtin_nontemporal_load(weights + i); }
     }
-  }
+  };
+  fetch(blockIdx.x);
   __syncthreads();
-  // exclusive scan of the counts over the buckets (thread = a run of buckets) + one reservation per bucket present
-  {
-    const int per = (nB + 1023) / 1024, b0 = threadIdx.x * per;
-    unsigned s = 0;
-    for (int k = 0; k < per; k++) if (b0 + k < nB) s += cnt[b0 + k];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned inc = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o); if (lane >= o) inc += up; }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    unsigned run = inc - s;
-    for (int k = 0; k < wv; k++) run += wsum[k];
-    for (int k = 0; k < per; k++) if (b0 + k < nB) {
-      const unsigned c = cnt[b0 + k];
-      lstart[b0 + k] = run;
-      if (c) gbase[b0 + k] = atomicAdd(&w.cursor[b0 + k], c);
-      run += c;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < PER; k++) if (id[k] >= 0) {
-    const unsigned p = lstart[id[k]] + rank[k];
-    stage[p] = make_int2(rs[k], re[k]); sid[p] = (unsigned short)id[k];
-    if (WEIGHTED) sw[p] = rw[k];
-  }
-  __syncthreads();
-  const unsigned total = lstart[nB - 1] + cnt[nB - 1];
+  unsigned nNoClass = 0, nDegen = 0, firstDegen = 0xffffffffu;
   int2 *__restrict__ out = (int2 *)w.tmpReads;                    // (start, end): the class is the bucket's
-  for (unsigned j = threadIdx.x; j < total; j += 1024) {
-    const unsigned b = sid[j], dst = gbase[b] + (j - lstart[b]);  // neighbours of one bucket are neighbours in the output
-    out[dst] = stage[j];
-    if (WEIGHTED) w.tmpWeights[dst] = sw[j];
+  const int sh = t.cellShift, lane = threadIdx.x & 63;
+  unsigned parity = 0;
+  for (unsigned tile = blockIdx.x; tile < tiles; tile += gridDim.x, parity ^= 1) {
+    int rc[PER], rs[PER], re[PER], rw[PER], id[PER]; unsigned rank[PER]; bool want[PER];
+    bool other = false;                                             // a read of this thread that is not counted: unknown class or start > end
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const unsigned i = tile * TB + k * 1024 + threadIdx.x;
+      const Tri3 r = nx[k];
+      rc[k] = r.c; rs[k] = r.s; re[k] = r.e; rw[k] = nw[k]; rank[k] = 0;
+      const bool in = i < un, ok = (unsigned)r.c < (unsigned)a.nClasses && r.s <= r.e + a.zeroLenOk;
+      want[k] = in && ok; other |= in && !ok;
+    }
+    if (__builtin_amdgcn_ballot_w64(other)) {                        // (rare: kept out of the way of the common path, which is bound by instruction issue)
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        const unsigned i = tile * TB + k * 1024 + threadIdx.x;
+        if (i < un && !want[k]) {
+          if ((unsigned)rc[k] >= (unsigned)a.nClasses) nNoClass++;
+          else {
+            nDegen++; if (i < firstDegen) firstDegen = i;
+            if (a.side) { const unsigned q = atomicAdd(a.sideCount, 1u); if (q < (unsigned)a.sideCap) a.side[q] = make_int4(rc[k], rs[k], re[k], rw[k]); }   // see CountArgs::side
+          }
+        }
+      }
+    }
+    bucket_lookup<PER>(clsCell, tab, posHi, sh, a.nClasses, want, rc, rs, id);
+    fetch(tile + gridDim.x);                                        // in flight until the top of the next round
+#pragma unroll
+    for (int k = 0; k < PER; k++) rank[k] = atomicAdd(&cnt[id[k]], 1u);   // its rank among the tile's reads of that bucket (bucket nB: the reads that are not counted)
+    __syncthreads();
+    // per bucket present: room in its chunk or new chunks from the arena, and its stretch of the staged tile
+    if (threadIdx.x == 0) { tileCur[parity ^ 1] = 0; cnt[nB] = 0; }
+    for (int b0 = 0; b0 < nB; b0 += 1024) {
+      const int b = b0 + threadIdx.x;
+      const unsigned c = b < nB ? cnt[b] : 0u;
+      const unsigned A = b < nB ? next[b] : 0u, room = (0u - A) & (kChunk - 1);
+      // the chunk fills up: as many new ones as the rest needs, side by side.  Both running sums (places in the staged tile, pairs
+      // of the arena) by wave prefix and one LDS atomic per wave
+      const unsigned need = c > room ? c - room : 0u, fresh = (need + kChunk - 1) & ~(unsigned)(kChunk - 1);
+      const unsigned incL = wave_prefix(c), incF = wave_prefix(fresh);
+      unsigned baseL = 0, baseF = 0;
+      if (lane == 63 && incL) { baseL = atomicAdd(&tileCur[parity], incL); if (incF) baseF = atomicAdd(&arenaCur, incF); }
+      baseL = (unsigned)__builtin_amdgcn_readlane((int)baseL, 63); baseF = (unsigned)__builtin_amdgcn_readlane((int)baseF, 63);
+      if (c) {
+        const unsigned at = baseF + incF - fresh;
+        cnt[b] = 0; next[b] = need ? at + need : A + c;
+        gb[b] = make_uint4(A, at - room, baseL + incL - c, 0u);
+        if (need) {
+          nch[b] += fresh >> kChunkShift;
+          for (unsigned j = 0; j < fresh >> kChunkShift; j++) w.dir[(at >> kChunkShift) + j] = (unsigned)b | ((unsigned)kChunk << 16);   // full, unless it stays the bucket's last (below)
+        }
+      }
+    }
+    __syncthreads();
+    {
+      uint4 g[PER];
+#pragma unroll
+      for (int k = 0; k < PER; k++) g[k] = gb[id[k]];               // (entry nB: whatever; not used)
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        const unsigned room = (0u - g[k].x) & (kChunk - 1), at = (rank[k] < room ? g[k].x : g[k].y) + rank[k], p = g[k].z + rank[k];
+        if (id[k] != nB) {
+          stage[p] = make_int2(rs[k], re[k]); sat[p] = at;
+          if (WEIGHTED) sw[p] = rw[k];
+        }
+      }
+    }
+    __syncthreads();
+    const unsigned total = tileCur[parity];
+    for (unsigned j = threadIdx.x; j < total; j += 1024) {
+      const unsigned at = sat[j];
+      out[at] = stage[j];
+      if (WEIGHTED) w.tmpWeights[at] = sw[j];
+    }
+    // (the next round's writes to cnt and tileCur come behind barriers every wave reaches after this copy; those to stage and gb too)
+  }
+
+  __syncthreads();
+  for (int b = threadIdx.x; b < nB; b += 1024) {
+    const unsigned e = next[b];
+    if (e & (kChunk - 1)) w.dir[e >> kChunkShift] = (unsigned)b | ((e & (kChunk - 1)) << 16);   // the bucket's last chunk is part full
+    w.chunkCount[(size_t)b * gridDim.x + blockIdx.x] = nch[b];
+  }
+  if (threadIdx.x == 0) w.arenaUsed[blockIdx.x] = (arenaCur - arena0) >> kChunkShift;
+  if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
+  if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, (i64)firstDegen + a.indexBase); }
+}
+
+// chunkCount[b * G + k] (chunks of bucket b in the arena of block k): exclusive prefix inside the row of every bucket (one block
+// per bucket), then over the buckets' totals (one block): bucket b's chunks of arena k start at rowOff[b] + chunkCount[b * G + k]
+__global__ __launch_bounds__(256) void chunk_rows_kernel(BucketWork w, unsigned nArenas)
+{
+  __shared__ unsigned wsum[4];
+  unsigned *row = w.chunkCount + (size_t)blockIdx.x * nArenas;
+  const unsigned per = (nArenas + 255) / 256, i0 = threadIdx.x * per;
+  unsigned s = 0;
+  for (unsigned k = 0; k < per; k++) if (i0 + k < nArenas) s += row[i0 + k];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  unsigned run = inc - s;
+  for (int k = 0; k < wv; k++) run += wsum[k];
+  for (unsigned k = 0; k < per; k++) if (i0 + k < nArenas) { const unsigned v = row[i0 + k]; row[i0 + k] = run; run += v; }
+  if (threadIdx.x == 255) w.rowOff[blockIdx.x] = run;             // the bucket's total, turned into its offset by the next kernel
+}
+
+__global__ __launch_bounds__(1024) void chunk_offsets_kernel(BucketWork w, int nB)
+{
+  __shared__ unsigned wsum[16];
+  const int per = (nB + 1023) / 1024, i0 = threadIdx.x * per;
+  unsigned s = 0;
+  for (int k = 0; k < per; k++) if (i0 + k < nB) s += w.rowOff[i0 + k];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  unsigned run = inc - s;
+  for (int k = 0; k < wv; k++) run += wsum[k];
+  for (int k = 0; k < per; k++) if (i0 + k < nB) { const unsigned v = w.rowOff[i0 + k]; w.rowOff[i0 + k] = run; run += v; }
+  if (threadIdx.x == 1023) w.rowOff[nB] = run;
+}
+
+// block k: the chunks of its arena into the bucket-major list: entry = chunk << 6 | (fill - 1)
+__global__ __launch_bounds__(1024) void chunk_place_kernel(BucketTable t, BucketWork w, unsigned nArenas)
+{
+  extern __shared__ unsigned seen[];
+  for (int i = threadIdx.x; i < t.nB; i += blockDim.x) seen[i] = 0;
+  __syncthreads();
+  const unsigned k = blockIdx.x, first = k * (w.arenaPairs >> kChunkShift), used = w.arenaUsed[k];
+  for (unsigned j = threadIdx.x; j < used; j += blockDim.x) {
+    const unsigned d = w.dir[first + j], b = d & 0xffffu, fill = d >> 16;
+    const unsigned r = atomicAdd(&seen[b], 1u);
+    w.list[w.rowOff[b] + w.chunkCount[(size_t)b * nArenas + k] + r] = ((first + j) << kChunkShift) | (fill - 1);
   }
 }
 
 static constexpr int kBktE = 2048, kBktS = 4096;                 // boundaries per bucket (ends array) / starts-array slice in LDS
 static constexpr int kCellsE = 2048, kCellsS = 4096;             // cells of the direct-address tables
 
-// rank of `key` among the sorted boundaries v[0..n): #{v < key} (LE = false) or #{v <= key} (true), through the table
-// tab[c] = first index whose value lies in cell >= c (cell(x) = (x - lo) >> sh, clamped to [0, cells)): two table reads bound
-// the search to the boundaries of one cell
-template <bool LE>
-__device__ __forceinline__ int table_rank(const int *__restrict__ v, const unsigned short *__restrict__ tab, int cells, int lo, int sh, int key)
+// ranks of U keys among the sorted boundaries v[0..n): #{v < key} (LE = false) or #{v <= key} (true), through the table
+// tab[c] = i0 | i1 << 16: the boundaries whose value lies in cell c are v[i0..i1) (cell(x) = (x - lo) >> sh, clamped to [0, cells)):
+// one table read bounds the search to the boundaries of one cell (~1).  The U keys of a thread go step by step together.
+template <bool LE, int U>
+__device__ __forceinline__ void table_ranks(const int *__restrict__ v, const unsigned *__restrict__ tab, int cells, int lo, int sh, const int (&key)[U], int (&rank)[U])
 {
-  const i64 d = (i64)key - lo;
-  const int c = d < 0 ? 0 : (int)((d >> sh) < cells - 1 ? (d >> sh) : cells - 1);
-  int a = tab[c], b = tab[c + 1];
-  while (a < b) { const int mid = (a + b) >> 1; if (LE ? v[mid] <= key : v[mid] < key) a = mid + 1; else b = mid; }
-  return a;
+  unsigned t[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    unsigned c = ((unsigned)key[u] - (unsigned)lo) >> sh;
+    c = c < (unsigned)cells - 1 ? c : (unsigned)cells - 1;
+    t[u] = tab[key[u] > lo ? c : 0u];
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    int a = (int)(t[u] & 0xffffu), b = (int)(t[u] >> 16);
+    while (a < b) { const int mid = (a + b) >> 1; if (LE ? v[mid] <= key[u] : v[mid] < key[u]) a = mid + 1; else b = mid; }
+    rank[u] = a;
+  }
 }
 
-// tab[0..cells]: tab[c] = #{v_i : cell(v_i) < c}; tab[cells] = n
-__device__ __forceinline__ void build_table(const int *__restrict__ v, int n, unsigned short *__restrict__ tab, int cells, int lo, int sh)
+// tab[c] for c in [0, cells): low half = #{v_i : cell(v_i) < c}, then the high half = the next cell's low half (n for the last)
+__device__ __forceinline__ void build_table(const int *__restrict__ v, int n, unsigned *__restrict__ tab, int cells, int lo, int sh)
 {
   for (int c = threadIdx.x; c <= cells; c += blockDim.x) {
     int a = 0, b = n;
@@ -200,8 +314,10 @@ __device__ __forceinline__ void build_table(const int *__restrict__ v, int n, un
       const i64 cm = (d >> sh) < cells - 1 ? (d >> sh) : cells - 1;    // cell of v[mid] (d >= 0: lo is the smallest value)
       if (cm < c) a = mid + 1; else b = mid;
     }
-    tab[c] = (unsigned short)a;
+    tab[c] = (unsigned)a;
   }
+  __syncthreads();
+  for (int c = threadIdx.x; c < cells; c += blockDim.x) tab[c] |= (tab[c + 1] & 0xffffu) << 16;   // (a neighbour's update leaves the low half as it is)
 }
 
 __device__ __forceinline__ int shift_for(int lo, int hi, int cells)
@@ -212,18 +328,18 @@ __device__ __forceinline__ int shift_for(int lo, int hi, int cells)
   return sh;
 }
 
-// (1024 threads, 4 reads in flight per thread: the loop is a chain global load -> table -> search -> atomic, and what bounds
-// the kernel is how many of those chains a CU has open)
+// (1024 threads, a chunk of <= 64 reads per wave and step, 4 in flight: the loop is a chain global load -> table -> search ->
+// atomic, and what bounds the kernel is how many of those chains a CU has open)
 template <bool WEIGHTED>
 __global__ __launch_bounds__(1024) void bucket_count_kernel(CountArgs a, BucketTable t, BucketWork w, int splits)
 {
   __shared__ int sE[kBktE], sS[kBktS];
-  __shared__ unsigned short tE[kCellsE + 2], tS[kCellsS + 2];
+  __shared__ unsigned tE[kCellsE + 1], tS[kCellsS + 1];
   typedef typename std::conditional<WEIGHTED, u64, unsigned>::type hist_t;   // a block sees < 2^32 reads
   __shared__ hist_t hA[kBktE + 1], hB[kBktS + 1];
   const int b = blockIdx.x / splits, k = blockIdx.x % splits;
-  const unsigned off = w.offset[b], cntB = w.offset[b + 1] - off;
-  const unsigned r0 = off + (unsigned)((u64)cntB * k / splits), r1 = off + (unsigned)((u64)cntB * (k + 1) / splits);
+  const unsigned c0 = w.rowOff[b], nCh = w.rowOff[b + 1] - c0;   // the bucket's stretch of the chunk list
+  const unsigned r0 = c0 + (unsigned)((u64)nCh * k / splits), r1 = c0 + (unsigned)((u64)nCh * (k + 1) / splits);
   if (r0 == r1) return;
   const int eLo = t.eLo[b], nE = t.eHi[b] - eLo, sLo = t.sLo[b], sHi = t.sHi[b], nS = sHi - sLo, cls = t.cls[b];
   const int segEnd = a.segStart[cls + 1];
@@ -238,27 +354,37 @@ __global__ __launch_bounds__(1024) void bucket_count_kernel(CountArgs a, BucketT
   build_table(sS, nS, tS, kCellsS, loS, shS);
   __syncthreads();
   const int2 *__restrict__ reads = (const int2 *)w.tmpReads;
-  const unsigned cnt = r1 - r0;
   constexpr int U = 4;
-  for (unsigned at = threadIdx.x; at < cnt; at += U * blockDim.x) {
-    int2 se[U]; int wt4[U];
+  const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nW = blockDim.x >> 6;
+  unsigned ent[U];                                                 // list entries of the round: loaded a round ahead
+  auto entries = [&](unsigned at) {
+#pragma unroll
+    for (int u = 0; u < U; u++) { const unsigned ci = at + u * nW; ent[u] = ci < r1 ? w.list[ci] : 0u; }
+  };
+  entries(r0 + wv);
+  for (unsigned at = r0 + wv; at < r1; at += U * nW) {
+    int2 se[U]; int wt4[U]; bool on[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const unsigned j = at + u * blockDim.x;
+      const unsigned e = ent[u], place = (e >> kChunkShift << kChunkShift) + lane;
       se[u] = make_int2(0, -1); wt4[u] = 1;
-      if (j < cnt) { se[u] = reads[r0 + j]; if (WEIGHTED) wt4[u] = w.tmpWeights[r0 + j]; }
+      on[u] = at + u * nW < r1 && lane <= (e & (kChunk - 1));
+      if (on[u]) { se[u] = reads[place]; if (WEIGHTED) wt4[u] = w.tmpWeights[place]; }
     }
+    entries(at + U * nW);
+    int ks[U], ke[U], slotA[U], slotB[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { ks[u] = se[u].x; ke[u] = se[u].y; }
+    table_ranks<false, U>(sE, tE, kCellsE, loE, shE, ks, slotA);      // #{E < s} inside the slice
+    table_ranks<true, U>(sS, tS, kCellsS, loS, shS, ke, slotB);       // #{S <= e} inside the slice
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (at + u * blockDim.x >= cnt) break;
       const u64 wt = WEIGHTED ? (u64)(i64)wt4[u] : 1;
-      const int slotA = table_rank<false>(sE, tE, kCellsE, loE, shE, se[u].x);           // #{E < s} inside the slice
-      atomicAdd(&hA[slotA], (hist_t)wt);
-      const int lo = table_rank<true>(sS, tS, kCellsS, loS, shS, se[u].y);               // #{S <= e} inside the slice
-      if (lo < nS || sHi == segEnd) atomicAdd(&hB[lo], (hist_t)wt);
-      else {                                                        // the read ends beyond the slice: global search above it
+      if (on[u]) atomicAdd(&hA[slotA[u]], (hist_t)wt);
+      if (on[u] && (slotB[u] < nS || sHi == segEnd)) atomicAdd(&hB[slotB[u]], (hist_t)wt);
+      else if (on[u]) {                                             // the read ends beyond the slice: global search above it
         int glo = sHi, ghi = segEnd;
-        while (glo < ghi) { const int mid = (int)(((i64)glo + ghi) >> 1); if (a.sortedS[mid] <= se[u].y) glo = mid + 1; else ghi = mid; }
+        while (glo < ghi) { const int mid = (int)(((i64)glo + ghi) >> 1); if (a.sortedS[mid] <= ke[u]) glo = mid + 1; else ghi = mid; }
         atomicAdd(&a.histB[(i64)glo + cls], wt);
       }
     }
@@ -271,42 +397,65 @@ __global__ __launch_bounds__(1024) void bucket_count_kernel(CountArgs a, BucketT
 int bucket_e_size() { return kBktE; }
 int bucket_s_size() { return kBktS; }
 
+static int device_cus()
+{
+  static int cus = 0;
+  if (!cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
+  return cus > 0 ? cus : 256;
+}
+
+static size_t scatter_lds(int nClasses, int nB, int nCells, int per, bool weighted) { return 16 * ((size_t)nClasses + 2) + 32 * (size_t)nB + 8 + (weighted ? 16 : 12) * 1024 * (size_t)per + 2 * ((size_t)nCells + 2) + 16; }
+
+// whether a reference set's tables fit the scatter kernel's LDS at its smallest tile (if not, the search kernel serves)
+bool bucket_tables_fit(int nClasses, int nB, int nCells) { return nB <= 65535 && scatter_lds(nClasses, nB, nCells, 1, true) <= 150 * 1024; }
+
+// The launch geometry of a call of n reads, and what it needs of scratch: blocks that stay (two per CU when the LDS tables
+// allow), an arena per block (its tiles' reads + a chunk per bucket), a directory and a list entry per chunk, the (bucket, block)
+// matrix of chunk counts.
+BucketPlan bucket_plan(i64 n, int nClasses, int nB, int nCells, bool weighted)
+{
+  BucketPlan p;
+  static const int perCu = getenv("GTX_SPLIT_BLOCKS_PER_CU") ? atoi(getenv("GTX_SPLIT_BLOCKS_PER_CU")) : 0;
+  static const int tbMax = getenv("GTX_SPLIT_TILE") ? atoi(getenv("GTX_SPLIT_TILE")) : 4096;
+  p.per = tbMax >= 4096 ? 4 : tbMax >= 2048 ? 2 : 1;
+  while (p.per > 1 && scatter_lds(nClasses, nB, nCells, p.per, weighted) > 150 * 1024) p.per >>= 1;     // (gtx_set_refs keeps nB and the classes within what per = 1 takes)
+  const i64 tb = (i64)p.per * 1024, tiles = (n + tb - 1) / tb;
+  const size_t lds = scatter_lds(nClasses, nB, nCells, p.per, weighted);
+  const int fit = perCu > 0 ? perCu : (2 * (lds + 1024) <= 160 * 1024 ? 2 : 1);
+  const i64 most = (i64)fit * device_cus();
+  p.blocks = (unsigned)(tiles < most ? (tiles > 0 ? tiles : 1) : most);
+  const i64 tilesPerBlock = (tiles + p.blocks - 1) / p.blocks;
+  p.arenaPairs = (size_t)tilesPerBlock * tb + (size_t)nB * kChunk;
+  p.pairs = p.arenaPairs * p.blocks;
+  p.chunks = p.pairs >> kChunkShift;
+  p.matrix = (size_t)nB * p.blocks;
+  return p;
+}
+
 hipError_t launch_count_bucketed(const void *reads, const void *weights, i64 n, const CountArgs &a, const BucketTable &t, const BucketWork &w,
-                                 hipStream_t st)
+                                 const BucketPlan &p, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
-  const size_t ldsHist = sizeof(int) * (2 * (size_t)t.nB + (size_t)a.nClasses + 2);
-  i64 blocks = (n + 1023) / 1024; if (blocks > 2048) blocks = 2048;
-  if (weights) bucket_hist_kernel<true><<<(unsigned)blocks, 1024, ldsHist, st>>>((const Tri3 *)reads, (const int *)weights, n, a, t, w);
-  else bucket_hist_kernel<false><<<(unsigned)blocks, 1024, ldsHist, st>>>((const Tri3 *)reads, (const int *)weights, n, a, t, w);
-  bucket_scan_kernel<<<1, 1024, 0, st>>>(t, w);
-  // tile of the split: as large as the LDS allows next to the per-bucket tables (longer bursts per bucket)
-  const size_t tables = sizeof(int) * (4 * (size_t)t.nB + (size_t)a.nClasses + 4);
-  const size_t perRead = 8 + 2 + (weights ? 4 : 0);
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipSuccess;
-    const void *fn[] = {(const void *)bucket_split_kernel<false, 8192>, (const void *)bucket_split_kernel<true, 8192>, (const void *)bucket_split_kernel<false, 4096>,
-                        (const void *)bucket_split_kernel<true, 4096>, (const void *)bucket_split_kernel<false, 2048>, (const void *)bucket_split_kernel<true, 2048>};
+    const void *fn[] = {(const void *)bucket_scatter_kernel<false, 1>, (const void *)bucket_scatter_kernel<true, 1>, (const void *)bucket_scatter_kernel<false, 4>,
+                        (const void *)bucket_scatter_kernel<true, 4>, (const void *)bucket_scatter_kernel<false, 2>, (const void *)bucket_scatter_kernel<true, 2>};
     for (const void *f : fn) if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  const size_t budget = 150 * 1024;
-  // (100 M shuffled reads, 540 buckets: tile 8192 = 1 block per CU 0.78 ms, 4096 = 3 blocks per CU 0.73 ms, 2048 = 1.37 ms: the bursts
-  // get too short; what the kernel waits for is the chain load -> LDS rank -> barrier -> reservation -> barrier -> copy of ONE tile per
-  // block, so blocks per CU count as much as burst length)
-  static const int tbMax = getenv("GTX_SPLIT_TILE") ? atoi(getenv("GTX_SPLIT_TILE")) : 4096;
-  int tb = tbMax >= 8192 ? 8192 : tbMax >= 4096 ? 4096 : 2048;
-  while (tb > 2048 && tables + (size_t)tb * perRead > budget) tb >>= 1;
-  const size_t ldsSplit = tables + (size_t)tb * perRead + 16;
-  const unsigned sblocks = (unsigned)((n + tb - 1) / tb);
-#define GTX_SPLIT(W, TBV) bucket_split_kernel<W, TBV><<<sblocks, 1024, ldsSplit, st>>>((const Tri3 *)reads, (const int *)weights, n, a, t, w)
-  if (weights) { if (tb == 8192) GTX_SPLIT(true, 8192); else if (tb == 4096) GTX_SPLIT(true, 4096); else GTX_SPLIT(true, 2048); }
-  else { if (tb == 8192) GTX_SPLIT(false, 8192); else if (tb == 4096) GTX_SPLIT(false, 4096); else GTX_SPLIT(false, 2048); }
-#undef GTX_SPLIT
-  // blocks of ~64k reads on average, at least one per bucket
-  static const i64 perBlock = getenv("GTX_COUNT_BLOCK_READS") ? atoll(getenv("GTX_COUNT_BLOCK_READS")) : 65536;   // 16 k: 0.48 ms, 32 k: 0.37, 64 k: 0.34 (table build per block)
+  const size_t lds = scatter_lds(a.nClasses, t.nB, t.nCells, p.per, weights != nullptr);
+#define GTX_SCATTER(W, P) bucket_scatter_kernel<W, P><<<p.blocks, 1024, lds, st>>>((const Tri3 *)reads, (const int *)weights, n, a, t, w)
+  if (weights) { if (p.per == 4) GTX_SCATTER(true, 4); else if (p.per == 2) GTX_SCATTER(true, 2); else GTX_SCATTER(true, 1); }
+  else { if (p.per == 4) GTX_SCATTER(false, 4); else if (p.per == 2) GTX_SCATTER(false, 2); else GTX_SCATTER(false, 1); }
+#undef GTX_SCATTER
+  chunk_rows_kernel<<<(unsigned)t.nB, 256, 0, st>>>(w, p.blocks);
+  chunk_offsets_kernel<<<1, 1024, 0, st>>>(w, t.nB);
+  chunk_place_kernel<<<p.blocks, 1024, sizeof(unsigned) * (size_t)t.nB, st>>>(t, w, p.blocks);
+  // blocks of ~128k reads on average, at least one per bucket (100 M reads, whole path: 32 k 1.17 ms, 64 k 1.12, 128 k 1.085, 256 k 1.10:
+  // the tables are built per block)
+  static const i64 perBlock = getenv("GTX_COUNT_BLOCK_READS") ? atoll(getenv("GTX_COUNT_BLOCK_READS")) : 131072;
   i64 splits = (n + (i64)t.nB * perBlock - 1) / ((i64)t.nB * perBlock);
   if (splits < 1) splits = 1;
   if (splits > 512) splits = 512;

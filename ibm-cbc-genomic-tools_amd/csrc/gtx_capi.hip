@@ -32,8 +32,9 @@ struct gtx_ctx {
   int *d_sampE = nullptr, *d_sampS = nullptr; int sampShift = 6, nSamp = 0;   // top level of the search kernel
   int *d_topE = nullptr, *d_topS = nullptr;   // every 256th boundary: first hop of the streaming kernel's start-of-span search
   // unsorted reads, bucket path (gtx_bucket.hip): table built with the references, scratch sized by the largest call
+  void *d_clsCell = nullptr, *d_cellTab = nullptr; int nCells = 0, cellShift = 0;   // direct-address bucket lookup (BucketTable)
   int *d_bkt = nullptr; int nB = 0;                  // posHi | eLo | eHi | sLo | sHi | cls (nB each) | clsStart (nClasses+1)
-  unsigned *d_bktCnt = nullptr;                      // count | offset (nB+1) | cursor
+  unsigned *d_bktCnt = nullptr, *d_bktDir = nullptr; size_t capBktMatrix = 0;   // scratch of the bucket path (gtx::BucketWork)
   void *d_bktReads = nullptr; int *d_bktWeights = nullptr; size_t capBkt = 0;
   int64_t bucketMinReads = 1 << 18;                  // below this the per-read search kernel is used (GTX_BUCKET_MIN_READS)
   int *d_posE = nullptr, *d_posS = nullptr, *d_classBase = nullptr;
@@ -152,7 +153,7 @@ void gtx_destroy(gtx_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
-  dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_bktCnt);
+  dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   for (int k = 0; k < 2; k++) {
@@ -257,7 +258,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   }
 
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
-  dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_bktCnt);
+  dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab);
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB);
   c->nRefs = -1;
   const int64_t histLen = nv + nClasses;
@@ -318,14 +319,47 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
     }
     clsStart[nClasses] = (int32_t)posHi.size();
     c->nB = (int)posHi.size();
-    if (c->nB > 6144) c->nB = 0;                                   // too many buckets for the LDS tables of the split kernel (16 B per bucket): the search kernel serves
+    if (c->nB > 8192 || nClasses > 2048) c->nB = 0;               // (certainly too many for the LDS tables of the scatter kernel; the exact test follows)
+    std::vector<int32_t> clsCell(4 * (size_t)nClasses);
+    std::vector<uint16_t> cellTab;
     if (c->nB > 0) {
+      // cells over the span of each class's cuts: the shift that keeps all classes within kCells cells
+      const int kCells = 4096;
+      int sh = 0;
+      auto cellsAt = [&](int shift) {
+        int64_t total = 0;
+        for (int cl = 0; cl < nClasses; cl++) {
+          const int b0 = clsStart[cl], b1 = clsStart[cl + 1];
+          total += b1 - b0 <= 1 ? b1 - b0 : ((((int64_t)posHi[b1 - 2] - posHi[b0]) >> shift) + 1);
+        }
+        return total;
+      };
+      while (sh < 40 && cellsAt(sh) > kCells) sh++;
+      for (int cl = 0; cl < nClasses; cl++) {
+        const int b0 = clsStart[cl], b1 = clsStart[cl + 1];
+        const int32_t lo = b1 - b0 <= 1 ? 0 : posHi[b0];
+        const int64_t nc = b1 == b0 ? 0 : b1 - b0 == 1 ? 1 : ((((int64_t)posHi[b1 - 2] - lo) >> sh) + 1);   // 0 cells: a class without reference regions
+        clsCell[4 * cl] = (int32_t)cellTab.size(); clsCell[4 * cl + 1] = lo; clsCell[4 * cl + 2] = (int32_t)nc; clsCell[4 * cl + 3] = b0;
+        int b = b0;
+        for (int64_t k = 0; k < nc; k++) {
+          const int64_t first = (int64_t)lo + (k << sh);
+          while (b < b1 - 1 && (int64_t)posHi[b] < first) b++;
+          cellTab.push_back((uint16_t)(b - b0));                   // relative to the class's first bucket
+        }
+      }
+      c->nCells = (int)cellTab.size(); c->cellShift = sh;
+      if (!gtx::bucket_tables_fit(nClasses, c->nB, c->nCells)) c->nB = 0;     // 32 B per bucket, 16 per class: the search kernel serves
+    }
+    if (c->nB > 0) {
+      cellTab.push_back(0);
+      HIPCHK(c, hipMalloc(&c->d_clsCell, sizeof(int32_t) * clsCell.size() + 16));
+      HIPCHK(c, hipMemcpy(c->d_clsCell, clsCell.data(), sizeof(int32_t) * clsCell.size(), hipMemcpyHostToDevice));
+      HIPCHK(c, hipMalloc(&c->d_cellTab, sizeof(uint16_t) * cellTab.size()));
+      HIPCHK(c, hipMemcpy(c->d_cellTab, cellTab.data(), sizeof(uint16_t) * cellTab.size(), hipMemcpyHostToDevice));
       std::vector<int32_t> all;
       for (auto *v : {&posHi, &eLo, &eHi, &sLo, &sHi, &cls, &clsStart}) all.insert(all.end(), v->begin(), v->end());
       HIPCHK(c, hipMalloc(&c->d_bkt, sizeof(int32_t) * all.size()));
       HIPCHK(c, hipMemcpy(c->d_bkt, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice));
-      HIPCHK(c, hipMalloc(&c->d_bktCnt, sizeof(unsigned) * (3 * (size_t)c->nB + 4)));
-      HIPCHK(c, hipMemset(c->d_bktCnt, 0, sizeof(unsigned) * (3 * (size_t)c->nB + 4)));
     }
   }
   if (m > 0) {
@@ -402,20 +436,30 @@ static int launch_unsorted(gtx_ctx *c, const void *d_reads, const void *d_weight
     HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, a, false, c->stream));
     return GTX_OK;
   }
-  if ((size_t)n > c->capBkt) {
-    dfree(c->d_bktReads); dfree(c->d_bktWeights); c->capBkt = 0;
-    HIPCHK(c, hipMalloc(&c->d_bktReads, 8 * (size_t)n));
-    HIPCHK(c, hipMalloc(&c->d_bktWeights, 4 * (size_t)n));
-    c->capBkt = (size_t)n;
+  const gtx::BucketPlan p = gtx::bucket_plan(n, a.nClasses, c->nB, c->nCells, d_weights != nullptr);
+  if (p.pairs >= (1ull << 32)) { HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, a, false, c->stream)); return GTX_OK; }
+  if (p.pairs > c->capBkt) {
+    dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); c->capBkt = 0;
+    HIPCHK(c, hipMalloc(&c->d_bktReads, 8 * p.pairs));
+    HIPCHK(c, hipMalloc(&c->d_bktWeights, 4 * p.pairs));
+    HIPCHK(c, hipMalloc(&c->d_bktDir, 4 * 2 * p.chunks));             // directory | list
+    c->capBkt = p.pairs;
+  }
+  const size_t words = p.matrix + p.blocks + (size_t)c->nB + 1;     // chunkCount | arenaUsed | rowOff
+  if (words > c->capBktMatrix) {
+    dfree(c->d_bktCnt); c->capBktMatrix = 0;
+    HIPCHK(c, hipMalloc(&c->d_bktCnt, 4 * words));
+    c->capBktMatrix = words;
   }
   gtx::BucketTable t;
   const int nB = c->nB;
   t.posHi = c->d_bkt; t.eLo = c->d_bkt + nB; t.eHi = c->d_bkt + 2 * nB; t.sLo = c->d_bkt + 3 * nB; t.sHi = c->d_bkt + 4 * nB;
   t.cls = c->d_bkt + 5 * nB; t.clsStart = c->d_bkt + 6 * nB; t.nB = nB;
+  t.clsCell = (const int4 *)c->d_clsCell; t.cellTab = (const unsigned short *)c->d_cellTab; t.nCells = c->nCells; t.cellShift = c->cellShift;
   gtx::BucketWork w;
-  w.count = c->d_bktCnt; w.offset = c->d_bktCnt + nB; w.cursor = c->d_bktCnt + 2 * nB + 1;
-  w.tmpReads = c->d_bktReads; w.tmpWeights = c->d_bktWeights;
-  HIPCHK(c, gtx::launch_count_bucketed(d_reads, d_weights, n, a, t, w, c->stream));
+  w.tmpReads = c->d_bktReads; w.tmpWeights = c->d_bktWeights; w.arenaPairs = (unsigned)p.arenaPairs;
+  w.dir = c->d_bktDir; w.list = c->d_bktDir + c->capBkt / 64; w.chunkCount = c->d_bktCnt; w.arenaUsed = c->d_bktCnt + p.matrix; w.rowOff = w.arenaUsed + p.blocks;
+  HIPCHK(c, gtx::launch_count_bucketed(d_reads, d_weights, n, a, t, w, p, c->stream));
   return GTX_OK;
 }
 

@@ -85,17 +85,28 @@ struct BucketTable {               // built by gtx_set_refs; a bucket = <= bucke
   const int *cls;                  // [nB]
   const int *clsStart;             // [nClasses+1] buckets of each class
   int nB;
+  // direct-address lookup of a read's bucket: per class {first cell, lowest cut, cells, first bucket}; a cell is 2^cellShift
+  // positions wide; cellTab[cell] = first bucket of the class whose posHi is not below the cell's first position
+  const int4 *clsCell;             // [nClasses]
+  const unsigned short *cellTab;   // [nCells]
+  int nCells, cellShift;
 };
-struct BucketWork {                // scratch of one call
-  unsigned *count;                 // [nB] reads per bucket (zero between calls)
-  unsigned *offset;                // [nB+1]
-  unsigned *cursor;                // [nB]
-  void *tmpReads; int *tmpWeights; // [n] the reads grouped by bucket
+struct BucketWork {                // scratch of one call (sizes: bucket_plan)
+  void *tmpReads; int *tmpWeights; // [pairs] (start, end) [, weight] of the reads, in chunks of 64 of one bucket; an arena per block
+  unsigned arenaPairs;             // pairs per arena
+  unsigned *dir;                   // [chunks] chunk -> bucket | fill << 16
+  unsigned *list;                  // [chunks] the chunks bucket by bucket: chunk << 6 | (fill - 1)
+  unsigned *chunkCount;            // [nB * blocks] chunks of bucket b in arena k, then their exclusive prefix inside the bucket's row
+  unsigned *rowOff;                // [nB + 1] first list entry of every bucket
+  unsigned *arenaUsed;             // [blocks] chunks dealt out
 };
+struct BucketPlan { int per; unsigned blocks; size_t arenaPairs, pairs, chunks, matrix; };
+BucketPlan bucket_plan(long long n, int nClasses, int nB, int nCells, bool weighted);
+bool bucket_tables_fit(int nClasses, int nB, int nCells);
 int bucket_e_size();
 int bucket_s_size();
 hipError_t launch_count_bucketed(const void *reads, const void *weights, long long n, const CountArgs &a, const BucketTable &t,
-                                 const BucketWork &w, hipStream_t st);
+                                 const BucketWork &w, const BucketPlan &p, hipStream_t st);
 
 // ---- intervals the rank difference does not cover (gtx_special.hip): plain pair tests, reference semantics of the sorted merge
 // value of a matching pair: mode 0 = w (count), mode 2 = w x (min(ends) - max(starts) + 1), the unclamped -gaps formula of

@@ -8,6 +8,7 @@ from gtx import synth
 from bench import make_reads_on_device
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 dev = torch.device("cuda", 0)
+if os.environ.get("GTX_X_LIB"): gtx.LIB_PATH = os.environ["GTX_X_LIB"]     # (kernel experiments: a variant build)
 eng = gtx.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream); eng.profile(True)
 reads = make_reads_on_device(n, np.arange(24), 1000, dev)
 reads = reads[torch.randperm(n, device=dev)]

@@ -1,11 +1,14 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r02_bucket; mkdir -p $out
-run() { tag=$1; shift; env "$@" timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$tag -- python3 scripts/bench_bucket.py > $out/bench_$tag.log 2>&1; grep "bucket path" $out/bench_$tag.log; python3 - <<PY
-import csv,glob
-f=glob.glob('$out/stats_$tag/*/*kernel_stats.csv')[0]
-print('$tag', ' '.join('%s=%.3f' % (r['Name'].split('(')[0].split('::')[-1].split('<')[0], float(r['AverageNs'])/1e6) for r in csv.DictReader(open(f)) if 'bucket_' in r['Name']))
+timeout -k 10 600 python3 -m pytest tests/test_gpu_bucket.py tests/test_gpu_fuzz.py -m gpu -x -q > $out/pytest.log 2>&1; rc=$?; tail -4 $out/pytest.log
+[ $rc -eq 0 ] || exit 1
+for r in 32768 65536 131072 262144; do
+  echo "count block reads $r: $(GTX_COUNT_BLOCK_READS=$r timeout -k 10 200 python3 scripts/bench_bucket.py 2>&1 | tail -1)"
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats4 -- python3 scripts/bench_bucket.py > $out/bench.log 2>&1
+f=$(ls -t $out/stats4/*/*kernel_stats.csv | head -1); python3 - $f <<'PY'
+import csv,sys
+for x in csv.DictReader(open(sys.argv[1])):
+    if 'gtx::' in x['Name']: print(x['Name'].split('(')[0][:60], x['Calls'], '%.4f ms' % (float(x['AverageNs'])/1e6))
 PY
-}
-run noatomic GTX_READS_PER_LANE=77
-run noatomic4k GTX_READS_PER_LANE=77 GTX_SPLIT_TILE=4096

@@ -125,3 +125,36 @@ def test_thousands_of_buckets_and_extreme_ends(beng):
     w = rng.integers(0, 4, size=len(reads)).astype(np.int32)
     check(beng, refs, reads, synth.n_classes())
     check(beng, refs, reads, synth.n_classes(), w)
+
+
+def test_reads_in_runs_and_in_stripes(beng):
+    # the scatter pass deals every block's arena out in chunks of 64 pairs per bucket (bucket_scatter_kernel): reads that alternate
+    # between two chromosomes in stripes of 64, and the same reads sorted (a bucket's reads are one stretch of the stream: whole tiles
+    # go to one bucket, 64 new chunks at a time)
+    rng = np.random.default_rng(77)
+    refs = synth.genome_intervals(200_000, 9, 50, 2000)
+    refs = refs[refs[:, 0] < 2]
+    n = 64 * 16 * 400
+    unit = np.arange(n) // 64
+    cls = np.where(unit % 16 == 0, 0, 1)
+    qs = rng.integers(1, 150_000_000, size=n)
+    reads = np.stack([cls, qs, qs + 35], axis=1).astype(np.int32)
+    check(beng, refs, reads, 2)
+    w = rng.integers(-1, 5, size=n).astype(np.int32)
+    check(beng, refs, reads, 2, w)
+    srt = reads[np.lexsort((reads[:, 1], reads[:, 0]))]
+    check(beng, refs, srt, 2)
+    check(beng, refs, srt, 2, w)
+
+
+def test_more_classes_than_the_lookup_tables_take(beng):
+    # 3000 classes: the scatter kernel's LDS tables (16 B per class) do not take them and the per-read search kernel serves
+    rng = np.random.default_rng(91)
+    n_classes, m, n = 3000, 20_000, 50_000
+    rc = np.sort(rng.integers(0, n_classes, size=m))
+    rs = rng.integers(1, 100_000, size=m)
+    refs = np.stack([rc, rs, rs + rng.integers(0, 500, size=m)], axis=1).astype(np.int32)
+    refs = refs[np.lexsort((refs[:, 1], refs[:, 0]))]
+    qs = rng.integers(1, 100_000, size=n)
+    reads = np.stack([rng.integers(0, n_classes + 5, size=n), qs, qs + rng.integers(0, 300, size=n)], axis=1).astype(np.int32)
+    check(beng, refs, reads, n_classes)
