@@ -70,7 +70,7 @@ pmc_json(R + "profiles/%s_pmc_count_walk.json" % rnd, "count_walk_kernel<false,4
          "100 M reads x 1 M regions, bench.py default workload")
 pmc_json(R + "profiles/%s_pmc_coverage_walk.json" % rnd, "coverage_walk_kernel<false>", "coverage_walk_kernel", "cov_fetch", "cov_write", (), 1.2e9,
          "100 M reads x 1 M regions, tests/tools/bench_coverage.py")
-for k, alg, note in (("bucket_hist_kernel", 1.2e9, "reads once"), ("bucket_split_kernel", 2.0e9, "reads once + (start, end) pairs written once"),
+for k, alg, note in (("bucket_scatter_kernel", 2.0e9, "reads once + (start, end) pairs written once"),
                      ("bucket_count_kernel", 0.8e9, "(start, end) pairs read once")):
     pmc_json(R + "profiles/%s_pmc_%s.json" % (rnd, k), k, k, "bucket_fetch", "bucket_write", (), alg, "100 M shuffled reads x 1 M regions, scripts/bench_bucket.py; " + note)
 # perm: per batch TWO launches of perm_stat_kernel (row-range parts): per-launch means are doubled to give the traffic of a 10 k-shuffle batch
