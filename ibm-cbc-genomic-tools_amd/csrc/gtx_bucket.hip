@@ -118,7 +118,7 @@ __global__ __launch_bounds__(1024, 8) void bucket_scatter_kernel(const Tri3 *__r
   const unsigned arena0 = blockIdx.x * w.arenaPairs;               // this block's part of the scratch array
   const int4 nullEntry = make_int4(t.nCells, INT_MAX, 0, nB);       // (bucket_lookup)
   for (int i = threadIdx.x; i < nB; i += 1024) { posHi[i] = t.posHi[i]; cnt[i] = 0; next[i] = 0; nch[i] = 0; }   // next = 0: no chunk yet, no room
-  for (int i = threadIdx.x; i < a.nClasses; i += 1024) { int4 e = t.clsCell[i]; e.z -= 1; clsCell[i] = e.z < 0 ? nullEntry : e; }
+  for (int i = threadIdx.x; i < a.nClasses; i += 1024) { const int4 e = t.clsCell[i]; const bool none = e.z <= 0; clsCell[i] = make_int4(none ? nullEntry.x : e.x, none ? nullEntry.y : e.y, none ? 0 : e.z - 1, none ? nullEntry.w : e.w); }
   for (int i = threadIdx.x; i < t.nCells; i += 1024) tab[i] = t.cellTab[i];
   if (threadIdx.x == 0) { arenaCur = arena0; tileCur[0] = tileCur[1] = 0; clsCell[a.nClasses] = nullEntry; tab[t.nCells] = 0; posHi[nB] = INT_MAX; cnt[nB] = 0; }
   // (this path takes n < 2^31: 32-bit indices)
