@@ -104,9 +104,10 @@ __device__ __forceinline__ unsigned wave_prefix(unsigned x)
 // ranks beyond, L = first place in the staged tile}; the tile regrouped by bucket: (start, end, place in the scratch array,
 // weight) per read, an array each -- neighbours in a bucket are neighbours in LDS and in the scratch array, so the copy out of LDS stores runs of
 // pairs (one 64-byte request per ~8 pairs; storing the pairs straight from the registers of the threads that loaded them is a
-// request per pair, and ~2e11 requests/s is what the L2 takes: 0.75 ms per 100 M reads against 0.4x here).
+// request per pair: no faster when a tile's pairs of a bucket still leave together, 1.8x slower when they leave one by one).
+// (launch bounds: weighted tiles of 4096 reads are one block per CU by LDS anyway)
 template <bool WEIGHTED, int PER>
-__global__ __launch_bounds__(1024, 8) void bucket_scatter_kernel(const Tri3 *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a, BucketTable t, BucketWork w)
+__global__ __launch_bounds__(1024, (WEIGHTED && PER == 4) ? 4 : 8) void bucket_scatter_kernel(const Tri3 *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a, BucketTable t, BucketWork w)
 {
   constexpr int TB = PER * 1024;
   extern __shared__ int4 lds4[];
