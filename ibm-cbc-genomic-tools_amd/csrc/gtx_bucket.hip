@@ -171,6 +171,7 @@ __global__ __launch_bounds__(1024, (WEIGHTED && PER == 4) ? 4 : 8) void bucket_s
     // per bucket present: room in its chunk or new chunks from the arena, and its stretch of the staged tile
     if (threadIdx.x == 0) { tileCur[parity ^ 1] = 0; cnt[nB] = 0; }
     for (int b0 = 0; b0 < nB; b0 += 1024) {
+      if (b0 + (int)(threadIdx.x & ~63u) >= nB) continue;          // (a whole wave without buckets: 7 of 16 at 540 buckets)
       const int b = b0 + threadIdx.x;
       const unsigned c = b < nB ? cnt[b] : 0u;
       const unsigned A = b < nB ? next[b] : 0u, room = (0u - A) & (kChunk - 1);
