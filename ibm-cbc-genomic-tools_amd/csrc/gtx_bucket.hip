@@ -83,7 +83,11 @@ __device__ __forceinline__ void bucket_lookup(const int4 *__restrict__ clsCell, 
 #pragma unroll
   for (int k = 0; k < N; k++) ph[k] = posHi[id[k]];
 #pragma unroll
-  for (int k = 0; k < N; k++) while (s[k] > ph[k]) ph[k] = posHi[++id[k]];              // the class's last bucket has posHi = INT_MAX
+  for (int k = 0; k < N; k++) id[k] += s[k] > ph[k];                                      // the first step upwards for all of them together
+#pragma unroll
+  for (int k = 0; k < N; k++) ph[k] = posHi[id[k]];
+#pragma unroll
+  for (int k = 0; k < N; k++) while (s[k] > ph[k]) ph[k] = posHi[++id[k]];              // (two cuts inside one cell: rare.  The class's last bucket has posHi = INT_MAX)
 }
 
 // inclusive prefix sum over the 64 lanes by DPP (row shifts, then row broadcasts); call with all lanes active
@@ -179,9 +183,12 @@ __global__ __launch_bounds__(1024, (WEIGHTED && PER == 4) ? 4 : 8) void bucket_s
       // of the arena) by wave prefix and one LDS atomic per wave
       const unsigned need = c > room ? c - room : 0u, fresh = (need + kChunk - 1) & ~(unsigned)(kChunk - 1);
       const unsigned incL = wave_prefix(c), incF = wave_prefix(fresh);
+      const unsigned totL = (unsigned)__builtin_amdgcn_readlane((int)incL, 63), totF = (unsigned)__builtin_amdgcn_readlane((int)incF, 63);
       unsigned baseL = 0, baseF = 0;
-      if (lane == 63 && incL) { baseL = atomicAdd(&tileCur[parity], incL); if (incF) baseF = atomicAdd(&arenaCur, incF); }
-      baseL = (unsigned)__builtin_amdgcn_readlane((int)baseL, 63); baseF = (unsigned)__builtin_amdgcn_readlane((int)baseF, 63);
+      if (totL) {                                                     // (wave-uniform; the sums are scalars: one lane adds them)
+        if (lane == 0) { baseL = atomicAdd(&tileCur[parity], totL); if (totF) baseF = atomicAdd(&arenaCur, totF); }
+        baseL = (unsigned)__builtin_amdgcn_readfirstlane((int)baseL); baseF = (unsigned)__builtin_amdgcn_readfirstlane((int)baseF);
+      }
       if (c) {
         const unsigned at = baseF + incF - fresh;
         cnt[b] = 0; next[b] = need ? at + need : A + c;
@@ -273,10 +280,22 @@ __global__ __launch_bounds__(1024) void chunk_place_kernel(BucketTable t, Bucket
   for (int i = threadIdx.x; i < t.nB; i += blockDim.x) seen[i] = 0;
   __syncthreads();
   const unsigned k = blockIdx.x, first = k * (w.arenaPairs >> kChunkShift), used = w.arenaUsed[k];
-  for (unsigned j = threadIdx.x; j < used; j += blockDim.x) {
-    const unsigned d = w.dir[first + j], b = d & 0xffffu, fill = d >> 16;
-    const unsigned r = atomicAdd(&seen[b], 1u);
-    w.list[w.rowOff[b] + w.chunkCount[(size_t)b * nArenas + k] + r] = ((first + j) << kChunkShift) | (fill - 1);
+  constexpr int U = 4;                                             // entries per thread and round: their loads together
+  for (unsigned j0 = threadIdx.x; j0 < used; j0 += U * blockDim.x) {
+    unsigned d[U], at[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const unsigned j = j0 + u * blockDim.x; d[u] = j < used ? w.dir[first + j] : 0u; }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const unsigned j = j0 + u * blockDim.x, b = d[u] & 0xffffu;
+      at[u] = 0;
+      if (j < used) at[u] = w.rowOff[b] + w.chunkCount[(size_t)b * nArenas + k] + atomicAdd(&seen[b], 1u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const unsigned j = j0 + u * blockDim.x;
+      if (j < used) w.list[at[u]] = ((first + j) << kChunkShift) | ((d[u] >> 16) - 1);
+    }
   }
 }
 
@@ -453,7 +472,7 @@ hipError_t launch_count_bucketed(const void *reads, const void *weights, i64 n, 
   else { if (p.per == 4) GTX_SCATTER(false, 4); else if (p.per == 2) GTX_SCATTER(false, 2); else GTX_SCATTER(false, 1); }
 #undef GTX_SCATTER
   chunk_rows_kernel<<<(unsigned)t.nB, 256, 0, st>>>(w, p.blocks);
-  chunk_offsets_kernel<<<1, 1024, 0, st>>>(w, t.nB);
+  chunk_offsets_kernel<<<1, 1024, 0, st>>>(w, t.nB);     // (one more launch: the block of chunk_rows_kernel that finishes last doing it was slower, 540 blocks adding to one counter)
   chunk_place_kernel<<<p.blocks, 1024, sizeof(unsigned) * (size_t)t.nB, st>>>(t, w, p.blocks);
   // blocks of ~128k reads on average, at least one per bucket (100 M reads, whole path: 32 k 1.17 ms, 64 k 1.12, 128 k 1.085, 256 k 1.10:
   // the tables are built per block)
