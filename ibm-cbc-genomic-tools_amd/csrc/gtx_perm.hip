@@ -220,6 +220,7 @@ enum { MODE_STAT = 0, MODE_GE = 1, MODE_RANK = 2 };
 
 struct StatArgs {
   const i64 *colPtr; const int32_t *rows;
+  const uint32_t *rows16;         // the same lists as 16-bit row ids, two per word (tables of <= 65536 rows): half the bytes that compete with the slab rows for the L2
   const float *Vp, *Vtp;          // slab(s) in the tile layout above, or (MODE_STAT) the plain value vectors
   i64 nCols, nPerm;               // permutations in this batch
   StatConsts k;
@@ -236,7 +237,7 @@ struct StatArgs {
 
 constexpr int kWavesPerBlock = 4;
 
-template <int STAT, bool TOTALS, bool HASVT, int MODE>
+template <int STAT, bool TOTALS, bool HASVT, int MODE, bool ROWS16>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void perm_stat_kernel(StatArgs a)
 {
   // Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8), and every XCD has its own
@@ -272,30 +273,50 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void perm_stat_kernel(StatArgs
   if (a.nParts > 1 && a.part > 0) {
     u64 w[kAccWords];
 #pragma unroll
-    for (int f = 0; f < kAccWords; f++) w[f] = accAt[(size_t)f * 64];
+    for (int f = 0; f < kAccWords; f++) w[f] = __builtin_nontemporal_load(accAt + (size_t)f * 64);   // (streamed once: not to displace the slab rows in the L2)
     __builtin_memcpy((void *)&acc, w, 8 * kAccWords);
   }
   i64 z = z0;
+  // one member: its row id from the 32-bit list or from the packed 16-bit one (z is wave-uniform: scalar loads and shifts)
+  auto row_at = [&](i64 q) -> uint32_t {
+    if constexpr (ROWS16) { const uint32_t w = a.rows16[q >> 1]; return (q & 1) ? w >> 16 : w & 0xffffu; }
+    else return (uint32_t)a.rows[q];
+  };
+  if constexpr (ROWS16) {
+    if ((z & 1) && z < z1) {                                        // up to an even member: the packed words are read whole from here on
+      const uint32_t off = (row_at(z) << kRowShift) + laneOff;
+      acc.add(*(const float *)(vp + off), HASVT ? *(const float *)(vtp + off) : 1.0f);
+      z++;
+    }
+  }
   // 8 gathers in flight, accumulated in list order
   for (; z + 8 <= z1; z += 8) {
     float v[8], vt[8];
+    uint32_t r[8];
+    if constexpr (ROWS16) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const uint32_t w = a.rows16[(z >> 1) + u]; r[2 * u] = w & 0xffffu; r[2 * u + 1] = w >> 16; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; u++) r[u] = (uint32_t)a.rows[z + u];
+    }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const uint32_t off = ((uint32_t)a.rows[z + u] << kRowShift) + laneOff;
+      const uint32_t off = (r[u] << kRowShift) + laneOff;
       v[u] = *(const float *)(vp + off); vt[u] = HASVT ? *(const float *)(vtp + off) : 1.0f;
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) acc.add(v[u], vt[u]);
   }
   for (; z < z1; z++) {
-    const uint32_t off = ((uint32_t)a.rows[z] << kRowShift) + laneOff;
+    const uint32_t off = (row_at(z) << kRowShift) + laneOff;
     acc.add(*(const float *)(vp + off), HASVT ? *(const float *)(vtp + off) : 1.0f);
   }
   if (a.nParts > 1 && a.part + 1 < a.nParts) {                     // not the last range: hand the accumulators on
     u64 w[kAccWords];
     __builtin_memcpy(w, (const void *)&acc, 8 * kAccWords);
 #pragma unroll
-    for (int f = 0; f < kAccWords; f++) accAt[(size_t)f * 64] = w[f];
+    for (int f = 0; f < kAccWords; f++) __builtin_nontemporal_store(w[f], accAt + (size_t)f * 64);
     return;
   }
   const i64 nc = a.colPtr[c + 1] - a.colPtr[c];
@@ -318,9 +339,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void perm_stat_kernel(StatArgs
 template <int STAT, bool TOTALS, bool HASVT>
 hipError_t launch_stat_mode(int mode, const StatArgs &a, unsigned grid, hipStream_t st)
 {
-  if (mode == MODE_STAT) perm_stat_kernel<STAT, TOTALS, HASVT, MODE_STAT><<<grid, 64 * kWavesPerBlock, 0, st>>>(a);
-  else if (mode == MODE_GE) perm_stat_kernel<STAT, TOTALS, HASVT, MODE_GE><<<grid, 64 * kWavesPerBlock, 0, st>>>(a);
-  else if constexpr (STAT == GTX_STAT_N) perm_stat_kernel<STAT, TOTALS, HASVT, MODE_RANK><<<grid, 64 * kWavesPerBlock, 0, st>>>(a);
+#define GTX_STAT(M) do { if (a.rows16) perm_stat_kernel<STAT, TOTALS, HASVT, M, true><<<grid, 64 * kWavesPerBlock, 0, st>>>(a); \
+                         else perm_stat_kernel<STAT, TOTALS, HASVT, M, false><<<grid, 64 * kWavesPerBlock, 0, st>>>(a); } while (0)
+  if (mode == MODE_STAT) GTX_STAT(MODE_STAT);
+  else if (mode == MODE_GE) GTX_STAT(MODE_GE);
+  else if constexpr (STAT == GTX_STAT_N) GTX_STAT(MODE_RANK);
+#undef GTX_STAT
   return hipGetLastError();
 }
 
@@ -370,7 +394,7 @@ struct gtx_perm {
   bool useTotals = false, hasVt = false;
   double sums[4] = {0, 0, 0, 0};
   i64 tPos = 0, tNeg = 0;
-  float *d_V = nullptr, *d_Vt = nullptr; i64 *d_colPtr = nullptr; int32_t *d_rows = nullptr;
+  float *d_V = nullptr, *d_Vt = nullptr; i64 *d_colPtr = nullptr; int32_t *d_rows = nullptr; uint32_t *d_rows16 = nullptr;
   float *d_Vp = nullptr, *d_Vtp = nullptr; size_t capSlab = 0;     // floats per slab
   int nParts = 1; i64 *d_colSplit = nullptr; u64 *d_accBuf = nullptr; size_t capAcc = 0;   // row-range parts of the stat kernel
   bool rowsAscending = true; std::vector<i64> h_colPtr; std::vector<int32_t> h_rows; int splitParts = 0;
@@ -406,7 +430,7 @@ void gtx_perm_destroy(gtx_perm *p)
 {
   if (!p) return;
   (void)hipSetDevice(p->device);
-  dfree(p->d_V); dfree(p->d_Vt); dfree(p->d_colPtr); dfree(p->d_rows); dfree(p->d_Vp); dfree(p->d_Vtp);
+  dfree(p->d_V); dfree(p->d_Vt); dfree(p->d_colPtr); dfree(p->d_rows); dfree(p->d_rows16); dfree(p->d_Vp); dfree(p->d_Vtp);
   dfree(p->d_Y); dfree(p->d_counts); dfree(p->d_tabPtr); dfree(p->d_tab); dfree(p->d_sortedY); dfree(p->d_colSplit); dfree(p->d_accBuf);
   for (auto &e : p->ev) if (e) (void)hipEventDestroy(e);
   delete p;
@@ -426,7 +450,7 @@ int gtx_perm_set_table(gtx_perm *p, int64_t n_rows, int64_t n_cols, const int64_
   for (i64 z = 0; z < nnz; z++) if (rows[z] < 0 || rows[z] >= n_rows) return pfail(p, GTX_E_RANGE, "gtx_perm_set_table: row id out of range");
   PCHK(p, hipSetDevice(p->device));
   p->nRows = -1;
-  dfree(p->d_V); dfree(p->d_Vt); dfree(p->d_colPtr); dfree(p->d_rows); dfree(p->d_Y); dfree(p->d_counts);
+  dfree(p->d_V); dfree(p->d_Vt); dfree(p->d_colPtr); dfree(p->d_rows); dfree(p->d_rows16); dfree(p->d_Y); dfree(p->d_counts);
   PCHK(p, hipMalloc(&p->d_V, sizeof(float) * n_rows));
   PCHK(p, hipMemcpy(p->d_V, V, sizeof(float) * n_rows, hipMemcpyHostToDevice));
   p->hasVt = Vtotal != nullptr;
@@ -435,6 +459,12 @@ int gtx_perm_set_table(gtx_perm *p, int64_t n_rows, int64_t n_cols, const int64_
   PCHK(p, hipMemcpy(p->d_colPtr, col_ptr, sizeof(i64) * (n_cols + 1), hipMemcpyHostToDevice));
   PCHK(p, hipMalloc(&p->d_rows, sizeof(int32_t) * (nnz + 1)));
   if (nnz) PCHK(p, hipMemcpy(p->d_rows, rows, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+  if (n_rows <= 65536 && !(getenv("GTX_PERM_ROWS32") && atoi(getenv("GTX_PERM_ROWS32")))) {      // the lists once more, two row ids per word
+    std::vector<uint32_t> packed((size_t)(nnz + 1) / 2 + 4, 0u);
+    for (i64 z = 0; z < nnz; z++) packed[(size_t)z >> 1] |= (uint32_t)rows[z] << ((z & 1) * 16);
+    PCHK(p, hipMalloc(&p->d_rows16, sizeof(uint32_t) * packed.size()));
+    PCHK(p, hipMemcpy(p->d_rows16, packed.data(), sizeof(uint32_t) * packed.size(), hipMemcpyHostToDevice));
+  }
   PCHK(p, hipMalloc(&p->d_Y, sizeof(double) * (n_cols + 1)));
   PCHK(p, hipMalloc(&p->d_counts, sizeof(u64) * (n_cols + 1)));
   p->tPos = p->tNeg = 0;
@@ -452,7 +482,7 @@ int gtx_perm_set_table(gtx_perm *p, int64_t n_rows, int64_t n_cols, const int64_
 static StatArgs base_args(gtx_perm *p, int under)
 {
   StatArgs a = {};
-  a.colPtr = p->d_colPtr; a.rows = p->d_rows; a.nCols = p->nCols;
+  a.colPtr = p->d_colPtr; a.rows = p->d_rows; a.rows16 = p->d_rows16; a.nCols = p->nCols;
   a.k.Vsum = p->sums[0]; a.k.VsumZ = p->sums[1]; a.k.Vsum2 = p->sums[2]; a.k.VtotalSum = p->sums[3];
   a.k.nRows = p->nRows; a.k.under = under ? 1 : 0; a.k.tAll = under ? p->tNeg : p->tPos;
   a.colBlocks = (p->nCols + kWavesPerBlock - 1) / kWavesPerBlock;

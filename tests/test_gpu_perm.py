@@ -253,3 +253,30 @@ def test_row_range_parts_keep_every_bit(pe, monkeypatch, l2_mb):
     k = porc.statistic(t3, "n", False).astype(np.int64)
     sorted_y = np.sort(tab[tab_ptr[:-1] + k], kind="stable")
     np.testing.assert_array_equal(pe.count_rank(tab_ptr, tab, sorted_y, 17, 0, 300, False), porc.count_rank(t3, tab_ptr, tab, sorted_y, 17, 0, 300, False))
+
+
+@pytest.mark.parametrize("rows32", ["0", "1"])
+def test_packed_and_plain_membership_lists(pe, monkeypatch, rows32):
+    """Tables of <= 65536 rows keep their membership lists as 16-bit row ids, two per word (half the bytes next to the slab rows in
+    the L2); larger tables, or GTX_PERM_ROWS32=1, read the 32-bit lists.  Lists that start at odd members, lists of 0..9 members
+    (head, the blocks of 8, the tail), with and without row ranges: the same bits either way, and the oracle's."""
+    monkeypatch.setenv("GTX_PERM_ROWS32", rows32)
+    rng = np.random.default_rng(5)
+    n_rows = 700
+    sizes = [0, 1, 2, 7, 8, 9, 15, 16, 17, 3, 64, 65] + list(rng.integers(0, 40, size=60))
+    col_ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    rows = np.concatenate([np.sort(rng.choice(n_rows, size=s, replace=False)) for s in sizes]).astype(np.int32)
+    V = rng.gamma(2.0, 3.0, size=n_rows).astype(np.float32)
+    t = perm.PermTable(n_rows, col_ptr, rows, V, None)
+    for l2 in ("100", "0.05"):
+        monkeypatch.setenv("GTX_PERM_L2_MB", l2)
+        pe.set_table(t)
+        for stat in ("sum", "n", "t"):
+            Y = porc.statistic(t, stat, False)
+            assert same_bits(pe.statistic(stat, False), Y)
+            np.testing.assert_array_equal(pe.count_ge(stat, Y, seed=3, first_perm=1, n_perm=130), porc.count_ge(t, stat, Y, 3, 1, 130), err_msg=stat)
+    if rows32 == "0":                                    # more rows than 16 bits take: the 32-bit lists by themselves
+        big = perm.PermTable.synthetic(70000, 40, 30, seed=4, values="normal")
+        pe.set_table(big)
+        Y = porc.statistic(big, "sum", False)
+        np.testing.assert_array_equal(pe.count_ge("sum", Y, 9, 0, 64), porc.count_ge(big, "sum", Y, 9, 0, 64))
