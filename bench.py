@@ -94,11 +94,11 @@ def emit(obj):
         os.write(_REAL_STDOUT, line)
 
 
-def kernel_source_sha16():
+def kernel_source_sha16(files=("gtx_kernels.hip", "gtx_kernels.h", "gtx_capi.hip")):
     """identity of the kernel sources a committed PMC profile belongs to (the GPU box has no .git to ask)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gtx_kernels.hip", "gtx_kernels.h", "gtx_capi.hip"):
+    for f in files:
         h.update(open(os.path.join(PKG, "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -294,12 +294,14 @@ def bench_perm(args, rank, world, local, device, rehearse):
         cpu = {"value": nnz * ps / cpu_s, "unit": "member-sums/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
                "sample": "first %d shuffles of the same table, oracle/perm_oracle.c (permute + per-category sums + compare); "
                          "counts bit-equal to the GPU's" % ps}
-    traffic = None                                                        # L2->fabric bytes per launch from the committed --pmc pass of this command
-    if P == 10000:
+    traffic, l2_hit = None, None                                          # L2->fabric bytes per batch and L2 hit rate from the committed --pmc passes
+    if P == 10000:                                                        # of this command -- only if they were taken from the sources that run here
         import glob
         cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_perm_stat.json")))
         if cand:
-            traffic = json.load(open(cand[-1])).get("traffic_bytes_per_launch")
+            prof = json.load(open(cand[-1]))
+            if prof.get("perm_source_sha16") == kernel_source_sha16(("gtx_perm.hip",)):
+                traffic, l2_hit = prof.get("traffic_bytes_per_launch"), prof.get("l2_hit_rate")
     if rank == 0:
         alg = 4.0 * nnz * P                                               # gathered: one 4-byte slab element per (membership, shuffle)
         unique = 4.0 * n_rows * P + 4.0 * nnz + 8.0 * n_cols              # slab read once + membership lists + offsets
@@ -320,8 +322,10 @@ def bench_perm(args, rank, world, local, device, rehearse):
                          "kernel_ms": stat_ms, "apply_kernel_ms": apply_ms, "algorithmic_bytes": unique,
                          "l2_gather": {"gathered_bytes": alg, "achieved": alg / (stat_ms * 1e-3) / 1e9, "peak": 18800.0, "unit": "GB/s",
                                        "frac": alg / (stat_ms * 1e-3) / 1e9 / 18800.0},
-                         "note": "not HBM-bound: 4 B x memberships x shuffles of 256-byte row gathers are served by the XCD's L2 "
-                                 "(hit rate 0.69); traffic = L2->fabric bytes of the committed PMC pass, includes Infinity-Cache hits"},
+                         "l2_hit_rate": l2_hit,
+                         "note": "not HBM-bound: 4 B x memberships x shuffles of 256-byte row gathers are served by the XCD's L2; "
+                                 "traffic = L2->fabric bytes per 10 k-shuffle batch and l2_hit_rate from the committed PMC passes (null when "
+                                 "they were not taken from these sources), includes Infinity-Cache hits"},
             "cpu_baseline": cpu}))
     e.close()
     if DIST_ON:

@@ -12,9 +12,9 @@ def newest(pattern):
     return g[-1] if g else None
 
 
-def sha16():
+def sha16(files=("gtx_kernels.hip", "gtx_kernels.h", "gtx_capi.hip")):
     h = hashlib.sha256()
-    for f in ("gtx_kernels.hip", "gtx_kernels.h", "gtx_capi.hip"):
+    for f in files:
         h.update(open(R + "ibm-cbc-genomic-tools_amd/csrc/" + f, "rb").read())
     return h.hexdigest()[:16]
 
@@ -81,7 +81,7 @@ if all(r) and "FETCH_SIZE" in r[0][0]:
     parts = 2
     unique = line["roofline"]["algorithmic_bytes"] if line else 0.81e9
     fb = c["FETCH_SIZE"] * 1024 * 2 * parts; wb = c["WRITE_SIZE"] * 1024 * parts
-    d = {"kernel": "perm_stat_kernel<GTX_STAT_SUM,false,false,MODE_GE>, 2 row-range launches per 10 k-shuffle batch", "kernel_source_sha16": sha16(),
+    d = {"kernel": "perm_stat_kernel<GTX_STAT_SUM,false,false,MODE_GE>, 2 row-range launches per 10 k-shuffle batch", "kernel_source_sha16": sha16(), "perm_source_sha16": sha16(("gtx_perm.hip",)),
          "counters_mean_per_launch": c, "launches_per_batch": parts, "fetch_bytes_corrected_per_batch": fb, "write_bytes_per_batch": wb,
          "traffic_bytes_per_launch": fb + wb, "unique_bytes_per_batch": unique, "traffic_over_unique": (fb + wb) / unique,
          "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
