@@ -8,6 +8,13 @@
 #include <string.h>
 #include <unistd.h>
 #include <algorithm>
+#include <functional>
+#include <shared_mutex>
+#include <sys/mman.h>
+#include <stdint.h>
+#include <condition_variable>
+#include <mutex>
+#include <atomic>
 #include <future>
 #include <thread>
 #include <iostream>
@@ -35,6 +42,7 @@ static void Mark(const char *what) { GtxMark(what); }
 // GTX_FULL_EXIT is set.
 void GtxFinish(int code)
 {
+  if (getenv("GTX_TIMING")) fprintf(stderr, "[gtx leaving at epoch ms %lld]\n", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count());
   fflush(stdout); fflush(stderr);
   const char *pre = getenv("LD_PRELOAD");
   if (getenv("GTX_FULL_EXIT") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("HSA_TOOLS_LIB") ||
@@ -46,13 +54,75 @@ void GtxMark(const char *what)
 {
   static const bool on = getenv("GTX_TIMING") != NULL;
   static const auto t0 = std::chrono::steady_clock::now();
+  static const bool first = on && fprintf(stderr, "[gtx first mark at epoch ms %lld]\n", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count()) > 0;
+  (void)first;
   if (on) fprintf(stderr, "[gtx %8.3f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what);
 }
 
-static char *CopyString(const char *s) { size_t n = strlen(s) + 1; char *p = new char[n]; memcpy(p, s, n); return p; }
+// ---- memory of region objects built in parallel (see genomic_intervals.h) ----
+namespace {
+struct Block { char *cur = NULL, *end = NULL; std::vector<std::pair<void *, size_t> > owned; };
+thread_local Block *tls_block = NULL;
+std::shared_timed_mutex g_blocks_mu;
+std::vector<std::pair<uintptr_t, uintptr_t> > g_blocks;            // [first, last) of every live block, sorted
+
+void BlockGrow(Block *b, size_t at_least)
+{
+  const size_t want = std::max(at_least, (size_t)4 << 20), bytes = (want + 4095) & ~(size_t)4095;
+  void *p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_POPULATE, -1, 0);   // (pre-faulted: one call instead of a fault per page)
+  if (p == MAP_FAILED) { fprintf(stderr, "Error: out of memory!\n"); exit(1); }
+  b->cur = (char *)p; b->end = b->cur + bytes; b->owned.push_back(std::make_pair(p, bytes));
+  std::unique_lock<std::shared_timed_mutex> lk(g_blocks_mu);
+  g_blocks.insert(std::upper_bound(g_blocks.begin(), g_blocks.end(), std::make_pair((uintptr_t)p, (uintptr_t)0)), std::make_pair((uintptr_t)p, (uintptr_t)p + bytes));
+}
+
+bool InBlocks(const void *p)
+{
+  std::shared_lock<std::shared_timed_mutex> lk(g_blocks_mu);
+  if (g_blocks.empty()) return false;
+  auto it = std::upper_bound(g_blocks.begin(), g_blocks.end(), std::make_pair((uintptr_t)p, ~(uintptr_t)0));
+  if (it == g_blocks.begin()) return false;
+  --it;
+  return (uintptr_t)p >= it->first && (uintptr_t)p < it->second;
+}
+
+void BlocksRelease(std::vector<std::pair<void *, size_t> > &owned)
+{
+  if (owned.empty()) return;
+  std::unique_lock<std::shared_timed_mutex> lk(g_blocks_mu);
+  for (auto &o : owned) {
+    auto it = std::lower_bound(g_blocks.begin(), g_blocks.end(), std::make_pair((uintptr_t)o.first, (uintptr_t)0));
+    if (it != g_blocks.end() && it->first == (uintptr_t)o.first) g_blocks.erase(it);
+    munmap(o.first, o.second);
+  }
+  owned.clear();
+}
+}  // namespace
+
+void *GtxRegionAlloc(size_t bytes)
+{
+  Block *b = tls_block;
+  if (!b) return ::operator new(bytes);
+  bytes = (bytes + 15) & ~(size_t)15;
+  if ((size_t)(b->end - b->cur) < bytes) BlockGrow(b, bytes);
+  void *p = b->cur; b->cur += bytes;
+  return p;
+}
+
+void GtxRegionFree(void *p) { if (p && !InBlocks(p)) ::operator delete(p); }
+
+static char *CopyString(const char *s) { size_t n = strlen(s) + 1; char *p = (char *)GtxRegionAlloc(n); memcpy(p, s, n); return p; }
+
+// The threads that build an in-memory set (GenomicRegionSet::Init) must not exit() on a malformed line -- another thread may hold
+// an earlier one: they note the error here and unwind; Init raises the one with the smallest line number, as the reference's
+// line-by-line reader would have.
+struct LoadError { bool set = false; long int line = 0; std::string msg; bool with_prefix = true; };
+struct LoadAbort {};
+static thread_local LoadError *tls_load_error = NULL;
 
 static void DieLine(long int n_line, const std::string &msg)
 {
+  if (tls_load_error) { tls_load_error->set = true; tls_load_error->line = n_line; tls_load_error->msg = msg; tls_load_error->with_prefix = true; throw LoadAbort(); }
   fflush(stdout);
   fprintf(stderr, "\n");
   fprintf(stderr, "Error: Line %ld: %s\n", n_line, msg.c_str());
@@ -73,7 +143,7 @@ GenomicInterval::GenomicInterval(const char *chromosome, char strand, long int s
   CHROMOSOME = CopyString(chromosome); STRAND = strand; START = start; STOP = stop; this->n_line = n_line;
 }
 
-GenomicInterval::~GenomicInterval() { delete[] CHROMOSOME; }
+GenomicInterval::~GenomicInterval() { GtxRegionFree(CHROMOSOME); }
 
 void GenomicInterval::PrintInterval() { printf("%s %c %ld %ld", CHROMOSOME, STRAND, START, STOP); }
 
@@ -107,7 +177,7 @@ GenomicRegion::GenomicRegion() : n_line(0), LABEL(NULL) {}
 
 GenomicRegion::~GenomicRegion()
 {
-  delete[] LABEL;
+  GtxRegionFree(LABEL);
   for (size_t k = 0; k < I.size(); k++) delete I[k];
 }
 
@@ -177,7 +247,10 @@ GenomicRegionBED::GenomicRegionBED(char *inp, long int n_line)
   gtxhost::BedFields f; char *bad = NULL;
   gtxhost::BedStatus st = gtxhost::ParseBedLine(inp, &f, &bad);
   if (st == gtxhost::BED_TOO_FEW_TOKENS) PrintError("number of tokens should be at least 3 for BED format!");
-  if (st == gtxhost::BED_BAD_STRAND) { fflush(stdout); std::cerr << "Error: invalid strand '" << bad << "'!\n"; exit(1); }
+  if (st == gtxhost::BED_BAD_STRAND) {
+    if (tls_load_error) { tls_load_error->set = true; tls_load_error->line = n_line; tls_load_error->msg = std::string("Error: invalid strand '") + bad + "'!"; tls_load_error->with_prefix = false; throw LoadAbort(); }
+    fflush(stdout); std::cerr << "Error: invalid strand '" << bad << "'!\n"; exit(1);
+  }
   n_tokens = f.n_tokens;
   LABEL = CopyString(f.label ? f.label : "_");
   if (n_tokens != 12) { I.push_back(new GenomicInterval(f.chrom, f.strand, f.start, f.stop, n_line)); return; }
@@ -215,7 +288,7 @@ GenomicRegionSet::GenomicRegionSet(FILE *file_ptr, unsigned long int buffer_size
 
 GenomicRegionSet::~GenomicRegionSet()
 {
-  delete[] file;
+  GtxRegionFree(file);
   delete src;
   delete packed;
   if (R) {
@@ -223,6 +296,7 @@ GenomicRegionSet::~GenomicRegionSet()
     for (long int k = 0; k < n; k++) delete R[k];
     delete[] R;
   }
+  BlocksRelease(blocks_);
   if (load_in_memory) Mark("GenomicRegionSet (in memory): released");
 }
 
@@ -286,10 +360,66 @@ void GenomicRegionSet::Init()
   else DetectFormat(line);
 
   if (load_in_memory) {
+    // The first line here, the rest in blocks of complete lines, each block cut at line ends into one piece per thread: the
+    // region objects (five small allocations each) are what the load costs, and the allocator scales with the threads
+    // (1 M regions: 0.23 s on one thread).  The set is the same objects in the same order; a malformed line is reported as the
+    // line-by-line reader would have met it -- the first one in the file.
     std::vector<GenomicRegion *> regs;
-    // (building the region objects in parallel does not pay: the load is bound by first-touch page faults of the
-    // ~200 B of heap per region, which the kernel serialises)
-    for (; line; line = src->Next()) regs.push_back(new GenomicRegionBED(line, src->line_no()));
+    if (line) regs.push_back(new GenomicRegionBED(line, src->line_no()));
+    const int T = getenv("GTX_LOAD_THREADS") && atoi(getenv("GTX_LOAD_THREADS")) > 0 ? atoi(getenv("GTX_LOAD_THREADS")) : std::min(gtxhost::WorkerThreads(), 16);
+    std::vector<char> block; char *view = NULL; long first_line = 0;
+    size_t got;
+    while (line && (got = src->NextBlockView(block, &view, (size_t)64 << 20, &first_line)) > 0) {
+      struct Piece { char *b, *e; long lines = 0, first = 0; std::vector<GenomicRegion *> out; LoadError err; Block mem; };
+      std::vector<Piece> pc((size_t)std::max(1, std::min<int>(T, (int)(got / (256u << 10)) + 1)));
+      char *end = view + got;
+      for (size_t t = 0; t < pc.size(); t++) {
+        char *b = t == 0 ? view : pc[t - 1].e, *e = t + 1 == pc.size() ? end : view + got * (t + 1) / pc.size();
+        if (e < b) e = b;
+        while (e < end && e > view && e[-1] != '\n') e++;                   // up to the end of the line it falls into
+        pc[t].b = b; pc[t].e = e;
+      }
+      auto count = [&](size_t t) { pc[t].lines = gtxhost::CountNewlines(pc[t].b, pc[t].e); };
+      auto build = [&](size_t t) {
+        Piece &p = pc[t];
+        p.out.reserve((size_t)p.lines);
+        const auto t0 = std::chrono::steady_clock::now();
+        BlockGrow(&p.mem, (size_t)p.lines * 176 + (size_t)(p.e - p.b) / 8 + 4096);   // a region (64 B), an interval (48), the vector's slot (16), two strings (more: another block)
+        const auto t1 = std::chrono::steady_clock::now();
+        tls_block = &p.mem;
+        tls_load_error = &p.err;
+        long no = p.first;
+        try {
+          for (char *q = p.b; q < p.e; no++) {
+            char *nl = (char *)memchr(q, '\n', (size_t)(p.e - q));
+            if (!nl) break;                                                // (cannot happen: pieces end at line ends)
+            *nl = 0;
+            p.out.push_back(new GenomicRegionBED(q, no));
+            q = nl + 1;
+          }
+        } catch (const LoadAbort &) {}
+        tls_load_error = NULL; tls_block = NULL;
+        if (getenv("GTX_PACK_TRACE")) fprintf(stderr, "[load] piece %zu: %ld lines, block %.1f ms, objects %.1f ms\n", t, p.lines, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+      };
+      auto run = [&](const std::function<void(size_t)> &f) { gtxhost::ParallelFor((int)pc.size(), [&](int t) { f((size_t)t); }); };
+      const auto tA = std::chrono::steady_clock::now();
+      run(count);
+      long total = 0;
+      for (auto &p : pc) { p.first = first_line + total; total += p.lines; }
+      src->AdvanceLines(total);
+      const auto tB = std::chrono::steady_clock::now();
+      run(build);
+      const auto tC = std::chrono::steady_clock::now();
+      if (getenv("GTX_PACK_TRACE")) fprintf(stderr, "[load] %zu pieces: count %.1f ms, build %.1f ms\n", pc.size(), std::chrono::duration<double, std::milli>(tB - tA).count(), std::chrono::duration<double, std::milli>(tC - tB).count());
+      for (auto &p : pc) {
+        blocks_.insert(blocks_.end(), p.mem.owned.begin(), p.mem.owned.end());
+        regs.insert(regs.end(), p.out.begin(), p.out.end());
+        if (p.err.set) {                                                    // the pieces are in file order: this is the first bad line
+          if (p.err.with_prefix) DieLine(p.err.line, p.err.msg);
+          fflush(stdout); fprintf(stderr, "%s\n", p.err.msg.c_str()); exit(1);
+        }
+      }
+    }
     n_regions = (long int)regs.size();
     R = n_regions > 0 ? new GenomicRegion *[n_regions] : NULL;
     for (long int k = 0; k < n_regions; k++) R[k] = regs[k];
@@ -434,12 +564,14 @@ static gtx_group *CreateGroup()
   const char *rh = getenv("GTX_GROUP_REHEARSE");           // test mode of the library: all members on one device
   for (int i = 0; i < n; i++) ids[i] = first + ((rh && atoi(rh)) ? 0 : i);
   gtx_group *g = gtx_group_create(n, ids.data());
+  Mark("HIP context(s) created (start-up thread)");
   if (!g) { g_ctx_error = gtx_group_last_error(NULL); return g; }   // thread-local in the library: copy it out on this thread
   if (getenv("GTX_NO_PINNED_BATCHES") == NULL) {
     // page-locking 2 x 190 MB takes ~70 ms: on a thread of its own, behind the packing of the index set and gtx_set_refs; DrainSet waits for it
     g_pool.owner = gtx_group_ctx(g, 0);
     g_pool_future = std::async(std::launch::async, [] {
       for (int k = 0; k < 2; k++) g_pool.buf[k] = gtx_host_alloc(g_pool.owner, kPoolBytes);    // (NULL: the heap serves)
+      Mark("page-locked batch buffers ready (start-up thread)");
       gtxhost::BatchArena::take = PoolTake; gtxhost::BatchArena::give = PoolGive;
     });
   }
@@ -475,26 +607,115 @@ static void CheckGrp(gtx_group *g, int rc)
   if (rc != GTX_OK) { fflush(stdout); fprintf(stderr, "\nError: [gtx %d] %s\n", rc, gtx_group_last_error(g)); exit(1); }
 }
 
-// Packs the rest of a query/input set batch by batch and hands every batch to `sink`.
+// Packs the rest of a query/input set batch by batch and hands every batch to `sink`, in order.
 // In-memory sets are walked region by region with the same rules.
-template <class Sink>
-static void DrainSet(GenomicRegionSet *set, PackOptions opt, Sink sink)
+// Text input: the packing (a long-lived helper thread driving the packer's pool) runs AHEAD of the hand-over.  This thread does
+// `prep` -- wait for the HIP context that the start-up thread is still making, gtx_set_refs, *_begin -- and every sink() call, so
+// text is being parsed while the ROCm runtime initialises (0.2 s of a 0.9 s run).  `ahead` batches are kept
+// (GTX_HOST_BATCHES_AHEAD, default 3); a batch is refilled only after the hand-over of the NEXT one has returned (the contract of
+// gtx_count_add in include/gtx.h).  The first batches are packed before the page-locked buffers exist and live in ordinary memory
+// (the library stages those itself); the two page-locked buffers join the rotation when a slot is refilled.
+// Packed region files have nothing to parse: two batches in the page-locked buffers, one thread, as before.
+static const int kBatchesAhead = getenv("GTX_HOST_BATCHES_AHEAD") && atoi(getenv("GTX_HOST_BATCHES_AHEAD")) >= 2 ? atoi(getenv("GTX_HOST_BATCHES_AHEAD")) : 3;
+
+static bool PoolHasFree()
 {
-  const size_t batch_reads = kBatchReads;
-  if (g_pool_future.valid()) g_pool_future.get();             // the page-locked batch buffers are there
-  PackedBatch two[2]; int cur = 0; PackError err;           // two batches in turn: one is packed while the device still reads the other
-  auto pump = [&](BedPacker &packer) {
-    for (;;) {
-      PackedBatch &batch = two[cur];
-      bool more = packer.NextBatch(&batch, batch_reads, &err);
-      if (err.set) DiePack(err);
-      if (!batch.tri.empty()) {
-        const auto t0 = std::chrono::steady_clock::now();
-        sink(batch); cur ^= 1;
-        if (getenv("GTX_PACK_TRACE")) fprintf(stderr, "[sink] %zu reads handed over in %.1f ms\n", batch.tri.size() / 3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  if (gtxhost::BatchArena::take == NULL) return false;
+  for (int k = 0; k < 2; k++) if (g_pool.buf[k] && !g_pool.used[k]) return true;
+  return false;
+}
+static bool PoolOwns(const void *p) { return p && (p == g_pool.buf[0] || p == g_pool.buf[1]); }
+
+// One long-lived helper thread for work that runs beside the calling thread (the packing of DrainSet).  Long-lived on purpose: see
+// gtxhost::ParallelFor.
+namespace {
+class Helper {
+ public:
+  static void Start(std::function<void()> f) { Get().Go(std::move(f)); }
+  static void Wait() { Helper &h = Get(); std::unique_lock<std::mutex> lk(h.m_); h.idle_.wait(lk, [&] { return !h.busy_; }); }
+ private:
+  static Helper &Get() { static Helper h; return h; }
+  std::thread th_; std::mutex m_; std::condition_variable wake_, idle_; std::function<void()> f_; bool busy_ = false, stop_ = false;
+  void Go(std::function<void()> f)
+  {
+    std::unique_lock<std::mutex> lk(m_);
+    idle_.wait(lk, [&] { return !busy_; });
+    f_ = std::move(f); busy_ = true;
+    if (!th_.joinable()) th_ = std::thread([this] {
+      std::unique_lock<std::mutex> l(m_);
+      for (;;) {
+        wake_.wait(l, [&] { return stop_ || (busy_ && f_); });
+        if (stop_) return;
+        std::function<void()> g = std::move(f_); f_ = nullptr;
+        l.unlock(); g(); l.lock();
+        busy_ = false; idle_.notify_all();
       }
-      if (!more) break;
+    });
+    wake_.notify_all();
+  }
+  ~Helper() { { std::lock_guard<std::mutex> lk(m_); stop_ = true; } wake_.notify_all(); if (th_.joinable()) th_.join(); }
+};
+}  // namespace
+
+static std::atomic<bool> g_drain_stop(false);                 // set by a sink that has seen enough (an error it will raise after DrainSet): no more batches
+
+template <class Prep, class Sink>
+static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sink)
+{
+  g_drain_stop = false;
+  const size_t batch_reads = kBatchReads;
+  // a packed region file has nothing to parse: running ahead buys nothing there, and batches outside the page-locked buffers cost
+  // first-touch page faults and a staging copy -- two batches, in the page-locked buffers, as soon as those exist
+  const bool packed_file = !set->load_in_memory && set->format == "GTX";
+  if (packed_file && g_pool_future.valid()) g_pool_future.get();
+  const int K = packed_file ? 2 : kBatchesAhead;
+  static std::vector<PackedBatch> ring;                        // kept between calls (and not freed before the tools exit: 1 GB of unmapping)
+  if ((int)ring.size() < K) ring.resize((size_t)K);
+  PackError err;
+  std::mutex mu; std::condition_variable cv;
+  long produced = 0, consumed = 0; bool done = false;        // batches packed / handed over; no more will come
+  // The packing runs on the helper thread; THIS thread keeps every call into the library.
+  auto pump = [&](BedPacker &packer) {
+    if (packed_file || getenv("GTX_NO_PACK_AHEAD")) {                // one batch at a time, everything on this thread
+      prep();
+      for (int cur = 0;;) {
+        bool more = packer.NextBatch(&ring[(size_t)cur], batch_reads, &err);
+        if (g_drain_stop) break;
+        if (err.set) DiePack(err);
+        if (!ring[(size_t)cur].tri.empty()) { sink(ring[(size_t)cur]); cur ^= 1; }
+        if (!more) break;
+      }
+      return;
     }
+    Helper::Start([&] {
+      for (long i = 0;;) {
+        if (i >= K) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return consumed >= i - K + 2 || g_drain_stop; }); }   // the slot's last batch and its successor are with the device
+        if (g_drain_stop) break;
+        PackedBatch &batch = ring[(size_t)(i % K)];
+        if (i >= K && !PoolOwns(batch.tri.data()) && PoolHasFree()) gtxhost::RawVec().swap(batch.tri);   // this slot moves into a page-locked buffer
+        bool more = packer.NextBatch(&batch, batch_reads, &err);
+        if (g_drain_stop || err.set) break;
+        if (!batch.tri.empty()) { { std::lock_guard<std::mutex> lk(mu); produced = ++i; } cv.notify_all(); }
+        if (!more) break;
+      }
+      { std::lock_guard<std::mutex> lk(mu); done = true; }
+      cv.notify_all();
+    });
+    prep();
+    for (long j = 0;; j++) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return produced > j || done; });
+        if (produced <= j) break;
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      sink(ring[(size_t)(j % K)]);
+      if (getenv("GTX_PACK_TRACE")) fprintf(stderr, "[sink] %zu reads handed over in %.1f ms\n", ring[(size_t)(j % K)].tri.size() / 3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      { std::lock_guard<std::mutex> lk(mu); consumed = j + 1; }
+      cv.notify_all();
+    }
+    Helper::Wait();
+    if (err.set && !g_drain_stop) DiePack(err);                   // (the batches before the bad line have been handed over, as the reference would have processed them)
   };
   if (!set->load_in_memory && set->format == "GTX") {
     long int at = 0;
@@ -647,11 +868,15 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
     refs[3 * k + 1] = (int32_t)i->START; refs[3 * k + 2] = (int32_t)STOP;
   }
   Mark("index packed");
-  gtx_group *grp = Devices();
-  Mark("device ready");
+  gtx_group *grp = NULL;
   const int n_classes = std::max(1, n_chrom * (strand_aware ? 2 : 1));
-  CheckGrp(grp, gtx_group_set_refs(grp, refs.data(), M, n_classes, sorted ? GTX_REFS_KEEP_ZERO_LENGTH : 0));
-  Mark("gtx_set_refs done");
+  auto device_side = [&](bool cover) {                              // (on DrainSet's hand-over thread, while the queries are already being packed)
+    grp = Devices();
+    Mark("device ready");
+    CheckGrp(grp, gtx_group_set_refs(grp, refs.data(), M, n_classes, sorted ? GTX_REFS_KEEP_ZERO_LENGTH : 0));
+    Mark("gtx_set_refs done");
+    CheckGrp(grp, cover ? gtx_group_coverage_begin(grp) : gtx_group_count_begin(grp));
+  };
 
   // ---- query side: stream -> packed batches -> device ----
   PackOptions opt;
@@ -665,8 +890,7 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   gtx_count_info info;
   if (coverage) {
     // zero-length reads (sorted rules let them through) and zero-length regions contribute 0: the device leaves them out
-    CheckGrp(grp, gtx_group_coverage_begin(grp));
-    DrainSet(QuerySet, opt, [&](const PackedBatch &b) {
+    DrainSet(QuerySet, opt, [&] { device_side(true); }, [&](const PackedBatch &b) {
       CheckGrp(grp, gtx_group_coverage_add(grp, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3),
                                            sorted ? (GTX_ZERO_LENGTH_OK | (match_gaps ? GTX_GAPS_FORMULA : 0u)) : 0u));
     });
@@ -676,9 +900,8 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
     Mark("coverage on the host");
     return hits;
   }
-  CheckGrp(grp, gtx_group_count_begin(grp));
   const uint32_t mode_flags = sorted ? GTX_ZERO_LENGTH_OK : 0;
-  DrainSet(QuerySet, opt, [&](const PackedBatch &b) {
+  DrainSet(QuerySet, opt, [&] { device_side(false); }, [&](const PackedBatch &b) {
     uint32_t flags = mode_flags | (LooksSorted(b.tri) ? GTX_READS_SORTED : 0);
     CheckGrp(grp, gtx_group_count_add(grp, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), flags));
     zero_len.insert(zero_len.end(), b.zero_len.begin(), b.zero_len.end());
@@ -988,13 +1211,15 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
   opt.chroms = &chroms; opt.strand_aware = !ignore_strand; opt.sorted_by_strand = !ignore_strand;
   opt.max_label_value = max_label_value;
   std::vector<int32_t> tri, w;
-  DrainSet(R, opt, [&](const PackedBatch &b) {
-    if (sorted_rules && preprocess != '1') { fprintf(stderr, "Error: [SortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
-    if (!sorted_rules && preprocess != '1' && preprocess != 'c') { fprintf(stderr, "Error: [UnsortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
+  bool bad_preprocess = false;                                     // raised at the first region that is processed, like the reference
+  DrainSet(R, opt, [] {}, [&](const PackedBatch &b) {
+    if ((sorted_rules && preprocess != '1') || (!sorted_rules && preprocess != '1' && preprocess != 'c')) { bad_preprocess = true; g_drain_stop = true; return; }
     total_label_value += (long int)b.label_sum;
     tri.insert(tri.end(), b.tri.begin(), b.tri.end());
     w.insert(w.end(), b.w.begin(), b.w.end());
   });
+  if (bad_preprocess && sorted_rules) { fprintf(stderr, "Error: [SortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
+  if (bad_preprocess) { fprintf(stderr, "Error: [UnsortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
   gtx_group *grp = Devices();
   const char prep = (preprocess == 'c' && !sorted_rules) ? 'c' : '1';
   CheckGrp(grp, gtx_group_scan(grp, tri.data(), w.empty() ? NULL : w.data(), (int64_t)(tri.size() / 3), class_len.data(), n_chrom * ns,

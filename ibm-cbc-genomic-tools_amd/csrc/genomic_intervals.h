@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace gtxhost { class LineSource; struct GtxView; }
@@ -28,6 +29,22 @@ namespace gtxhost { class LineSource; struct GtxView; }
 typedef std::map<std::string, long int> StringLIntMap;          // genomic_intervals.h:41
 
 extern bool _MESSAGES_;                                          // verbose switch (core.h; set from -v)
+
+// Region objects of an in-memory set are built by several threads at once (GenomicRegionSet::Init); the general heap does not
+// scale there (every arena growth takes the address-space lock that page faults need), so those objects, their strings and their
+// interval vectors come out of per-thread blocks owned by the set.  Objects made anywhere else use the ordinary heap; `delete`
+// works on both.
+void *GtxRegionAlloc(size_t bytes);                               // from the calling thread's block if it has one, else operator new
+void GtxRegionFree(void *p);                                      // nothing for block memory, operator delete otherwise
+template <class T> struct GtxRegionAllocator {
+  typedef T value_type;
+  GtxRegionAllocator() {}
+  template <class U> GtxRegionAllocator(const GtxRegionAllocator<U> &) {}
+  T *allocate(size_t n) { return (T *)GtxRegionAlloc(n * sizeof(T)); }
+  void deallocate(T *p, size_t) { GtxRegionFree(p); }
+  template <class U> bool operator==(const GtxRegionAllocator<U> &) const { return true; }
+  template <class U> bool operator!=(const GtxRegionAllocator<U> &) const { return false; }
+};
 
 // ---- GenomicInterval (genomic_intervals.h:91) ---------------------------------------------------------
 class GenomicInterval
@@ -42,13 +59,16 @@ class GenomicInterval
   bool OverlapsWith(GenomicInterval *i, bool ignore_strand);      // :624-630
   long int CalcOverlap(GenomicInterval *i, bool ignore_strand);   // :427-432
 
+  static void *operator new(size_t n) { return GtxRegionAlloc(n); }
+  static void operator delete(void *p) { GtxRegionFree(p); }
+
   char *CHROMOSOME;
   char STRAND;
   long int START, STOP;          // 1-based, inclusive
   long int n_line;
 };
 
-typedef std::vector<GenomicInterval *> GenomicIntervalSet;        // genomic_intervals.h:46
+typedef std::vector<GenomicInterval *, GtxRegionAllocator<GenomicInterval *> > GenomicIntervalSet;   // genomic_intervals.h:46 (a vector of pointers there too)
 
 // ---- GenomicRegion (genomic_intervals.h:591) / GenomicRegionBED (:1112) ------------------------------
 class GenomicRegion
@@ -65,6 +85,9 @@ class GenomicRegion
   bool OverlapsWith(GenomicRegion *r, bool ignore_strand);        // :1167-1172 (any interval pair)
   long int CalcOverlap(GenomicRegion *r, bool ignore_strand);     // :1196-1202 (sum over interval pairs)
   int CalcDirection(GenomicRegion *r, bool sorted_by_strand);     // :1225-1236 (on the envelopes)
+
+  static void *operator new(size_t n) { return GtxRegionAlloc(n); }
+  static void operator delete(void *p) { GtxRegionFree(p); }
 
   long int n_line;
   char *LABEL;
@@ -114,6 +137,7 @@ class GenomicRegionSet
   void DetectFormat(const char *first_line);
   gtxhost::LineSource *src;
   gtxhost::GtxView *packed;                                        // format "GTX"
+  std::vector<std::pair<void *, size_t> > blocks_;                  // memory of the region objects built in parallel (GtxRegionAlloc)
   GenomicRegion *PackedRegion(long int record);                    // region object of one record of the packed file
   std::string cur_raw;                                             // unparsed copy of the current line (streaming mode)
   long int r_index;

@@ -725,6 +725,18 @@ long CountLines(const char *b, const char *e)
 
 }  // namespace
 
+// what the bulk readers of this library use by default: GTX_PACK_THREADS, else the container's CPU quota (<= 64)
+int WorkerThreads()
+{
+  const char *e = getenv("GTX_PACK_THREADS");
+  if (e && atoi(e) > 0) return atoi(e);
+  return std::min(EffectiveCpus(), 64);
+}
+
+long CountNewlines(const char *b, const char *e) { return CountLines(b, e); }
+
+void ParallelFor(int n, const std::function<void(int)> &fn) { Pool::Run(n, fn); }
+
 BedPacker::BedPacker(LineSource *src, const PackOptions &opt) : src_(src), opt_(opt)
 {
   if (opt_.guard) opt_.threads = 1;
@@ -852,7 +864,7 @@ bool BedPacker::PackPieces(void *pieces_ptr, long first_line, PackedBatch *out, 
 
 bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
 {
-  out->tri.clear(); out->w.clear(); out->zero_len.clear(); out->n_lines = 0;
+  out->tri.clear(); out->w.clear(); out->zero_len.clear(); out->n_lines = 0; out->label_sum = 0;    // (the batch object is the caller's and is reused)
   out->tri.reserve(target_reads * 3 + (24u << 20));       // one allocation; its pages are first touched by the copy threads
   if (opt_.max_label_value > 1) out->w.reserve(target_reads + (8u << 20));
   if (primed_set_) {

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <future>
 #include <memory>
+#include <functional>
 #include <string>
 #include <vector>
 #include <zlib.h>
@@ -54,6 +55,12 @@ class LineSource {
   bool eof_ = false;
   long line_no_ = 0;
 };
+
+int WorkerThreads();                                  // GTX_PACK_THREADS, else the container's CPU quota (<= 64)
+long CountNewlines(const char *b, const char *e);
+// fn(t) for t in [0, n) on the library's worker threads (t = 0 on the caller); returns when all are done.  The workers live as long as
+// the process.
+void ParallelFor(int n, const std::function<void(int)> &fn);
 
 // ---- one BED line ---------------------------------------------------------------------------------
 struct BedFields {
