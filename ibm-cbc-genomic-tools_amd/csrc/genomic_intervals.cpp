@@ -366,7 +366,11 @@ void GenomicRegionSet::Init()
     // line-by-line reader would have met it -- the first one in the file.
     std::vector<GenomicRegion *> regs;
     if (line) regs.push_back(new GenomicRegionBED(line, src->line_no()));
-    const int T = getenv("GTX_LOAD_THREADS") && atoi(getenv("GTX_LOAD_THREADS")) > 0 ? atoi(getenv("GTX_LOAD_THREADS")) : std::min(gtxhost::WorkerThreads(), 16);
+    // Four threads, not all of them: this runs while the start-up thread brings up the HIP runtime, and a process that had many
+    // threads running then takes 0.15-0.2 s longer to go away at exit (measured on the MI355X boxes, 16 threads against 4: every
+    // run against none; where the time goes inside the driver's teardown was not found).  Four are enough: the runtime is what the
+    // set's caller waits for anyway.
+    const int T = getenv("GTX_LOAD_THREADS") && atoi(getenv("GTX_LOAD_THREADS")) > 0 ? atoi(getenv("GTX_LOAD_THREADS")) : std::min(gtxhost::WorkerThreads(), 4);
     std::vector<char> block; char *view = NULL; long first_line = 0;
     size_t got;
     while (line && (got = src->NextBlockView(block, &view, (size_t)64 << 20, &first_line)) > 0) {
@@ -609,12 +613,10 @@ static void CheckGrp(gtx_group *g, int rc)
 
 // Packs the rest of a query/input set batch by batch and hands every batch to `sink`, in order.
 // In-memory sets are walked region by region with the same rules.
-// Text input: the packing (a long-lived helper thread driving the packer's pool) runs AHEAD of the hand-over.  This thread does
-// `prep` -- wait for the HIP context that the start-up thread is still making, gtx_set_refs, *_begin -- and every sink() call, so
-// text is being parsed while the ROCm runtime initialises (0.2 s of a 0.9 s run).  `ahead` batches are kept
-// (GTX_HOST_BATCHES_AHEAD, default 3); a batch is refilled only after the hand-over of the NEXT one has returned (the contract of
-// gtx_count_add in include/gtx.h).  The first batches are packed before the page-locked buffers exist and live in ordinary memory
-// (the library stages those itself); the two page-locked buffers join the rotation when a slot is refilled.
+// Text input: after `prep` (wait for the HIP context that the start-up thread is making, gtx_set_refs, *_begin) the packing runs on a
+// long-lived helper thread driving the packer's pool, AHEAD of the hand-over, which stays on this thread: parsing never waits for a
+// hand-over to return.  `ahead` batches are kept (GTX_HOST_BATCHES_AHEAD, default 3); a batch is refilled only after the hand-over
+// of the NEXT one has returned (the contract of gtx_count_add in include/gtx.h).
 // Packed region files have nothing to parse: two batches in the page-locked buffers, one thread, as before.
 static const int kBatchesAhead = getenv("GTX_HOST_BATCHES_AHEAD") && atoi(getenv("GTX_HOST_BATCHES_AHEAD")) >= 2 ? atoi(getenv("GTX_HOST_BATCHES_AHEAD")) : 3;
 
@@ -687,6 +689,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       }
       return;
     }
+    prep();                                                         // (first: the packer's full pool starts only once the HIP runtime is up, see GenomicRegionSet::Init)
     Helper::Start([&] {
       for (long i = 0;;) {
         if (i >= K) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return consumed >= i - K + 2 || g_drain_stop; }); }   // the slot's last batch and its successor are with the device
@@ -701,7 +704,6 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       { std::lock_guard<std::mutex> lk(mu); done = true; }
       cv.notify_all();
     });
-    prep();
     for (long j = 0;; j++) {
       {
         std::unique_lock<std::mutex> lk(mu);

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 P=./xbuild/new
 $P/gtx_packtool synth 100000000 7 /tmp/e2e_reads.bed; $P/gtx_packtool synthrefs 1000000 8 /tmp/e2e_refs.bed; $P/gtx_packtool pack /tmp/e2e_reads.bed /tmp/e2e_reads.gtx
-for f in /tmp/e2e_reads.gtx /tmp/e2e_reads.bed; do for rep in 1 2 3 4; do for v in old new; do
+for f in /tmp/e2e_reads.gtx /tmp/e2e_reads.bed; do for rep in 1 2 3 4; do for v in new new:GTX_LOAD_THREADS=16; do
   b=${v%%:*}; e1=A=1; [ "$v" != "$b" ] && e1=${v#*:}
   e1=$(echo $e1 | tr ',' ' ')
   s=$(date +%s%N); env $e1 GTX_TIMING=1 ./xbuild/$b/genomic_overlaps count -S -i /tmp/e2e_refs.bed $f 2> /tmp/e2e.err > /tmp/e2e_out.txt; e=$(date +%s%N)
