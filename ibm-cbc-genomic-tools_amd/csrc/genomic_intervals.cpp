@@ -611,54 +611,12 @@ static void CheckGrp(gtx_group *g, int rc)
   if (rc != GTX_OK) { fflush(stdout); fprintf(stderr, "\nError: [gtx %d] %s\n", rc, gtx_group_last_error(g)); exit(1); }
 }
 
-// Packs the rest of a query/input set batch by batch and hands every batch to `sink`, in order.
-// In-memory sets are walked region by region with the same rules.
-// Text input: after `prep` (wait for the HIP context that the start-up thread is making, gtx_set_refs, *_begin) the packing runs on a
-// long-lived helper thread driving the packer's pool, AHEAD of the hand-over, which stays on this thread: parsing never waits for a
-// hand-over to return.  `ahead` batches are kept (GTX_HOST_BATCHES_AHEAD, default 3); a batch is refilled only after the hand-over
-// of the NEXT one has returned (the contract of gtx_count_add in include/gtx.h).
-// Packed region files have nothing to parse: two batches in the page-locked buffers, one thread, as before.
-static const int kBatchesAhead = getenv("GTX_HOST_BATCHES_AHEAD") && atoi(getenv("GTX_HOST_BATCHES_AHEAD")) >= 2 ? atoi(getenv("GTX_HOST_BATCHES_AHEAD")) : 3;
-
-static bool PoolHasFree()
-{
-  if (gtxhost::BatchArena::take == NULL) return false;
-  for (int k = 0; k < 2; k++) if (g_pool.buf[k] && !g_pool.used[k]) return true;
-  return false;
-}
-static bool PoolOwns(const void *p) { return p && (p == g_pool.buf[0] || p == g_pool.buf[1]); }
-
-// One long-lived helper thread for work that runs beside the calling thread (the packing of DrainSet).  Long-lived on purpose: see
-// gtxhost::ParallelFor.
-namespace {
-class Helper {
- public:
-  static void Start(std::function<void()> f) { Get().Go(std::move(f)); }
-  static void Wait() { Helper &h = Get(); std::unique_lock<std::mutex> lk(h.m_); h.idle_.wait(lk, [&] { return !h.busy_; }); }
- private:
-  static Helper &Get() { static Helper h; return h; }
-  std::thread th_; std::mutex m_; std::condition_variable wake_, idle_; std::function<void()> f_; bool busy_ = false, stop_ = false;
-  void Go(std::function<void()> f)
-  {
-    std::unique_lock<std::mutex> lk(m_);
-    idle_.wait(lk, [&] { return !busy_; });
-    f_ = std::move(f); busy_ = true;
-    if (!th_.joinable()) th_ = std::thread([this] {
-      std::unique_lock<std::mutex> l(m_);
-      for (;;) {
-        wake_.wait(l, [&] { return stop_ || (busy_ && f_); });
-        if (stop_) return;
-        std::function<void()> g = std::move(f_); f_ = nullptr;
-        l.unlock(); g(); l.lock();
-        busy_ = false; idle_.notify_all();
-      }
-    });
-    wake_.notify_all();
-  }
-  ~Helper() { { std::lock_guard<std::mutex> lk(m_); stop_ = true; } wake_.notify_all(); if (th_.joinable()) th_.join(); }
-};
-}  // namespace
-
+// Packs the rest of a query/input set batch by batch and hands every batch to `sink`, in order; `prep` (wait for the HIP context
+// that the start-up thread is making, gtx_set_refs, *_begin) runs first.  In-memory sets are walked region by region with the same
+// rules.  Two batches in turn, in the two page-locked buffers: one is packed while the device still reads the other (the hand-over
+// returns with the copy in flight).  Measured and dropped: packing AHEAD of the hand-over on a helper thread, started before the HIP
+// runtime is up -- batches outside the page-locked buffers cost first-touch page faults and a staging copy in the library, more
+// page-locked memory to release at exit, and 100 M reads from text came out 10 % slower (0.95 -> 1.06 s on one box).
 static std::atomic<bool> g_drain_stop(false);                 // set by a sink that has seen enough (an error it will raise after DrainSet): no more batches
 
 template <class Prep, class Sink>
@@ -666,58 +624,22 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
 {
   g_drain_stop = false;
   const size_t batch_reads = kBatchReads;
-  // a packed region file has nothing to parse: running ahead buys nothing there, and batches outside the page-locked buffers cost
-  // first-touch page faults and a staging copy -- two batches, in the page-locked buffers, as soon as those exist
-  const bool packed_file = !set->load_in_memory && set->format == "GTX";
-  if (packed_file && g_pool_future.valid()) g_pool_future.get();
-  const int K = packed_file ? 2 : kBatchesAhead;
-  static std::vector<PackedBatch> ring;                        // kept between calls (and not freed before the tools exit: 1 GB of unmapping)
-  if ((int)ring.size() < K) ring.resize((size_t)K);
-  PackError err;
-  std::mutex mu; std::condition_variable cv;
-  long produced = 0, consumed = 0; bool done = false;        // batches packed / handed over; no more will come
-  // The packing runs on the helper thread; THIS thread keeps every call into the library.
+  PackedBatch two[2]; PackError err;
   auto pump = [&](BedPacker &packer) {
-    if (packed_file || getenv("GTX_NO_PACK_AHEAD")) {                // one batch at a time, everything on this thread
-      prep();
-      for (int cur = 0;;) {
-        bool more = packer.NextBatch(&ring[(size_t)cur], batch_reads, &err);
-        if (g_drain_stop) break;
-        if (err.set) DiePack(err);
-        if (!ring[(size_t)cur].tri.empty()) { sink(ring[(size_t)cur]); cur ^= 1; }
-        if (!more) break;
+    prep();
+    if (g_pool_future.valid()) g_pool_future.get();             // the page-locked batch buffers are there
+    for (int cur = 0;;) {
+      PackedBatch &batch = two[cur];
+      bool more = packer.NextBatch(&batch, batch_reads, &err);
+      if (g_drain_stop) break;
+      if (err.set) DiePack(err);
+      if (!batch.tri.empty()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        sink(batch); cur ^= 1;
+        if (getenv("GTX_PACK_TRACE")) fprintf(stderr, "[sink] %zu reads handed over in %.1f ms\n", batch.tri.size() / 3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       }
-      return;
+      if (!more) break;
     }
-    prep();                                                         // (first: the packer's full pool starts only once the HIP runtime is up, see GenomicRegionSet::Init)
-    Helper::Start([&] {
-      for (long i = 0;;) {
-        if (i >= K) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return consumed >= i - K + 2 || g_drain_stop; }); }   // the slot's last batch and its successor are with the device
-        if (g_drain_stop) break;
-        PackedBatch &batch = ring[(size_t)(i % K)];
-        if (i >= K && !PoolOwns(batch.tri.data()) && PoolHasFree()) gtxhost::RawVec().swap(batch.tri);   // this slot moves into a page-locked buffer
-        bool more = packer.NextBatch(&batch, batch_reads, &err);
-        if (g_drain_stop || err.set) break;
-        if (!batch.tri.empty()) { { std::lock_guard<std::mutex> lk(mu); produced = ++i; } cv.notify_all(); }
-        if (!more) break;
-      }
-      { std::lock_guard<std::mutex> lk(mu); done = true; }
-      cv.notify_all();
-    });
-    for (long j = 0;; j++) {
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return produced > j || done; });
-        if (produced <= j) break;
-      }
-      const auto t0 = std::chrono::steady_clock::now();
-      sink(ring[(size_t)(j % K)]);
-      if (getenv("GTX_PACK_TRACE")) fprintf(stderr, "[sink] %zu reads handed over in %.1f ms\n", ring[(size_t)(j % K)].tri.size() / 3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-      { std::lock_guard<std::mutex> lk(mu); consumed = j + 1; }
-      cv.notify_all();
-    }
-    Helper::Wait();
-    if (err.set && !g_drain_stop) DiePack(err);                   // (the batches before the bad line have been handed over, as the reference would have processed them)
   };
   if (!set->load_in_memory && set->format == "GTX") {
     long int at = 0;

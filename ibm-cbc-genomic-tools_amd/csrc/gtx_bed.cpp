@@ -57,10 +57,10 @@ class Pool {
   static void Run(int n, const std::function<void(int)> &fn)
   {
     if (n <= 1) { if (n == 1) fn(0); return; }
-    static Pool pool;
-    pool.Go(n, fn);
+    Get().Go(n, fn);
   }
  private:
+  static Pool &Get() { static Pool pool; return pool; }
   std::vector<std::thread> workers_;
   std::mutex m_; std::condition_variable wake_, done_;
   const std::function<void(int)> *fn_ = nullptr; int n_ = 0, next_ = 0, left_ = 0; unsigned long gen_ = 0; bool stop_ = false;
