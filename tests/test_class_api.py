@@ -120,3 +120,49 @@ def test_the_fixture_is_not_vacuous(api_beds):
     out12 = subprocess.run([orc.CLI, "pairs", "-i", "refs12.bed", "reads12.bed"], capture_output=True, cwd=api_beds).stdout.decode().splitlines()
     gaps12 = subprocess.run([orc.CLI, "pairs", "-i", "-gaps", "refs12.bed", "reads12.bed"], capture_output=True, cwd=api_beds).stdout.decode().splitlines()
     assert len(gaps12) > len(out12) > 50                                       # -gaps matches pairs that only meet in a gap
+
+
+def _big_refs(path, n, bad=None):
+    """n sorted BED6 lines on chr1 (about 30 bytes each: more than one piece per block of the parallel loader); bad = {line: text}"""
+    with open(path, "w") as f:
+        for i in range(n):
+            if bad and i + 1 in bad:
+                f.write(bad[i + 1] + "\n")
+            else:
+                f.write("chr1\t%d\t%d\tr%d\t0\t+\n" % (10 * i, 10 * i + 25, i))
+
+
+@pytest.mark.parametrize("threads", ["1", "4", "13"])
+def test_in_memory_set_from_worker_threads(tmp_path, threads):
+    """GenomicRegionSet(load_in_memory) builds its region objects on several threads, a piece of every block each (csrc/
+    genomic_intervals.cpp: Init): the same regions in the same order with the same line numbers as the line-by-line reader (the
+    pairs of a sorted walk name them), whatever the number of threads."""
+    _big_refs(tmp_path / "refs.bed", 60_000)
+    with open(tmp_path / "q.bed", "w") as f:
+        for i in range(0, 60_000, 997):
+            f.write("chr1\t%d\t%d\tq%d\t0\t+\n" % (10 * i + 3, 10 * i + 40, i))
+    args = ["pairs", "-S", "-i", "refs.bed", "q.bed"]
+    want = subprocess.run([orc.CLI] + args, capture_output=True, cwd=tmp_path)
+    env = dict(os.environ, GTX_NO_WARMUP="1", GTX_LOAD_THREADS=threads)
+    got = subprocess.run([CALLER] + args, capture_output=True, cwd=tmp_path, env=env)
+    assert got.returncode == want.returncode == 0, got.stderr.decode()
+    assert got.stdout == want.stdout and len(got.stdout.splitlines()) > 150
+
+
+@pytest.mark.parametrize("threads", ["1", "4", "13"])
+def test_in_memory_set_reports_the_first_bad_line(tmp_path, threads):
+    """malformed lines in two different pieces: the error is the one of the smaller line number, as the line-by-line reader meets it"""
+    bad = {41_000: "chr1\t410000", 17_500: "chr1\t175000\t175025\tx\t0\t?", 55_000: "chr1"}
+    _big_refs(tmp_path / "refs.bed", 60_000, bad)
+    with open(tmp_path / "q.bed", "w") as f:
+        f.write("chr1\t5\t40\tq\t0\t+\n")
+    env = dict(os.environ, GTX_NO_WARMUP="1", GTX_LOAD_THREADS=threads)
+    got = subprocess.run([CALLER, "pairs", "-i", "refs.bed", "q.bed"], capture_output=True, cwd=tmp_path, env=env)
+    assert got.returncode == 1
+    assert got.stderr.decode().strip() == "Error: invalid strand '?'!"            # line 17500 (genomic_intervals.cpp:5956-5962)
+    bad.pop(17_500)
+    _big_refs(tmp_path / "refs.bed", 60_000, bad)
+    got = subprocess.run([CALLER, "pairs", "-i", "refs.bed", "q.bed"], capture_output=True, cwd=tmp_path, env=env)
+    want = subprocess.run([orc.CLI, "pairs", "-i", "refs.bed", "q.bed"], capture_output=True, cwd=tmp_path)
+    assert got.returncode == want.returncode == 1
+    assert got.stderr.decode().strip() == want.stderr.decode().strip() and "Line 41000" in got.stderr.decode()

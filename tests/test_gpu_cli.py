@@ -339,6 +339,24 @@ def test_peaks_cli_equals_oracle_cli(beds, args):
             assert len(got[1].splitlines()) >= 10      # the planted clusters are found
 
 
+def test_small_host_batches_give_the_same_output(beds, monkeypatch):
+    """GTX_HOST_BATCH_READS=700: the input sets go to the device in dozens of batches through two buffers that are used in turn --
+    totals that are summed over the batches (the label sums behind the background probability of `peaks`, the read count of `rpkm`)
+    and everything else come out as with one batch"""
+    runs = [("scans", PEAK_RUNS[0]), ("scans", PEAK_RUNS[2]), ("overlaps", ["count", "-i", "refs.bed", "reads_pos.bed"]),
+            ("overlaps", ["count", "-S", "-i", "refs.bed", "reads_pos.bed"]), ("overlaps", ["rpkm", "-i", "refs.bed", "reads_shuffled.bed.gz"]),
+            ("overlaps", ["coverage", "-i", "refs.bed", "reads_pos.bed"]), ("scans", SCAN_RUNS[0]), ("scans", SCAN_RUNS[3])]
+    for tool, args in runs:
+        cwd = beds
+        one = product(tool, args, cwd=cwd)
+        monkeypatch.setenv("GTX_HOST_BATCH_READS", "700")
+        many = product(tool, args, cwd=cwd)
+        monkeypatch.delenv("GTX_HOST_BATCH_READS")
+        assert one[0] == many[0] == 0, (args, many[2])
+        assert one[1] == many[1] and one[2] == many[2], args
+        assert len(one[1].splitlines()) > 5, args
+
+
 def test_peaks_finds_the_planted_clusters(beds):
     out = product("scans", ["peaks", "-i", "-g", "genome.bed", "-qval", "0.01", "peaks_signal.bed", "peaks_control.bed"], cwd=beds)[1].splitlines()
     assert len(out) > 100
