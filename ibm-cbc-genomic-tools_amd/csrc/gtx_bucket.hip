@@ -160,7 +160,7 @@ __global__ __launch_bounds__(1024, (WEIGHTED && PER == 4) ? 4 : 8) void bucket_s
         const unsigned i = tile * TB + k * 1024 + threadIdx.x;
         if (i < un && !want[k]) {
           if ((unsigned)rc[k] >= (unsigned)a.nClasses) nNoClass++;
-          else {
+          else if (!a.coverRule || rs[k] > re[k] + 1) {
             nDegen++; if (i < firstDegen) firstDegen = i;
             if (a.side) { const unsigned q = atomicAdd(a.sideCount, 1u); if (q < (unsigned)a.sideCap) a.side[q] = make_int4(rc[k], rs[k], re[k], rw[k]); }   // see CountArgs::side
           }
@@ -415,6 +415,79 @@ __global__ __launch_bounds__(1024) void bucket_count_kernel(CountArgs a, BucketT
   for (int i = threadIdx.x; i <= nS; i += blockDim.x) { const u64 v = hB[i]; if (v) atomicAdd(&a.histB[(i64)sLo + i + cls], v); }
 }
 
+// Coverage (CoverArgs: one threshold array, four histograms; a key x belongs to the slots at or below threshold T iff x <= T): the
+// bucket's cuts and its slice are both in sortedT, the slice beginning where the bucket does (a read ends at or behind its start).
+// Per read four LDS atomics: (w, w x start) at the rank of the start, (w, w x end) at the rank of the end; an end beyond the slice
+// goes to the global histograms.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(1024) void bucket_cover_kernel(CoverArgs cv, BucketTable t, BucketWork w, int splits)
+{
+  __shared__ int sT[kBktS];
+  __shared__ unsigned tT[kCellsS + 1];
+  __shared__ u64 hWs[kBktE + 1], hFs[kBktE + 1], hWe[kBktS + 1], hFe[kBktS + 1];
+  const int b = blockIdx.x / splits, k = blockIdx.x % splits;
+  const unsigned c0 = w.rowOff[b], nCh = w.rowOff[b + 1] - c0;   // the bucket's stretch of the chunk list
+  const unsigned r0 = c0 + (unsigned)((u64)nCh * k / splits), r1 = c0 + (unsigned)((u64)nCh * (k + 1) / splits);
+  if (r0 == r1) return;
+  const int sLo = t.sLo[b], sHi = t.sHi[b], nS = sHi - sLo, nE = t.eHi[b] - t.eLo[b], cls = t.cls[b];   // (t.eLo[b] == sLo)
+  const int segEnd = cv.segStartT[cls + 1];
+  for (int i = threadIdx.x; i < nS; i += blockDim.x) sT[i] = cv.sortedT[sLo + i];
+  for (int i = threadIdx.x; i <= nE; i += blockDim.x) { hWs[i] = 0; hFs[i] = 0; }
+  for (int i = threadIdx.x; i <= nS; i += blockDim.x) { hWe[i] = 0; hFe[i] = 0; }
+  __syncthreads();
+  const int loT = nS ? sT[0] : 0, shT = nS ? shift_for(loT, sT[nS - 1], kCellsS) : 0;
+  build_table(sT, nS, tT, kCellsS, loT, shT);
+  __syncthreads();
+  const int2 *__restrict__ reads = (const int2 *)w.tmpReads;
+  constexpr int U = 4;
+  const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nW = blockDim.x >> 6;
+  unsigned ent[U];
+  auto entries = [&](unsigned at) {
+#pragma unroll
+    for (int u = 0; u < U; u++) { const unsigned ci = at + u * nW; ent[u] = ci < r1 ? w.list[ci] : 0u; }
+  };
+  entries(r0 + wv);
+  for (unsigned at = r0 + wv; at < r1; at += U * nW) {
+    int2 se[U]; int wt4[U]; bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const unsigned e = ent[u], place = (e >> kChunkShift << kChunkShift) + lane;
+      se[u] = make_int2(0, -1); wt4[u] = 1;
+      on[u] = at + u * nW < r1 && lane <= (e & (kChunk - 1));
+      if (on[u]) { se[u] = reads[place]; if (WEIGHTED) wt4[u] = w.tmpWeights[place]; }
+    }
+    entries(at + U * nW);
+    int ks[U], ke[U], slotS[U], slotE[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { ks[u] = se[u].x; ke[u] = se[u].y; }
+    table_ranks<false, U>(sT, tT, kCellsS, loT, shT, ks, slotS);      // #{T < s} inside the slice
+    table_ranks<false, U>(sT, tT, kCellsS, loT, shT, ke, slotE);      // #{T < e}
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!on[u]) continue;
+      const u64 wt = WEIGHTED ? (u64)(i64)wt4[u] : 1;
+      atomicAdd(&hWs[slotS[u]], wt); atomicAdd(&hFs[slotS[u]], wt * (u64)(i64)ks[u]);
+      if (slotE[u] < nS || sHi == segEnd) { atomicAdd(&hWe[slotE[u]], wt); atomicAdd(&hFe[slotE[u]], wt * (u64)(i64)ke[u]); }
+      else {                                                          // the read ends beyond the slice: global search above it
+        int glo = sHi, ghi = segEnd;
+        while (glo < ghi) { const int mid = (int)(((i64)glo + ghi) >> 1); if (cv.sortedT[mid] < ke[u]) glo = mid + 1; else ghi = mid; }
+        atomicAdd(&cv.hist[2][(i64)glo + cls], wt); atomicAdd(&cv.hist[3][(i64)glo + cls], wt * (u64)(i64)ke[u]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= nE; i += blockDim.x) {
+    const u64 a0 = hWs[i], a1 = hFs[i];
+    if (a0) atomicAdd(&cv.hist[0][(i64)sLo + i + cls], a0);
+    if (a1) atomicAdd(&cv.hist[1][(i64)sLo + i + cls], a1);
+  }
+  for (int i = threadIdx.x; i <= nS; i += blockDim.x) {
+    const u64 a0 = hWe[i], a1 = hFe[i];
+    if (a0) atomicAdd(&cv.hist[2][(i64)sLo + i + cls], a0);
+    if (a1) atomicAdd(&cv.hist[3][(i64)sLo + i + cls], a1);
+  }
+}
+
 int bucket_e_size() { return kBktE; }
 int bucket_s_size() { return kBktS; }
 
@@ -453,10 +526,10 @@ BucketPlan bucket_plan(i64 n, int nClasses, int nB, int nCells, bool weighted)
   return p;
 }
 
-hipError_t launch_count_bucketed(const void *reads, const void *weights, i64 n, const CountArgs &a, const BucketTable &t, const BucketWork &w,
-                                 const BucketPlan &p, hipStream_t st)
+// the partition: scatter pass, chunk list
+static hipError_t launch_partition(const void *reads, const void *weights, i64 n, const CountArgs &a, const BucketTable &t, const BucketWork &w,
+                                   const BucketPlan &p, hipStream_t st)
 {
-  if (n <= 0) return hipSuccess;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipSuccess;
@@ -474,14 +547,41 @@ hipError_t launch_count_bucketed(const void *reads, const void *weights, i64 n, 
   chunk_rows_kernel<<<(unsigned)t.nB, 256, 0, st>>>(w, p.blocks);
   chunk_offsets_kernel<<<1, 1024, 0, st>>>(w, t.nB);     // (one more launch: the block of chunk_rows_kernel that finishes last doing it was slower, 540 blocks adding to one counter)
   chunk_place_kernel<<<p.blocks, 1024, sizeof(unsigned) * (size_t)t.nB, st>>>(t, w, p.blocks);
+  return hipGetLastError();
+}
+
+static i64 count_splits(i64 n, int nB)
+{
   // blocks of ~128k reads on average, at least one per bucket (100 M reads, whole path: 32 k 1.17 ms, 64 k 1.12, 128 k 1.085, 256 k 1.10:
   // the tables are built per block)
   static const i64 perBlock = getenv("GTX_COUNT_BLOCK_READS") ? atoll(getenv("GTX_COUNT_BLOCK_READS")) : 131072;
-  i64 splits = (n + (i64)t.nB * perBlock - 1) / ((i64)t.nB * perBlock);
+  i64 splits = (n + (i64)nB * perBlock - 1) / ((i64)nB * perBlock);
   if (splits < 1) splits = 1;
   if (splits > 512) splits = 512;
+  return splits;
+}
+
+hipError_t launch_count_bucketed(const void *reads, const void *weights, i64 n, const CountArgs &a, const BucketTable &t, const BucketWork &w,
+                                 const BucketPlan &p, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipError_t e = launch_partition(reads, weights, n, a, t, w, p, st);
+  if (e != hipSuccess) return e;
+  const i64 splits = count_splits(n, t.nB);
   if (weights) bucket_count_kernel<true><<<(unsigned)(t.nB * splits), 1024, 0, st>>>(a, t, w, (int)splits);
   else bucket_count_kernel<false><<<(unsigned)(t.nB * splits), 1024, 0, st>>>(a, t, w, (int)splits);
+  return hipGetLastError();
+}
+
+hipError_t launch_cover_bucketed(const void *reads, const void *weights, i64 n, const CountArgs &a, const CoverArgs &cv, const BucketTable &t,
+                                 const BucketWork &w, const BucketPlan &p, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipError_t e = launch_partition(reads, weights, n, a, t, w, p, st);
+  if (e != hipSuccess) return e;
+  const i64 splits = count_splits(n, t.nB);
+  if (weights) bucket_cover_kernel<true><<<(unsigned)(t.nB * splits), 1024, 0, st>>>(cv, t, w, (int)splits);
+  else bucket_cover_kernel<false><<<(unsigned)(t.nB * splits), 1024, 0, st>>>(cv, t, w, (int)splits);
   return hipGetLastError();
 }
 

@@ -33,6 +33,8 @@ struct gtx_ctx {
   int *d_topE = nullptr, *d_topS = nullptr;   // every 256th boundary: first hop of the streaming kernel's start-of-span search
   // unsorted reads, bucket path (gtx_bucket.hip): table built with the references, scratch sized by the largest call
   void *d_clsCell = nullptr, *d_cellTab = nullptr; int nCells = 0, cellShift = 0;   // direct-address bucket lookup (BucketTable)
+  int *d_bktT = nullptr; void *d_clsCellT = nullptr, *d_cellTabT = nullptr; int nBT = 0, nCellsT = 0, cellShiftT = 0;   // the same tables over the coverage thresholds (cover_prepare)
+  bool covTileSums = true;                           // false: a batch went through the partition path, the tile sums are rebuilt before the finalize step
   int *d_bkt = nullptr; int nB = 0;                  // posHi | eLo | eHi | sLo | sHi | cls (nB each) | clsStart (nClasses+1)
   unsigned *d_bktCnt = nullptr, *d_bktDir = nullptr; size_t capBktMatrix = 0;   // scratch of the bucket path (gtx::BucketWork)
   void *d_bktReads = nullptr; int *d_bktWeights = nullptr; size_t capBkt = 0;
@@ -153,7 +155,7 @@ void gtx_destroy(gtx_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
-  dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab);
+  dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab); dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   for (int k = 0; k < 2; k++) {
@@ -420,13 +422,43 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int
   a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0; a.prefetch = c->prefetch;
   a.zeroLenOk = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   const bool merge = (flags & GTX_ZERO_LENGTH_OK) && c->mergeRefs && c->d_side;       // full sorted-merge semantics (see merge_prepare)
-  a.side = merge ? c->d_side : nullptr; a.sideCount = merge ? c->d_sideCount : nullptr; a.sideCap = c->sideCap;
+  a.side = merge ? c->d_side : nullptr; a.sideCount = merge ? c->d_sideCount : nullptr; a.sideCap = c->sideCap; a.coverRule = 0;
   a.sampE = c->d_sampE; a.sampS = c->d_sampS; a.sampShift = c->sampShift; a.nSamp = c->nSamp;
   a.topE = c->d_topE; a.topS = c->d_topS;
   // dense references (>= 4 boundaries per 256 reads and array): all boundaries of a window at once instead of the
   // per-boundary loop (100 M reads x 4 M regions: 0.41 -> 0.28 ms; at 1 M regions the loop is 3 % faster).  GTX_FLIP=0|1 forces.
   { static const char *fl = getenv("GTX_FLIP"); a.flip = fl ? atoi(fl) : (c->nValid * 256 >= 4 * std::max<int64_t>(nReads, 1)); }
   return a;
+}
+
+// scratch of the partition path for a call of plan p (grown, never shrunk), and the views the kernels take
+static int bucket_scratch(gtx_ctx *c, const gtx::BucketPlan &p, int nB, gtx::BucketWork *w)
+{
+  if (p.pairs > c->capBkt) {
+    dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); c->capBkt = 0;
+    HIPCHK(c, hipMalloc(&c->d_bktReads, 8 * p.pairs));
+    HIPCHK(c, hipMalloc(&c->d_bktWeights, 4 * p.pairs));
+    HIPCHK(c, hipMalloc(&c->d_bktDir, 4 * 2 * p.chunks));             // directory | list
+    c->capBkt = p.pairs;
+  }
+  const size_t words = p.matrix + p.blocks + (size_t)nB + 1;         // chunkCount | arenaUsed | rowOff
+  if (words > c->capBktMatrix) {
+    dfree(c->d_bktCnt); c->capBktMatrix = 0;
+    HIPCHK(c, hipMalloc(&c->d_bktCnt, 4 * words));
+    c->capBktMatrix = words;
+  }
+  w->tmpReads = c->d_bktReads; w->tmpWeights = c->d_bktWeights; w->arenaPairs = (unsigned)p.arenaPairs;
+  w->dir = c->d_bktDir; w->list = c->d_bktDir + c->capBkt / 64; w->chunkCount = c->d_bktCnt; w->arenaUsed = c->d_bktCnt + p.matrix; w->rowOff = w->arenaUsed + p.blocks;
+  return GTX_OK;
+}
+
+static gtx::BucketTable bucket_table(const int *d_bkt, int nB, const void *clsCell, const void *cellTab, int nCells, int cellShift)
+{
+  gtx::BucketTable t;
+  t.posHi = d_bkt; t.eLo = d_bkt + nB; t.eHi = d_bkt + 2 * nB; t.sLo = d_bkt + 3 * nB; t.sHi = d_bkt + 4 * nB;
+  t.cls = d_bkt + 5 * nB; t.clsStart = d_bkt + 6 * nB; t.nB = nB;
+  t.clsCell = (const int4 *)clsCell; t.cellTab = (const unsigned short *)cellTab; t.nCells = nCells; t.cellShift = cellShift;
+  return t;
 }
 
 // reads in no particular order: bucket partition + LDS counting for large batches, per-read search kernel otherwise
@@ -438,27 +470,9 @@ static int launch_unsorted(gtx_ctx *c, const void *d_reads, const void *d_weight
   }
   const gtx::BucketPlan p = gtx::bucket_plan(n, a.nClasses, c->nB, c->nCells, d_weights != nullptr);
   if (p.pairs >= (1ull << 32)) { HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, a, false, c->stream)); return GTX_OK; }
-  if (p.pairs > c->capBkt) {
-    dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); c->capBkt = 0;
-    HIPCHK(c, hipMalloc(&c->d_bktReads, 8 * p.pairs));
-    HIPCHK(c, hipMalloc(&c->d_bktWeights, 4 * p.pairs));
-    HIPCHK(c, hipMalloc(&c->d_bktDir, 4 * 2 * p.chunks));             // directory | list
-    c->capBkt = p.pairs;
-  }
-  const size_t words = p.matrix + p.blocks + (size_t)c->nB + 1;     // chunkCount | arenaUsed | rowOff
-  if (words > c->capBktMatrix) {
-    dfree(c->d_bktCnt); c->capBktMatrix = 0;
-    HIPCHK(c, hipMalloc(&c->d_bktCnt, 4 * words));
-    c->capBktMatrix = words;
-  }
-  gtx::BucketTable t;
-  const int nB = c->nB;
-  t.posHi = c->d_bkt; t.eLo = c->d_bkt + nB; t.eHi = c->d_bkt + 2 * nB; t.sLo = c->d_bkt + 3 * nB; t.sHi = c->d_bkt + 4 * nB;
-  t.cls = c->d_bkt + 5 * nB; t.clsStart = c->d_bkt + 6 * nB; t.nB = nB;
-  t.clsCell = (const int4 *)c->d_clsCell; t.cellTab = (const unsigned short *)c->d_cellTab; t.nCells = c->nCells; t.cellShift = c->cellShift;
   gtx::BucketWork w;
-  w.tmpReads = c->d_bktReads; w.tmpWeights = c->d_bktWeights; w.arenaPairs = (unsigned)p.arenaPairs;
-  w.dir = c->d_bktDir; w.list = c->d_bktDir + c->capBkt / 64; w.chunkCount = c->d_bktCnt; w.arenaUsed = c->d_bktCnt + p.matrix; w.rowOff = w.arenaUsed + p.blocks;
+  { int rc = bucket_scratch(c, p, c->nB, &w); if (rc) return rc; }
+  const gtx::BucketTable t = bucket_table(c->d_bkt, c->nB, c->d_clsCell, c->d_cellTab, c->nCells, c->cellShift);
   HIPCHK(c, gtx::launch_count_bucketed(d_reads, d_weights, n, a, t, w, p, c->stream));
   return GTX_OK;
 }
@@ -769,6 +783,67 @@ int gtx_count(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t 
 // ---------------------------------------------------------------------------------------------
 // coverage
 // ---------------------------------------------------------------------------------------------
+// bucket tables over ONE sorted array (the coverage thresholds): cuts every bucket_e_size() entries, never across classes; the slice
+// a bucket keeps in LDS begins where the bucket does (a read ends at or behind its start) -- see the same for the two boundary
+// arrays of the count path in gtx_set_refs_ex
+static int cover_bucket_tables(gtx_ctx *c, const std::vector<int32_t> &sortedT, const std::vector<int32_t> &seg)
+{
+  const int nClasses = c->nClasses;
+  const int kE = gtx::bucket_e_size(), kS = gtx::bucket_s_size();
+  std::vector<int32_t> posHi, eLo, eHi, sLo, sHi, cls, clsStart(nClasses + 1, 0);
+  for (int cl = 0; cl < nClasses; cl++) {
+    clsStart[cl] = (int32_t)posHi.size();
+    const int32_t s0 = seg[cl], s1 = seg[cl + 1];
+    for (int32_t e0 = s0; e0 < s1; e0 += kE) {
+      const int32_t e1 = (int32_t)std::min<int64_t>((int64_t)e0 + kE, s1);
+      posHi.push_back(e1 == s1 ? INT32_MAX : sortedT[e1 - 1]);
+      eLo.push_back(e0); eHi.push_back(e1); cls.push_back(cl);
+      sLo.push_back(e0); sHi.push_back((int32_t)std::min<int64_t>((int64_t)e0 + kS, s1));
+    }
+  }
+  clsStart[nClasses] = (int32_t)posHi.size();
+  c->nBT = (int)posHi.size();
+  if (c->nBT > 8192 || nClasses > 2048) c->nBT = 0;
+  if (c->nBT == 0) return GTX_OK;
+  const int kCells = 4096;
+  int sh = 0;
+  auto cellsAt = [&](int shift) {
+    int64_t total = 0;
+    for (int cl = 0; cl < nClasses; cl++) {
+      const int b0 = clsStart[cl], b1 = clsStart[cl + 1];
+      total += b1 - b0 <= 1 ? b1 - b0 : ((((int64_t)posHi[b1 - 2] - posHi[b0]) >> shift) + 1);
+    }
+    return total;
+  };
+  while (sh < 40 && cellsAt(sh) > kCells) sh++;
+  std::vector<int32_t> clsCell(4 * (size_t)nClasses);
+  std::vector<uint16_t> cellTab;
+  for (int cl = 0; cl < nClasses; cl++) {
+    const int b0 = clsStart[cl], b1 = clsStart[cl + 1];
+    const int32_t lo = b1 - b0 <= 1 ? 0 : posHi[b0];
+    const int64_t nc = b1 == b0 ? 0 : b1 - b0 == 1 ? 1 : ((((int64_t)posHi[b1 - 2] - lo) >> sh) + 1);
+    clsCell[4 * cl] = (int32_t)cellTab.size(); clsCell[4 * cl + 1] = lo; clsCell[4 * cl + 2] = (int32_t)nc; clsCell[4 * cl + 3] = b0;
+    int b = b0;
+    for (int64_t k = 0; k < nc; k++) {
+      const int64_t first = (int64_t)lo + (k << sh);
+      while (b < b1 - 1 && (int64_t)posHi[b] < first) b++;
+      cellTab.push_back((uint16_t)(b - b0));
+    }
+  }
+  c->nCellsT = (int)cellTab.size(); c->cellShiftT = sh;
+  if (!gtx::bucket_tables_fit(nClasses, c->nBT, c->nCellsT)) { c->nBT = 0; return GTX_OK; }
+  cellTab.push_back(0);
+  std::vector<int32_t> all;
+  for (auto *v : {&posHi, &eLo, &eHi, &sLo, &sHi, &cls, &clsStart}) all.insert(all.end(), v->begin(), v->end());
+  HIPCHK(c, hipMalloc(&c->d_bktT, sizeof(int32_t) * all.size()));
+  HIPCHK(c, hipMemcpy(c->d_bktT, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMalloc(&c->d_clsCellT, sizeof(int32_t) * clsCell.size() + 16));
+  HIPCHK(c, hipMemcpy(c->d_clsCellT, clsCell.data(), sizeof(int32_t) * clsCell.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMalloc(&c->d_cellTabT, sizeof(uint16_t) * cellTab.size()));
+  HIPCHK(c, hipMemcpy(c->d_cellTabT, cellTab.data(), sizeof(uint16_t) * cellTab.size(), hipMemcpyHostToDevice));
+  return GTX_OK;
+}
+
 static int cover_prepare(gtx_ctx *c)
 {
   if (c->covReady) return GTX_OK;
@@ -821,6 +896,7 @@ static int cover_prepare(gtx_ctx *c)
     HIPCHK(c, hipMemset(c->d_cov[4 + q], 0, sizeof(u64) * (nTiles + 2)));
   }
   { int rc = ref_columns(c); if (rc) return rc; }
+  { int rc = cover_bucket_tables(c, sortedT, seg); if (rc) return rc; }
   c->covReady = true; c->covDirty = false;
   return GTX_OK;
 }
@@ -860,8 +936,44 @@ static int cover_begin(gtx_ctx *c)
     }
   }
   c->sideUsed = false;
-  c->covDirty = true;
+  c->covDirty = true; c->covTileSums = true;
   return GTX_OK;
+}
+
+// One batch of reads into the four coverage histograms: the streaming kernel (exact for any order, fast for sorted reads), or --
+// for a batch the caller (GTX_READS_UNSORTED) or a sample of the host buffer says is in no particular order -- the partition path.
+static int cover_launch(gtx_ctx *c, const void *dR, const int *dW, int64_t n, int64_t indexBase, uint32_t flags, bool unsorted)
+{
+  const gtx::CoverArgs cv = cover_args(c, n, indexBase, flags);
+  if (unsorted && c->nBT > 0 && n >= c->bucketMinReads && n < (1ll << 31)) {
+    const gtx::BucketPlan p = gtx::bucket_plan(n, c->nClasses, c->nBT, c->nCellsT, dW != nullptr);
+    if (p.pairs < (1ull << 32)) {
+      gtx::BucketWork w;
+      { int rc = bucket_scratch(c, p, c->nBT, &w); if (rc) return rc; }
+      const gtx::BucketTable t = bucket_table(c->d_bktT, c->nBT, c->d_clsCellT, c->d_cellTabT, c->nCellsT, c->cellShiftT);
+      gtx::CountArgs a = {};                                        // what the partition pass reads of it
+      a.nClasses = c->nClasses; a.zeroLenOk = 0; a.coverRule = 1; a.info = cv.info; a.indexBase = indexBase;
+      a.side = cv.side; a.sideCount = cv.sideCount; a.sideCap = cv.sideCap;
+      HIPCHK(c, gtx::launch_cover_bucketed(dR, dW, n, a, cv, t, w, p, c->stream));
+      c->covTileSums = false;
+      return GTX_OK;
+    }
+  }
+  HIPCHK(c, gtx::launch_coverage(dR, dW, n, cv, c->stream));
+  return GTX_OK;
+}
+
+// a host buffer's order, from 4096 adjacent pairs: a few descents are a few sorted runs (still the streaming kernel's business)
+static bool host_reads_look_unsorted(const int32_t *tri, int64_t n)
+{
+  if (n < 2) return false;
+  const int64_t stride = n > 4096 ? n / 4096 : 1;
+  int descents = 0;
+  for (int64_t i = 0; i + 1 < n; i += stride) {
+    const int32_t *a = tri + 3 * i, *b = a + 3;
+    if ((b[0] < a[0] || (b[0] == a[0] && b[1] < a[1])) && ++descents > 8) return true;
+  }
+  return false;
 }
 
 static int cover_end(gtx_ctx *c, void *d_cov_out)
@@ -869,6 +981,8 @@ static int cover_end(gtx_ctx *c, void *d_cov_out)
   gtx::CoverGather g;
   for (int q = 0; q < 4; q++) { g.pref[q] = c->d_cov[8 + q]; g.part[q] = c->d_cov[4 + q]; }
   g.posTE = c->d_posTE; g.posTS = c->d_posTS; g.classBaseT = c->d_classBaseT; g.refS = c->d_refS; g.refE = c->d_refE;
+  if (!c->covTileSums)                                               // (the partition path does not keep them)
+    for (int q = 0; q < 4; q += 2) HIPCHK(c, gtx::launch_tile_sums(c->d_cov[q], c->d_cov[q + 1], c->histLenT, c->d_cov[4 + q], c->d_cov[5 + q], c->stream));
   HIPCHK(c, gtx::launch_coverage_finalize(cover_args(c, 0), c->histLenT, g, c->nRefs, (u64 *)d_cov_out, c->d_info + (c->infoCur ^ 1), c->stream));
   { int rc = merge_end(c, d_cov_out); if (rc) return rc; }
   c->covDirty = false;
@@ -886,7 +1000,7 @@ int gtx_coverage_device(gtx_ctx *c, const void *d_reads, const void *d_weights, 
   c->profThis = c->prof && (c->profEvery <= 1 || (c->profSeq++ % c->profEvery) == 0);
   if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
   if (flags & GTX_GAPS_FORMULA) { rc = merge_prepare(c, flags, 2); if (rc) return rc; }
-  HIPCHK(c, gtx::launch_coverage(d_reads, d_weights, n, cover_args(c, n, 0, flags), c->stream));
+  rc = cover_launch(c, d_reads, (const int *)d_weights, n, 0, flags, (flags & GTX_READS_UNSORTED) != 0); if (rc) return rc;
   rc = merge_batch(c, d_reads, d_weights, n); if (rc) return rc;
   if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   rc = cover_end(c, d_cov); if (rc) return rc;
@@ -914,7 +1028,8 @@ int gtx_coverage_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, i
   int rc = GTX_OK;
   if (flags & GTX_GAPS_FORMULA) { rc = merge_prepare(c, flags, 2); if (rc) return rc; }
   rc = stage_batches(c, reads, weights, n, [&](const void *dR, const int *dW, int64_t cnt, int64_t off) -> int {
-    HIPCHK(c, gtx::launch_coverage(dR, dW, cnt, cover_args(c, cnt, seen + off, flags), c->stream));
+    const bool unsorted = (flags & GTX_READS_UNSORTED) || (!(flags & GTX_READS_SORTED) && host_reads_look_unsorted(reads + 3 * off, cnt));
+    { int rc2 = cover_launch(c, dR, dW, cnt, seen + off, flags, unsorted); if (rc2) return rc2; }
     return merge_batch(c, dR, dW, cnt);
   });
   if (rc) return rc;

@@ -40,6 +40,8 @@ struct CountArgs {
   // by its two comparisons like any other read (genomic_intervals.cpp:1225-1236).  The rank difference does not hold for
   // them, so the kernels set them aside here (class, start, end, weight) for the pair kernels of gtx_special.hip.
   int4 *side; unsigned *sideCount; int sideCap;
+  int coverRule;                 // the partition pass of the coverage path: a zero-length read (start == end + 1) is dropped silently, only
+                                 // inverted ones (start > end + 1) are reported and set aside -- as coverage_walk_kernel does
 };
 
 // coverage: ONE boundary array per class -- the thresholds E_k and S_k - 1 of all its regions, merged and sorted (sortedT) --
@@ -107,6 +109,12 @@ int bucket_e_size();
 int bucket_s_size();
 hipError_t launch_count_bucketed(const void *reads, const void *weights, long long n, const CountArgs &a, const BucketTable &t,
                                  const BucketWork &w, const BucketPlan &p, hipStream_t st);
+// coverage of reads in no particular order: the same partition over a bucket table of the THRESHOLD array (cuts and slices both
+// in sortedT), then per bucket the four histograms of CoverArgs in LDS.  The tile sums are NOT kept: launch_tile_sums before the
+// finalize step.
+hipError_t launch_cover_bucketed(const void *reads, const void *weights, long long n, const CountArgs &a, const CoverArgs &cv, const BucketTable &t,
+                                 const BucketWork &w, const BucketPlan &p, hipStream_t st);
+hipError_t launch_tile_sums(unsigned long long *histA, unsigned long long *histB, long long histLen, unsigned long long *tileA, unsigned long long *tileB, hipStream_t st);
 
 // ---- intervals the rank difference does not cover (gtx_special.hip): plain pair tests, reference semantics of the sorted merge
 // value of a matching pair: mode 0 = w (count), mode 2 = w x (min(ends) - max(starts) + 1), the unclamped -gaps formula of

@@ -1647,6 +1647,13 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
   return hipGetLastError();
 }
 
+hipError_t launch_tile_sums(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, hipStream_t st)
+{
+  const int nb = scan_tiles(histLen);
+  if (nb > 0) tile_sums_kernel<<<dim3(nb, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB);
+  return hipGetLastError();
+}
+
 hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, bool tileSumsValid, u64 *prefA, u64 *prefB,
                            const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, DevInfo *nextInfo, hipStream_t st)
 {

@@ -16,6 +16,7 @@ READS_SORTED = 1
 CHECK_SORTED = 2
 ZERO_LENGTH_OK = 4
 GAPS_FORMULA = 8
+READS_UNSORTED = 16
 REFS_KEEP_ZERO_LENGTH = 1
 
 _lib = None

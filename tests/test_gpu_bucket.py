@@ -158,3 +158,49 @@ def test_more_classes_than_the_lookup_tables_take(beng):
     qs = rng.integers(1, 100_000, size=n)
     reads = np.stack([rng.integers(0, n_classes + 5, size=n), qs, qs + rng.integers(0, 300, size=n)], axis=1).astype(np.int32)
     check(beng, refs, reads, n_classes)
+
+
+# ---- coverage through the partition path (bucket_cover_kernel): reads in no particular order, flags without the sorted hint ----
+def check_cov(e, refs, reads, n_classes, w=None, flags=0):
+    e.set_refs(refs, n_classes)
+    got, info = e.coverage(reads, w, flags)
+    sel = reads[:, 0] < n_classes
+    want = orc.coverage(refs, reads[sel], None if w is None else w[sel], algo=orc.BIN_INDEX)
+    np.testing.assert_array_equal(got, want)
+    return info
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_coverage_fuzz_small_tables(beng, seed):
+    rng = np.random.default_rng(9100 + seed)
+    for _ in range(8):
+        n = int(rng.choice([1, 63, 257, 1000, 5000]))
+        m = int(rng.choice([0, 1, 2, 64, 500, 3000, 9000]))
+        n_classes = int(rng.choice([1, 2, 5, 40]))
+        span = int(rng.choice([10, 300, 100000]))
+        refs, reads = gen(rng, n, m, n_classes, span, allow_invalid_refs=True)
+        reads = reads[reads[:, 1] <= reads[:, 2]]                    # (inverted reads are the merge's business: test_gpu_count / CLI tests)
+        if len(reads) == 0:
+            continue
+        for r in orders(rng, reads):
+            check_cov(beng, refs, r, n_classes, flags=gtx.READS_UNSORTED)
+        w = rng.integers(-2, 6, size=len(reads)).astype(np.int32)
+        p = rng.permutation(len(reads))
+        check_cov(beng, refs, reads[p], n_classes, w[p], flags=gtx.READS_UNSORTED)
+
+
+def test_coverage_shuffled_large(beng):
+    # 300 k regions (600 k thresholds: ~300 buckets), 2 M shuffled reads of 20-4000 bp: ends beyond the slice, one chromosome without
+    # regions, the host-side sample decides (flags = 0), and the same call again in sorted order through the streaming kernel
+    rng = np.random.default_rng(15)
+    refs = synth.genome_intervals(300_000, 5, 50, 2000)
+    refs = refs[refs[:, 0] != 7]
+    reads = synth.genome_intervals(2_000_000, 6, 20, 4000)
+    shuf = reads[rng.permutation(len(reads))]
+    check_cov(beng, refs, shuf, synth.n_classes())
+    w = rng.integers(0, 4, size=len(reads)).astype(np.int32)
+    check_cov(beng, refs, shuf, synth.n_classes(), w)
+    check_cov(beng, refs, reads, synth.n_classes(), w, flags=gtx.READS_SORTED)
+    # count and coverage in turn on one context: neither disturbs the other's zeroed state
+    check(beng, refs, shuf, synth.n_classes())
+    check_cov(beng, refs, shuf, synth.n_classes())
