@@ -22,14 +22,14 @@ def sha16(files=("gtx_kernels.hip", "gtx_kernels.h", "gtx_capi.hip")):
 for a in ("bench_line", "bench_scans_line", "bench_perm_line", "bench_c5_line", "bench_line_under_rocprof"):
     if os.path.exists(src + a + ".json") and os.path.getsize(src + a + ".json"):
         shutil.copy(src + a + ".json", R + "profiles/%s_%s.json" % (rnd, a))
-for tag, name in (("stats", "bench"), ("stats_scans", "bench_scans"), ("stats_perm", "bench_perm"), ("stats_c5", "c5_bench"), ("stats_bucket", "bucket"),
+for tag, name in (("stats", "bench"), ("stats_scans", "bench_scans"), ("stats_perm", "bench_perm"), ("stats_c5", "c5_bench"), ("stats_bucket", "bucket"), ("stats_covshuf", "cov_shuffled"),
                   ("stats_cov", "coverage"), ("stats_scanfine", "scan_geometries")):
     f = newest(src + tag + "/*/*kernel_stats.csv")
     if f:
         shutil.copy(f, R + "profiles/%s_%s_kernel_stats.csv" % (rnd, name))
-for log in ("bench_bucket.log", "bench_cov.log", "bench_scan.log"):
+for log in ("bench_bucket.log", "bench_cov.log", "bench_scan.log", "bench_covshuf.log", "bench_scanshuf.log"):
     if os.path.exists(src + log):
-        keep = [l for l in open(src + log) if ("bucket path" in l or "coverage:" in l or "scan -w" in l or "bit-equal" in l)]
+        keep = [l for l in open(src + log) if ("bucket path" in l or "coverage:" in l or "coverage, " in l or "scan -w" in l or "bit-equal" in l)]
         open(R + "profiles/%s_%s.txt" % (rnd, log[:-4]), "w").write("".join(keep))
 
 

@@ -19,6 +19,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c5 -- python3
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_bucket -- python3 scripts/bench_bucket.py > $out/bench_bucket.log 2>&1 && echo "bucket stats ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_cov -- python3 tests/tools/bench_coverage.py > $out/bench_cov.log 2>&1 && echo "coverage stats ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_scanfine -- python3 scripts/bench_scan.py > $out/bench_scan.log 2>&1 && echo "scan geometry stats ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_covshuf -- python3 scripts/bench_cov_shuffled.py > $out/bench_covshuf.log 2>&1 && echo "coverage (shuffled reads) stats ok"
+python3 scripts/bench_scan_shuffled.py > $out/bench_scanshuf.log 2>&1 && echo "scans (shuffled reads) ok"
 step "pmc"
 pmc() { name=$1; ctr=$2; shift 2; rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_$name -- "$@" > $out/pmc_$name.log 2>&1 && echo "pmc $name ok"; }
 Q="--no-e2e --cpu-sample 0 --steps 3 --warmup 1"
@@ -31,5 +33,5 @@ pmc bucket_fetch FETCH_SIZE python3 scripts/bench_bucket.py
 pmc bucket_write WRITE_SIZE python3 scripts/bench_bucket.py
 pmc cov_fetch FETCH_SIZE python3 tests/tools/bench_coverage.py
 pmc cov_write WRITE_SIZE python3 tests/tools/bench_coverage.py
-grep -h "bucket path\|coverage:\|scan -w" $out/bench_bucket.log $out/bench_cov.log $out/bench_scan.log
+grep -h "bucket path\|coverage:\|coverage, \|scan -w" $out/bench_bucket.log $out/bench_cov.log $out/bench_scan.log $out/bench_covshuf.log $out/bench_scanshuf.log
 echo "refresh done"
