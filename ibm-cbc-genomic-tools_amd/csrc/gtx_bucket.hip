@@ -488,6 +488,63 @@ __global__ __launch_bounds__(1024) void bucket_cover_kernel(CoverArgs cv, Bucket
   }
 }
 
+// genomic_scans counts (unsorted rule, start positions): one part = some consecutive micro-windows of a bucket; the block reads ALL
+// chunks of the bucket (they come from the L2 for the second and later parts of a bucket) and counts the reads of its own
+// micro-windows in LDS -- no bucket is wider than a few parts.  (pos - 1) / step as in scan_slot (gtx_kernels.hip).
+static constexpr int kScanBins32 = 30720, kScanBins64 = 15360;   // 120 KB of LDS counters
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(1024) void bucket_scanhist_kernel(ScanArgs sc, BucketTable t, BucketWork w, const ScanPart *__restrict__ parts)
+{
+  typedef typename std::conditional<WEIGHTED, u64, unsigned>::type ct;
+  extern __shared__ unsigned char ldsRaw[];
+  ct *h = (ct *)ldsRaw;
+  const ScanPart pt = parts[blockIdx.x];
+  const int b = pt.bucket, cls = t.cls[b];
+  const unsigned r0 = w.rowOff[b], r1 = w.rowOff[b + 1];
+  if (r0 == r1) return;
+  for (int i = threadIdx.x; i < pt.count; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  const i64 nm = sc.nMicro[cls];
+  const unsigned d = (unsigned)sc.winStep;
+  const int2 *__restrict__ reads = (const int2 *)w.tmpReads;
+  constexpr int U = 4;
+  const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nW = blockDim.x >> 6;
+  unsigned ent[U];
+  auto entries = [&](unsigned at) {
+#pragma unroll
+    for (int u = 0; u < U; u++) { const unsigned ci = at + u * nW; ent[u] = ci < r1 ? w.list[ci] : 0u; }
+  };
+  entries(r0 + wv);
+  for (unsigned at = r0 + wv; at < r1; at += U * nW) {
+    int2 se[U]; int wt4[U]; bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const unsigned e = ent[u], place = (e >> kChunkShift << kChunkShift) + lane;
+      se[u] = make_int2(0, -1); wt4[u] = 1;
+      on[u] = at + u * nW < r1 && lane <= (e & (kChunk - 1));
+      if (on[u]) { se[u] = reads[place]; if (WEIGHTED) wt4[u] = w.tmpWeights[place]; }
+    }
+    entries(at + U * nW);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!on[u] || se[u].x < 1 || se[u].y <= 0) continue;           // the unsorted scanner's rule: start <= stop (the partition's), stop > 0, position >= 1
+      const unsigned x = (unsigned)(se[u].x - 1);
+      unsigned q = d == 1 ? x : __umulhi(x, sc.winStepInv);
+      unsigned r = x - q * d;
+      if (r >= d) { q++; r -= d; }
+      if (r >= d) q++;
+      const i64 m = (i64)q - pt.first;
+      if ((i64)q < nm && m >= 0 && m < pt.count) atomicAdd(&h[m], WEIGHTED ? (ct)(i64)wt4[u] : (ct)1);
+    }
+  }
+  __syncthreads();
+  ct *dst = (ct *)sc.micro + sc.microOff[cls] + pt.first;
+  for (int i = threadIdx.x; i < pt.count; i += blockDim.x) { const ct v = h[i]; if (v) atomicAdd(&dst[i], v); }
+}
+
+int scan_part_bins(bool weighted) { return weighted ? kScanBins64 : kScanBins32; }
+
 int bucket_e_size() { return kBktE; }
 int bucket_s_size() { return kBktS; }
 
@@ -570,6 +627,25 @@ hipError_t launch_count_bucketed(const void *reads, const void *weights, i64 n, 
   const i64 splits = count_splits(n, t.nB);
   if (weights) bucket_count_kernel<true><<<(unsigned)(t.nB * splits), 1024, 0, st>>>(a, t, w, (int)splits);
   else bucket_count_kernel<false><<<(unsigned)(t.nB * splits), 1024, 0, st>>>(a, t, w, (int)splits);
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_bucketed(const void *reads, const void *weights, i64 n, const CountArgs &a, const ScanArgs &sc, const BucketTable &t,
+                                const BucketWork &w, const BucketPlan &p, const ScanPart *parts, int nParts, hipStream_t st)
+{
+  if (n <= 0 || nParts <= 0) return hipSuccess;
+  hipError_t e = launch_partition(reads, weights, n, a, t, w, p, st);
+  if (e != hipSuccess) return e;
+  static bool attr = false;
+  if (!attr) {
+    e = hipFuncSetAttribute((const void *)bucket_scanhist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)bucket_scanhist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const size_t lds = (size_t)scan_part_bins(weights != nullptr) * (weights ? 8 : 4);
+  if (weights) bucket_scanhist_kernel<true><<<(unsigned)nParts, 1024, lds, st>>>(sc, t, w, parts);
+  else bucket_scanhist_kernel<false><<<(unsigned)nParts, 1024, lds, st>>>(sc, t, w, parts);
   return hipGetLastError();
 }
 

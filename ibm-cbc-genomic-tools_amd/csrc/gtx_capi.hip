@@ -34,6 +34,8 @@ struct gtx_ctx {
   // unsorted reads, bucket path (gtx_bucket.hip): table built with the references, scratch sized by the largest call
   void *d_clsCell = nullptr, *d_cellTab = nullptr; int nCells = 0, cellShift = 0;   // direct-address bucket lookup (BucketTable)
   int *d_bktT = nullptr; void *d_clsCellT = nullptr, *d_cellTabT = nullptr; int nBT = 0, nCellsT = 0, cellShiftT = 0;   // the same tables over the coverage thresholds (cover_prepare)
+  int *d_bktS = nullptr; void *d_clsCellS = nullptr, *d_cellTabS = nullptr; int nBS = 0, nCellsS = 0, cellShiftS = 0;          // ... and over the positions of a scan geometry (scan_bucket_tables)
+  gtx::ScanPart *d_scanParts = nullptr; int nScanParts = 0; std::vector<long long> scanBktKey; gtx::DevInfo *d_scanInfo = nullptr;
   bool covTileSums = true;                           // false: a batch went through the partition path, the tile sums are rebuilt before the finalize step
   int *d_bkt = nullptr; int nB = 0;                  // posHi | eLo | eHi | sLo | sHi | cls (nB each) | clsStart (nClasses+1)
   unsigned *d_bktCnt = nullptr, *d_bktDir = nullptr; size_t capBktMatrix = 0;   // scratch of the bucket path (gtx::BucketWork)
@@ -1122,6 +1124,101 @@ static int scan_prepare(gtx_ctx *c, const int32_t *classLen, int nClasses, int s
   return GTX_OK;
 }
 
+// Bucket tables over the POSITIONS of a scan geometry, for reads in no particular order (gtx_bucket.hip: bucket_scanhist_kernel):
+// a bucket is a run of consecutive micro-windows of one class -- at most ~1000 buckets in all, at least 16 k micro-windows each --
+// and is counted in parts of scan_part_bins() micro-windows.  Built when the geometry (or weighted / not) changes.
+static int scan_bucket_tables(gtx_ctx *c, const int32_t *classLen, int nClasses, int step, bool weighted)
+{
+  std::vector<long long> key = c->scanKey; key.push_back(weighted ? 1 : 0);
+  if (key == c->scanBktKey) return GTX_OK;
+  c->scanBktKey.clear(); c->nBS = 0; c->nScanParts = 0;
+  dfree(c->d_bktS); dfree(c->d_clsCellS); dfree(c->d_cellTabS); dfree(c->d_scanParts);
+  if (!c->d_scanInfo) HIPCHK(c, hipMalloc(&c->d_scanInfo, sizeof(gtx::DevInfo)));
+  long long total = 0;
+  for (int i = 0; i < nClasses; i++) total += classLen[i] < 0 ? 0 : classLen[i] / step;
+  const long long per = std::max<long long>(16384, (total + 999) / 1000);          // micro-windows per bucket
+  std::vector<int32_t> posHi, eLo, eHi, sLo, sHi, cls, clsStart(nClasses + 1, 0);
+  std::vector<gtx::ScanPart> parts;
+  const int bins = gtx::scan_part_bins(weighted);
+  for (int cl = 0; cl < nClasses; cl++) {
+    clsStart[cl] = (int32_t)posHi.size();
+    const long long nm = classLen[cl] < 0 ? 0 : classLen[cl] / step;
+    for (long long f = 0; f < nm; f += per) {
+      const long long g = std::min(f + per, nm);
+      posHi.push_back(g == nm ? INT32_MAX : (int32_t)(g * step));                // positions <= g * step lie in micro-windows < g
+      eLo.push_back((int32_t)f); eHi.push_back((int32_t)g); sLo.push_back(0); sHi.push_back(0); cls.push_back(cl);
+      for (long long m = f; m < g; m += bins) parts.push_back({(int)posHi.size() - 1, (int)m, (int)std::min<long long>(bins, g - m), 0});
+    }
+  }
+  clsStart[nClasses] = (int32_t)posHi.size();
+  const int nB = (int)posHi.size();
+  if (nB == 0 || nB > 4096 || nClasses > 2048 || total >= (1ll << 31)) { c->scanBktKey = key; return GTX_OK; }   // (nBS == 0: the general kernels serve)
+  const int kCells = 4096;
+  int sh = 0;
+  auto cellsAt = [&](int shift) {
+    int64_t tot = 0;
+    for (int cl = 0; cl < nClasses; cl++) {
+      const int b0 = clsStart[cl], b1 = clsStart[cl + 1];
+      tot += b1 - b0 <= 1 ? b1 - b0 : ((((int64_t)posHi[b1 - 2] - posHi[b0]) >> shift) + 1);
+    }
+    return tot;
+  };
+  while (sh < 40 && cellsAt(sh) > kCells) sh++;
+  std::vector<int32_t> clsCell(4 * (size_t)nClasses);
+  std::vector<uint16_t> cellTab;
+  for (int cl = 0; cl < nClasses; cl++) {
+    const int b0 = clsStart[cl], b1 = clsStart[cl + 1];
+    const int32_t lo = b1 - b0 <= 1 ? 0 : posHi[b0];
+    const int64_t nc = b1 == b0 ? 0 : b1 - b0 == 1 ? 1 : ((((int64_t)posHi[b1 - 2] - lo) >> sh) + 1);
+    clsCell[4 * cl] = (int32_t)cellTab.size(); clsCell[4 * cl + 1] = lo; clsCell[4 * cl + 2] = (int32_t)nc; clsCell[4 * cl + 3] = b0;
+    int b = b0;
+    for (int64_t k = 0; k < nc; k++) {
+      const int64_t first = (int64_t)lo + (k << sh);
+      while (b < b1 - 1 && (int64_t)posHi[b] < first) b++;
+      cellTab.push_back((uint16_t)(b - b0));
+    }
+  }
+  if (!gtx::bucket_tables_fit(nClasses, nB, (int)cellTab.size())) { c->scanBktKey = key; return GTX_OK; }
+  c->nCellsS = (int)cellTab.size(); c->cellShiftS = sh;
+  cellTab.push_back(0);
+  std::vector<int32_t> all;
+  for (auto *v : {&posHi, &eLo, &eHi, &sLo, &sHi, &cls, &clsStart}) all.insert(all.end(), v->begin(), v->end());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMalloc(&c->d_bktS, sizeof(int32_t) * all.size()));
+  HIPCHK(c, hipMemcpy(c->d_bktS, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMalloc(&c->d_clsCellS, sizeof(int32_t) * clsCell.size() + 16));
+  HIPCHK(c, hipMemcpy(c->d_clsCellS, clsCell.data(), sizeof(int32_t) * clsCell.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMalloc(&c->d_cellTabS, sizeof(uint16_t) * cellTab.size()));
+  HIPCHK(c, hipMemcpy(c->d_cellTabS, cellTab.data(), sizeof(uint16_t) * cellTab.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMalloc(&c->d_scanParts, sizeof(gtx::ScanPart) * parts.size()));
+  HIPCHK(c, hipMemcpy(c->d_scanParts, parts.data(), sizeof(gtx::ScanPart) * parts.size(), hipMemcpyHostToDevice));
+  c->nBS = nB; c->nScanParts = (int)parts.size(); c->scanBktKey = key;
+  return GTX_OK;
+}
+
+// one batch of reads into the micro-window histogram (zeroed by the caller): the partition path for a batch in no particular order
+// under the unsorted scanner's rule with start positions, the general kernel otherwise
+static int scan_hist_any(gtx_ctx *c, const void *dR, const int *dW, int64_t n, const gtx::ScanArgs &a, const int32_t *classLen, bool unsorted)
+{
+  if (unsorted && !a.center && !a.sortedRule && n >= c->bucketMinReads && n < (1ll << 31)) {
+    int rc = scan_bucket_tables(c, classLen, a.nClasses, a.winStep, dW != nullptr); if (rc) return rc;
+    if (c->nBS > 0) {
+      const gtx::BucketPlan p = gtx::bucket_plan(n, a.nClasses, c->nBS, c->nCellsS, dW != nullptr);
+      if (p.pairs < (1ull << 32)) {
+        gtx::BucketWork w;
+        rc = bucket_scratch(c, p, c->nBS, &w); if (rc) return rc;
+        const gtx::BucketTable t = bucket_table(c->d_bktS, c->nBS, c->d_clsCellS, c->d_cellTabS, c->nCellsS, c->cellShiftS);
+        gtx::CountArgs ca = {};                                      // what the partition pass reads of it; its counts of dropped reads go nowhere
+        ca.nClasses = a.nClasses; ca.zeroLenOk = 0; ca.coverRule = 1; ca.info = c->d_scanInfo; ca.indexBase = 0;
+        HIPCHK(c, gtx::launch_scan_bucketed(dR, dW, n, ca, a, t, w, p, c->d_scanParts, c->nScanParts, c->stream));
+        return GTX_OK;
+      }
+    }
+  }
+  HIPCHK(c, gtx::launch_scan_hist(dR, dW, n, a, c->stream));
+  return GTX_OK;
+}
+
 // the scan of reads resident in HBM, enqueued: owner-computes when the caller says the reads are sorted (checked on the device; the
 // general kernels follow as conditional launches and run only if the check fails), the general kernels otherwise
 static int scan_launch(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, const int32_t *classLen, int32_t nClasses, int32_t step,
@@ -1149,7 +1246,7 @@ static int scan_launch(gtx_ctx *c, const void *d_reads, const void *d_weights, i
   } else {
     if (microBytes) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, microBytes, c->stream));
     if (profile) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream));
+    rc = scan_hist_any(c, d_reads, (const int *)d_weights, n, a, classLen, (flags & GTX_READS_UNSORTED) != 0); if (rc) return rc;
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   }
   HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, (u64 *)d_out, c->stream, runIf));
@@ -1240,9 +1337,9 @@ int gtxi_scan_enqueue(gtx_ctx *c, const int32_t *reads, const int32_t *weights, 
     a.center = prep == 'c'; a.sortedRule = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
     const bool micro64 = weights != nullptr;
     if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (micro64 ? 8 : 4), c->stream));
-    rc = stage_batches(c, reads, weights, n, [&](const void *dR, const int *dW, int64_t cnt, int64_t) -> int {
-      HIPCHK(c, gtx::launch_scan_hist(dR, dW, cnt, a, c->stream));
-      return GTX_OK;
+    rc = stage_batches(c, reads, weights, n, [&](const void *dR, const int *dW, int64_t cnt, int64_t off) -> int {
+      const bool unsorted = (flags & GTX_READS_UNSORTED) || host_reads_look_unsorted(reads + 3 * off, cnt);
+      return scan_hist_any(c, dR, dW, cnt, a, classLen, unsorted);
     });
     if (rc) return rc;
     HIPCHK(c, gtx::launch_scan_windows(c->d_micro, micro64, a, c->scanTotalTiles, c->d_out, c->stream));

@@ -114,6 +114,14 @@ hipError_t launch_count_bucketed(const void *reads, const void *weights, long lo
 // finalize step.
 hipError_t launch_cover_bucketed(const void *reads, const void *weights, long long n, const CountArgs &a, const CoverArgs &cv, const BucketTable &t,
                                  const BucketWork &w, const BucketPlan &p, hipStream_t st);
+// genomic_scans counts of reads in no particular order (unsorted rule, preprocess '1'): the same partition over a bucket table of
+// POSITION cuts (a bucket = a run of consecutive micro-windows of one class: eLo/eHi hold its first / end micro-window), then every
+// part -- (bucket, first micro-window, micro-windows) -- counts the bucket's reads that fall into it in LDS and adds its counters to
+// the micro-window histogram of ScanArgs (which the caller has zeroed, as for launch_scan_hist).
+struct ScanPart { int bucket, first, count, pad; };
+int scan_part_bins(bool weighted);     // micro-windows one part keeps in LDS
+hipError_t launch_scan_bucketed(const void *reads, const void *weights, long long n, const CountArgs &a, const ScanArgs &sc, const BucketTable &t,
+                                const BucketWork &w, const BucketPlan &p, const ScanPart *parts, int nParts, hipStream_t st);
 hipError_t launch_tile_sums(unsigned long long *histA, unsigned long long *histB, long long histLen, unsigned long long *tileA, unsigned long long *tileB, hipStream_t st);
 
 // ---- intervals the rank difference does not cover (gtx_special.hip): plain pair tests, reference semantics of the sorted merge

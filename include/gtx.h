@@ -75,10 +75,10 @@ typedef struct gtx_ctx gtx_ctx;
                                    (genomic_intervals.cpp:5278); it differs from the clamped CalcOverlap (:427-432)
                                    only for pairs with an inverted interval, so it matters only together with
                                    GTX_ZERO_LENGTH_OK on a GTX_REFS_KEEP_ZERO_LENGTH reference set            */
-#define GTX_READS_UNSORTED  16u  /* gtx_coverage*: hint that the reads are in no particular order -- the partition path
+#define GTX_READS_UNSORTED  16u  /* gtx_coverage*, gtx_scan*: hint that the reads are in no particular order -- the partition path
                                    (buckets in LDS) instead of the streaming kernel, which is exact for any order but
                                    slow for shuffled reads.  The host-buffer calls sample their input and decide by
-                                   themselves; gtx_coverage_device takes the caller's word.  Results do not depend on it. */
+                                   themselves; gtx_coverage_device / gtx_scan_device take the caller's word.  Results do not depend on it. */
 #define GTX_CHECK_SORTED    2u  /* also verify the order the sorted merge requires
                                    (SortedGenomicRegionSetOverlaps::NextQuery,
                                    genomic_intervals.cpp:5889-5898) and report the first

@@ -14,7 +14,8 @@ eng = gtx.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
 for step, size in ((1000, 1000), (25, 500)):
     off, tot = gtx.scan_layout(synth.CHROM_LEN, step, size)
     out = torch.zeros(tot, dtype=torch.int64, device=dev)
-    eng.profile(True)
-    for it in range(4): eng.scan_device(reads.data_ptr(), n, synth.CHROM_LEN, step, size, out.data_ptr(), flags=0)
-    eng.sync()
-    print("shuffled reads, scan -w %d -d %d: whole call %.2f ms (sum=%d)" % (size, step, np.mean([eng.profile_last(b)[1] for b in range(2)]), int(out.sum())))
+    for name, flags in (("partition path (GTX_READS_UNSORTED)", gtx.READS_UNSORTED), ("general kernels (no hint)", 0)):
+        eng.profile(True)
+        for it in range(4): eng.scan_device(reads.data_ptr(), n, synth.CHROM_LEN, step, size, out.data_ptr(), flags=flags)
+        eng.sync()
+        print("shuffled reads, scan -w %d -d %d, %s: whole call %.2f ms (sum=%d)" % (size, step, name, np.mean([eng.profile_last(b)[1] for b in range(2)]), int(out.sum())))

@@ -204,3 +204,48 @@ def test_coverage_shuffled_large(beng):
     # count and coverage in turn on one context: neither disturbs the other's zeroed state
     check(beng, refs, shuf, synth.n_classes())
     check_cov(beng, refs, shuf, synth.n_classes())
+
+
+# ---- genomic_scans counts through the partition path (bucket_scanhist_kernel): unsorted rule, start positions ----
+SCAN_LENS = synth.CHROM_LEN // 20
+
+
+def scan_reads(n, seed):
+    r = synth.genome_intervals(n, seed, 50, 51)
+    r[:, 1] = r[:, 1] // 20 + 1
+    r[:, 2] = r[:, 1] + 49
+    return r
+
+
+@pytest.mark.parametrize("step,size", [(1000, 1000), (25, 500), (100, 300), (7, 7 * 13), (1, 4)])
+def test_scan_shuffled_reads(beng, step, size):
+    rng = np.random.default_rng(61)
+    reads = scan_reads(300_000, 61)
+    reads = reads[rng.permutation(len(reads))]
+    # rows the unsorted scanner ignores: start > stop, stop <= 0, start < 1, beyond the chromosome, unknown class
+    odd = np.array([[0, 500, 400], [1, -30, 0], [2, -5, 20], [3, 0, 10], [4, int(SCAN_LENS[4]) + 5000, int(SCAN_LENS[4]) + 5050], [40, 10, 60],
+                    [5, int(SCAN_LENS[5]), int(SCAN_LENS[5]) + 10], [6, 1, 1]], dtype=np.int32)
+    reads = np.concatenate([reads[:1000], odd, reads[1000:]])
+    for flags in (gtx.READS_UNSORTED, 0):                           # the caller's word / the library's own sample of the host buffer
+        got, off = beng.scan(reads, SCAN_LENS, step, size, "1", flags=flags)
+        want, woff = orc.scan(reads, SCAN_LENS, step, size, "1", algo=0)
+        np.testing.assert_array_equal(off, woff)
+        np.testing.assert_array_equal(got, want)
+    w = rng.integers(-3, 6, size=len(reads)).astype(np.int32)
+    got, _ = beng.scan(reads, SCAN_LENS, step, size, "1", weights=w, flags=gtx.READS_UNSORTED)
+    want, _ = orc.scan(reads, SCAN_LENS, step, size, "1", weights=w, algo=0)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_scan_shuffled_reads_other_rules_keep_the_general_kernels(beng):
+    # preprocess 'c' and the sorted scanner's rule are not the partition path's: same results through the general kernels
+    rng = np.random.default_rng(62)
+    reads = scan_reads(100_000, 62)
+    reads = reads[rng.permutation(len(reads))]
+    got, _ = beng.scan(reads, SCAN_LENS, 200, 1000, "c", flags=gtx.READS_UNSORTED)
+    want, _ = orc.scan(reads, SCAN_LENS, 200, 1000, "c", algo=0)
+    np.testing.assert_array_equal(got, want)
+    srt = reads[np.lexsort((reads[:, 1], reads[:, 0]))]
+    got, _ = beng.scan(srt, SCAN_LENS, 200, 1000, "1", flags=gtx.ZERO_LENGTH_OK | gtx.READS_UNSORTED)
+    want, _ = orc.scan(srt, SCAN_LENS, 200, 1000, "1", algo=1)
+    np.testing.assert_array_equal(got, want)
