@@ -359,13 +359,20 @@ def test_small_host_batches_give_the_same_output(beds, monkeypatch):
 
 def test_partition_paths_through_the_tools(beds, monkeypatch):
     """GTX_BUCKET_MIN_READS=1: the tools' shuffled input takes the partition path of the library whatever its size (count: no sorted
-    hint from the host side; coverage / density: the library's own sample of the batch) -- byte for byte the oracle's output"""
+    hint from the host side; coverage / density / scans: the library's own sample of the batch) -- byte for byte the oracle's output"""
     monkeypatch.setenv("GTX_BUCKET_MIN_READS", "1")
     for args in (["count", "-i", "refs.bed", "reads_shuffled.bed.gz"], ["count", "refs.bed", "reads_shuffled.bed.gz"],
                  ["coverage", "-i", "refs.bed", "reads_shuffled.bed.gz"], ["coverage", "-i", "--max-label-value", "4", "refs.bed", "reads_shuffled.bed.gz"],
                  ["density", "refs.bed", "reads_shuffled.bed.gz"], ["coverage", "-i", "-gaps", "refs.bed", "reads_shuffled.bed.gz"]):
         want = oracle(args, cwd=beds)
         got = product("overlaps", args, cwd=beds)
+        assert got[0] == want[0] == 0, (args, got[2])
+        assert got[1] == want[1], args
+        assert len(got[1].splitlines()) > 5
+    for args in (["counts", "-i", "-g", "genome.bed", "-w", "1000", "-d", "1000", "-min", "1", "reads_shuffled.bed.gz"],
+                 ["counts", "-g", "genome.bed", "-w", "500", "-d", "25", "-min", "2", "reads_shuffled.bed.gz"]):
+        want = oracle(args, cwd=beds)
+        got = product("scans", args, cwd=beds)
         assert got[0] == want[0] == 0, (args, got[2])
         assert got[1] == want[1], args
         assert len(got[1].splitlines()) > 5
