@@ -1125,7 +1125,7 @@ static int scan_prepare(gtx_ctx *c, const int32_t *classLen, int nClasses, int s
 }
 
 // Bucket tables over the POSITIONS of a scan geometry, for reads in no particular order (gtx_bucket.hip: bucket_scanhist_kernel):
-// a bucket is a run of consecutive micro-windows of one class -- at most ~1000 buckets in all, at least 16 k micro-windows each --
+// a bucket is a run of consecutive micro-windows of one class -- at most ~2000 buckets in all, at least 16 k micro-windows each --
 // and is counted in parts of scan_part_bins() micro-windows.  Built when the geometry (or weighted / not) changes.
 static int scan_bucket_tables(gtx_ctx *c, const int32_t *classLen, int nClasses, int step, bool weighted)
 {
@@ -1136,7 +1136,8 @@ static int scan_bucket_tables(gtx_ctx *c, const int32_t *classLen, int nClasses,
   if (!c->d_scanInfo) HIPCHK(c, hipMalloc(&c->d_scanInfo, sizeof(gtx::DevInfo)));
   long long total = 0;
   for (int i = 0; i < nClasses; i++) total += classLen[i] < 0 ? 0 : classLen[i] / step;
-  const long long per = std::max<long long>(16384, (total + 999) / 1000);          // micro-windows per bucket
+  static const long long want = getenv("GTX_SCAN_BUCKETS") && atoll(getenv("GTX_SCAN_BUCKETS")) > 0 ? atoll(getenv("GTX_SCAN_BUCKETS")) : 2000;     // (100 M shuffled reads, -d 25: 500 -> 2.77 ms, 1000 -> 2.30, 2000 -> 2.15, 3000 -> 2.10)
+  const long long per = std::max<long long>(16384, (total + want - 1) / want);     // micro-windows per bucket
   std::vector<int32_t> posHi, eLo, eHi, sLo, sHi, cls, clsStart(nClasses + 1, 0);
   std::vector<gtx::ScanPart> parts;
   const int bins = gtx::scan_part_bins(weighted);
