@@ -167,7 +167,12 @@ __global__ __launch_bounds__(1024, (WEIGHTED && PER == 4) ? 4 : 8) void bucket_s
         }
       }
     }
-    bucket_lookup<PER>(clsCell, tab, posHi, sh, a.nClasses, want, rc, rs, id);
+    if (a.keyCenter) {                                              // (genomic_scans -op c: the read's centre decides)
+      int key[PER];
+#pragma unroll
+      for (int k = 0; k < PER; k++) key[k] = (int)((i64)rs[k] + ((i64)re[k] - rs[k]) / 2);
+      bucket_lookup<PER>(clsCell, tab, posHi, sh, a.nClasses, want, rc, key, id);
+    } else bucket_lookup<PER>(clsCell, tab, posHi, sh, a.nClasses, want, rc, rs, id);
     fetch(tile + gridDim.x);                                        // in flight until the top of the next round
 #pragma unroll
     for (int k = 0; k < PER; k++) rank[k] = atomicAdd(&cnt[id[k]], 1u);   // its rank among the tile's reads of that bucket (bucket nB: the reads that are not counted)
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(1024) void bucket_cover_kernel(CoverArgs cv, Bucket
   }
 }
 
-// genomic_scans counts (unsorted rule, start positions): one part = some consecutive micro-windows of a bucket; the block reads ALL
+// genomic_scans counts (unsorted rule; start positions or centres): one part = some consecutive micro-windows of a bucket; the block reads ALL
 // chunks of the bucket (they come from the L2 for the second and later parts of a bucket) and counts the reads of its own
 // micro-windows in LDS -- no bucket is wider than a few parts.  (pos - 1) / step as in scan_slot (gtx_kernels.hip).
 static constexpr int kScanBins32 = 30720, kScanBins64 = 15360;   // 120 KB of LDS counters
@@ -528,8 +533,9 @@ __global__ __launch_bounds__(1024) void bucket_scanhist_kernel(ScanArgs sc, Buck
     entries(at + U * nW);
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (!on[u] || se[u].x < 1 || se[u].y <= 0) continue;           // the unsorted scanner's rule: start <= stop (the partition's), stop > 0, position >= 1
-      const unsigned x = (unsigned)(se[u].x - 1);
+      const i64 pos = sc.center ? (i64)se[u].x + ((i64)se[u].y - se[u].x) / 2 : (i64)se[u].x;
+      if (!on[u] || pos < 1 || se[u].y <= 0) continue;               // the unsorted scanner's rule: start <= stop (the partition's), stop > 0, position >= 1
+      const unsigned x = (unsigned)(pos - 1);
       unsigned q = d == 1 ? x : __umulhi(x, sc.winStepInv);
       unsigned r = x - q * d;
       if (r >= d) { q++; r -= d; }

@@ -424,7 +424,7 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int
   a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0; a.prefetch = c->prefetch;
   a.zeroLenOk = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   const bool merge = (flags & GTX_ZERO_LENGTH_OK) && c->mergeRefs && c->d_side;       // full sorted-merge semantics (see merge_prepare)
-  a.side = merge ? c->d_side : nullptr; a.sideCount = merge ? c->d_sideCount : nullptr; a.sideCap = c->sideCap; a.coverRule = 0;
+  a.side = merge ? c->d_side : nullptr; a.sideCount = merge ? c->d_sideCount : nullptr; a.sideCap = c->sideCap; a.coverRule = 0; a.keyCenter = 0;
   a.sampE = c->d_sampE; a.sampS = c->d_sampS; a.sampShift = c->sampShift; a.nSamp = c->nSamp;
   a.topE = c->d_topE; a.topS = c->d_topS;
   // dense references (>= 4 boundaries per 256 reads and array): all boundaries of a window at once instead of the
@@ -1198,10 +1198,10 @@ static int scan_bucket_tables(gtx_ctx *c, const int32_t *classLen, int nClasses,
 }
 
 // one batch of reads into the micro-window histogram (zeroed by the caller): the partition path for a batch in no particular order
-// under the unsorted scanner's rule with start positions, the general kernel otherwise
+// under the unsorted scanner's rule, the general kernel otherwise
 static int scan_hist_any(gtx_ctx *c, const void *dR, const int *dW, int64_t n, const gtx::ScanArgs &a, const int32_t *classLen, bool unsorted)
 {
-  if (unsorted && !a.center && !a.sortedRule && n >= c->bucketMinReads && n < (1ll << 31)) {
+  if (unsorted && !a.sortedRule && n >= c->bucketMinReads && n < (1ll << 31)) {
     int rc = scan_bucket_tables(c, classLen, a.nClasses, a.winStep, dW != nullptr); if (rc) return rc;
     if (c->nBS > 0) {
       const gtx::BucketPlan p = gtx::bucket_plan(n, a.nClasses, c->nBS, c->nCellsS, dW != nullptr);
@@ -1210,7 +1210,7 @@ static int scan_hist_any(gtx_ctx *c, const void *dR, const int *dW, int64_t n, c
         rc = bucket_scratch(c, p, c->nBS, &w); if (rc) return rc;
         const gtx::BucketTable t = bucket_table(c->d_bktS, c->nBS, c->d_clsCellS, c->d_cellTabS, c->nCellsS, c->cellShiftS);
         gtx::CountArgs ca = {};                                      // what the partition pass reads of it; its counts of dropped reads go nowhere
-        ca.nClasses = a.nClasses; ca.zeroLenOk = 0; ca.coverRule = 1; ca.info = c->d_scanInfo; ca.indexBase = 0;
+        ca.nClasses = a.nClasses; ca.zeroLenOk = 0; ca.coverRule = 1; ca.keyCenter = a.center; ca.info = c->d_scanInfo; ca.indexBase = 0;
         HIPCHK(c, gtx::launch_scan_bucketed(dR, dW, n, ca, a, t, w, p, c->d_scanParts, c->nScanParts, c->stream));
         return GTX_OK;
       }

@@ -40,6 +40,7 @@ struct CountArgs {
   // by its two comparisons like any other read (genomic_intervals.cpp:1225-1236).  The rank difference does not hold for
   // them, so the kernels set them aside here (class, start, end, weight) for the pair kernels of gtx_special.hip.
   int4 *side; unsigned *sideCount; int sideCap;
+  int keyCenter;                 // the partition pass of the scan path with preprocess 'c': a read is placed by its centre start + (end - start) / 2
   int coverRule;                 // the partition pass of the coverage path: a zero-length read (start == end + 1) is dropped silently, only
                                  // inverted ones (start > end + 1) are reported and set aside -- as coverage_walk_kernel does
 };

@@ -237,13 +237,21 @@ def test_scan_shuffled_reads(beng, step, size):
     np.testing.assert_array_equal(got, want)
 
 
-def test_scan_shuffled_reads_other_rules_keep_the_general_kernels(beng):
-    # preprocess 'c' and the sorted scanner's rule are not the partition path's: same results through the general kernels
+def test_scan_shuffled_reads_centres_and_the_sorted_rule(beng):
+    # preprocess 'c': placed by the centre (reads of 1..4000 bp, some starting below 1 with their centre inside, some with the centre
+    # beyond the chromosome); the sorted scanner's rule is not the partition path's: the general kernels
     rng = np.random.default_rng(62)
     reads = scan_reads(100_000, 62)
+    reads[:, 2] = reads[:, 1] + rng.integers(0, 4000, size=len(reads))
+    reads[:50, 1] -= 3000
     reads = reads[rng.permutation(len(reads))]
-    got, _ = beng.scan(reads, SCAN_LENS, 200, 1000, "c", flags=gtx.READS_UNSORTED)
-    want, _ = orc.scan(reads, SCAN_LENS, 200, 1000, "c", algo=0)
+    for step, size in ((200, 1000), (25, 500), (1000, 1000)):
+        got, _ = beng.scan(reads, SCAN_LENS, step, size, "c", flags=gtx.READS_UNSORTED)
+        want, _ = orc.scan(reads, SCAN_LENS, step, size, "c", algo=0)
+        np.testing.assert_array_equal(got, want)
+    w = rng.integers(-3, 6, size=len(reads)).astype(np.int32)
+    got, _ = beng.scan(reads, SCAN_LENS, 200, 1000, "c", weights=w)
+    want, _ = orc.scan(reads, SCAN_LENS, 200, 1000, "c", weights=w, algo=0)
     np.testing.assert_array_equal(got, want)
     srt = reads[np.lexsort((reads[:, 1], reads[:, 0]))]
     got, _ = beng.scan(srt, SCAN_LENS, 200, 1000, "1", flags=gtx.ZERO_LENGTH_OK | gtx.READS_UNSORTED)
