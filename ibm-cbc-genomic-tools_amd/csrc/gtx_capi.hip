@@ -31,6 +31,9 @@ struct gtx_ctx {
   int *d_sortedE = nullptr, *d_sortedS = nullptr, *d_segStart = nullptr;
   int *d_sampE = nullptr, *d_sampS = nullptr; int sampShift = 6, nSamp = 0;   // top level of the search kernel
   int *d_topE = nullptr, *d_topS = nullptr;   // every 256th boundary: first hop of the streaming kernel's start-of-span search
+  // direct placement at the start of a span (gtx::PlaceTable): per class {segment start, end, first cell, cells}; per cell the rank
+  // of the cell's first position in the ends array and in the starts array
+  int4 *d_placeCls = nullptr; int *d_placeRank = nullptr; int placeShift = 0;
   // unsorted reads, bucket path (gtx_bucket.hip): table built with the references, scratch sized by the largest call
   void *d_clsCell = nullptr, *d_cellTab = nullptr; int nCells = 0, cellShift = 0;   // direct-address bucket lookup (BucketTable)
   int *d_bktT = nullptr; void *d_clsCellT = nullptr, *d_cellTabT = nullptr; int nBT = 0, nCellsT = 0, cellShiftT = 0;   // the same tables over the coverage thresholds (cover_prepare)
@@ -97,6 +100,7 @@ struct gtx_ctx {
 
   int64_t batchReads = 8ll << 20;       // reads per device batch of the host-buffer entry points (96 MiB of triples: ~2 ms of PCIe)
   int chunksPerWave = 0;                // 0 = choose per call from the number of reads
+  int64_t waveSlots = 8192;             // resident waves of the device (CUs x 32)
   int prefetch = 4;                     // reads per lane per step (R) of the streaming kernel (GTX_READS_PER_LANE)
 };
 
@@ -124,6 +128,7 @@ gtx_ctx *gtx_create(int device_id)
   if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
   gtx_ctx *c = new gtx_ctx();
   c->device = device_id;
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->waveSlots = 32ll * cus; }
   if (hipMalloc(&c->d_info, 2 * sizeof(gtx::DevInfo)) != hipSuccess || hipHostMalloc(&c->h_info, 2 * sizeof(gtx::DevInfo)) != hipSuccess) {
     g_create_error = "gtx_create: allocation failed"; delete c; return nullptr;
   }
@@ -158,6 +163,8 @@ void gtx_destroy(gtx_ctx *c)
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
   dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab); dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;
+  dfree(c->d_placeCls); dfree(c->d_placeRank);
+  dfree(c->d_bktCnt); dfree(c->d_bktS); dfree(c->d_clsCellS); dfree(c->d_cellTabS); dfree(c->d_scanParts); dfree(c->d_scanInfo); c->nBS = 0;
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   for (int k = 0; k < 2; k++) {
@@ -263,6 +270,8 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
 
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
   dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab);
+  dfree(c->d_placeCls); dfree(c->d_placeRank);
+  dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;      // tables over the coverage thresholds: rebuilt by cover_prepare
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB);
   c->nRefs = -1;
   const int64_t histLen = nv + nClasses;
@@ -304,6 +313,36 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
     HIPCHK(c, hipMalloc(&c->d_topS, sizeof(int32_t) * (nTop + 1)));
     HIPCHK(c, hipMemcpy(c->d_topE, topE.data(), sizeof(int32_t) * (nTop + 1), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_topS, topS.data(), sizeof(int32_t) * (nTop + 1), hipMemcpyHostToDevice));
+  }
+  {
+    // direct placement (gtx::PlaceTable): cells of 2^sh positions, sh the smallest shift that keeps the table at about one cell
+    // per eight boundaries; a cell's entry = how many boundaries of the class lie below the cell's first position (cell 0: none)
+    const int64_t budget = std::max<int64_t>(1024, nv / 8) + 2 * (int64_t)nClasses;
+    auto cellsOf = [&](int cl, int sh) -> int64_t {
+      if (seg[cl] == seg[cl + 1]) return 0;
+      const int64_t top = std::max<int64_t>(0, sortedE[seg[cl + 1] - 1]);
+      return (top >> sh) + 2;
+    };
+    int sh = 0;
+    for (;; sh++) { int64_t t = 0; for (int cl = 0; cl < nClasses; cl++) t += cellsOf(cl, sh); if (t <= budget || sh >= 31) break; }
+    std::vector<int4> pc(nClasses);
+    std::vector<int32_t> rank;
+    for (int cl = 0; cl < nClasses; cl++) {
+      const int64_t nc = cellsOf(cl, sh);
+      pc[cl] = make_int4(seg[cl], seg[cl + 1], (int)(rank.size() / 2), (int)nc);
+      int32_t ie = seg[cl], is = seg[cl];
+      for (int64_t k = 0; k < nc; k++) {
+        const int64_t first = k << sh;                           // cell 0 stands for everything below 2^sh, negative keys included
+        if (k > 0) { while (ie < seg[cl + 1] && sortedE[ie] < first) ie++; while (is < seg[cl + 1] && sortedS[is] < first) is++; }
+        rank.push_back(ie); rank.push_back(is);
+      }
+    }
+    rank.push_back(0); rank.push_back(0);
+    HIPCHK(c, hipMalloc(&c->d_placeCls, sizeof(int4) * (size_t)std::max(nClasses, 1)));
+    HIPCHK(c, hipMalloc(&c->d_placeRank, sizeof(int32_t) * rank.size()));
+    HIPCHK(c, hipMemcpy(c->d_placeCls, pc.data(), sizeof(int4) * (size_t)nClasses, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_placeRank, rank.data(), sizeof(int32_t) * rank.size(), hipMemcpyHostToDevice));
+    c->placeShift = sh;
   }
   {
     // bucket table of the unsorted path: cuts of the ends array every bucket_e_size() boundaries, never across classes
@@ -399,6 +438,24 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
 // ---------------------------------------------------------------------------------------------
 // count
 // ---------------------------------------------------------------------------------------------
+#ifdef GTX_WAVE_TRACE
+// diagnostic build (make trace -> libgtx_trace.so, scripts/wave_trace.py): per-wave time stamps of the streaming count kernel
+static constexpr size_t kTraceWaves = 1u << 20;
+static unsigned long long *g_trace = nullptr;
+static unsigned long long *gtx_debug_trace_buffer()
+{
+  if (!g_trace && hipMalloc(&g_trace, kTraceWaves * 32) == hipSuccess) (void)hipMemset(g_trace, 0, kTraceWaves * 32);
+  return g_trace;
+}
+extern "C" int gtx_debug_trace_read(unsigned long long *out, long long nWaves)
+{
+  if (!g_trace || nWaves > (long long)kTraceWaves) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpy(out, g_trace, (size_t)nWaves * 32, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+  return hipMemset(g_trace, 0, kTraceWaves * 32) == hipSuccess ? 0 : -4;      // (the next launch may have fewer waves)
+}
+#endif
+
 static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int64_t indexBase = 0)
 {
   gtx::CountArgs a;
@@ -421,15 +478,20 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int
   if (cpw <= 0) { int64_t nChunks = (nReads + 63) >> 6; cpw = (int)std::min<int64_t>(56, std::max<int64_t>(8, nChunks / 24576)); }
   const int r = std::max(1, std::min(4, c->prefetch));
   a.chunksPerWave = (cpw + r - 1) / r * r;
+  a.sched = gtx::span_schedule((nReads + 63) >> 6, a.chunksPerWave, r, c->waveSlots);
   a.checkSorted = (flags & GTX_CHECK_SORTED) ? 1 : 0; a.sortClassShift = 0; a.prefetch = c->prefetch;
   a.zeroLenOk = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
   const bool merge = (flags & GTX_ZERO_LENGTH_OK) && c->mergeRefs && c->d_side;       // full sorted-merge semantics (see merge_prepare)
   a.side = merge ? c->d_side : nullptr; a.sideCount = merge ? c->d_sideCount : nullptr; a.sideCap = c->sideCap; a.coverRule = 0; a.keyCenter = 0;
   a.sampE = c->d_sampE; a.sampS = c->d_sampS; a.sampShift = c->sampShift; a.nSamp = c->nSamp;
   a.topE = c->d_topE; a.topS = c->d_topS;
+  a.place.cls = c->d_placeCls; a.place.rank = c->d_placeRank; a.place.shift = c->placeShift;
   // dense references (>= 4 boundaries per 256 reads and array): all boundaries of a window at once instead of the
   // per-boundary loop (100 M reads x 4 M regions: 0.41 -> 0.28 ms; at 1 M regions the loop is 3 % faster).  GTX_FLIP=0|1 forces.
   { static const char *fl = getenv("GTX_FLIP"); a.flip = fl ? atoi(fl) : (c->nValid * 256 >= 4 * std::max<int64_t>(nReads, 1)); }
+#ifdef GTX_WAVE_TRACE
+  a.trace = gtx_debug_trace_buffer();
+#endif
   return a;
 }
 

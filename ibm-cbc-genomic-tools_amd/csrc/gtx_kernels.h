@@ -14,6 +14,28 @@ struct DevInfo {
   long long n_unplaced;          // inverted reads that did not fit the side buffer (counts incomplete: the caller must fail)
 };
 
+// Direct placement of a wave's two windows at the start of its span: the positions of a class are cut into cells of
+// 2^shift, rank[2 * (first cell of the class + cell)] / [.. + 1] = how many boundaries of the ends / starts array lie before
+// the cell's first position (as global indices into the sorted arrays).  Read with scalar loads.
+struct PlaceTable {
+  const int4 *cls;               // [nClasses] {segment start, segment end, first cell, cells}
+  const int *rank;               // [2 * cells]
+  int shift;
+};
+
+// How the read stream is dealt to the waves of a launch: segment k = the waves from wave0[k] up to the next segment take cpw[k]
+// chunks each, beginning at chunk chunk0[k].  Workgroups are dispatched in grid order, so the segments are phases in time: a
+// head of spans of growing length (the first round's waves all start together; equal spans would also end together, and again
+// a round later), the main segment, and a tail of spans that shrink in step with the time the launch has left.
+struct SpanSchedule {
+  static constexpr int kMax = 32;
+  int wave0[kMax];               // INT32_MAX for the segments not in use
+  int chunk0[kMax];
+  int cpw[kMax];
+  int nSeg;
+  long long nWaves;              // all segments together (the waves a grid has beyond them find their span behind the stream's end)
+};
+
 struct CountArgs {
   const int *sortedE;            // reference ends, sorted by (class, value)
   const int *sortedS;            // reference starts, sorted by (class, value)
@@ -34,6 +56,8 @@ struct CountArgs {
   int sampShift, nSamp;
   const int *topE;               // every 256th element of sortedE / sortedS (index i << 8): first hop of the streaming
   const int *topS;               //   kernel's start-of-span search (rank_pair)
+  PlaceTable place;
+  SpanSchedule sched;
   int flip;                      // streaming kernel: meet all boundaries of a window at once (dense references)
   long long indexBase;           // position of reads[0] in the caller's stream: added to the indices reported in `info`
   // sorted-merge semantics (zeroLenOk): inverted reads (start > end + 1) are not degenerate there -- the merge matches them
@@ -43,6 +67,9 @@ struct CountArgs {
   int keyCenter;                 // the partition pass of the scan path with preprocess 'c': a read is placed by its centre start + (end - start) / 2
   int coverRule;                 // the partition pass of the coverage path: a zero-length read (start == end + 1) is dropped silently, only
                                  // inverted ones (start > end + 1) are reported and set aside -- as coverage_walk_kernel does
+#ifdef GTX_WAVE_TRACE
+  unsigned long long *trace;     // diagnostic build only (make trace): 4 words per wave -- start, windows placed, end (100 MHz ticks), XCC id
+#endif
 };
 
 // coverage: ONE boundary array per class -- the thresholds E_k and S_k - 1 of all its regions, merged and sorted (sortedT) --
@@ -135,6 +162,7 @@ hipError_t launch_side_reads(const int *refC, const int *refS, const int *refE, 
 hipError_t launch_special_scatter(const int *specialIdx, unsigned long long *specialOut, int nSpecial, unsigned long long *hits,
                                   unsigned *sideCount, hipStream_t st);                  // hits[idx[j]] = out[j]; out and the side counter cleared
 
+SpanSchedule span_schedule(long long nChunks, int cpw, int r, long long slots);
 int search_sample_shift(long long nValid);   // stride of the sample arrays such that both fit the LDS budget
 int scan_tiles(long long len);
 

@@ -36,7 +36,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
 #include <type_traits>
+#include <vector>
+#include <algorithm>
 #include "gtx_kernels.h"
 
 namespace gtx {
@@ -198,6 +202,13 @@ struct Win {
     W = load_window(sg, base, lane);
     Wn = load_window(sg, base + kSlots, lane);
     prevW = rdlane(W, 0); curW = rdlane(W, 1);
+  }
+
+  // the windows W / Wn already hold base p and p + kSlots: stand in slot j of it
+  __device__ __forceinline__ void place_loaded(int p, int jj)
+  {
+    base = p; j = jj; pend = 0; acc = 0; acc2 = 0; pend2 = 0;
+    prevW = rdlane(W, jj); curW = rdlane(W, jj + 1);
   }
 
   // wave-cooperative 64-ary search: sg.start + #{v in arr[sg.start..sg.end) : before(v, key)}
@@ -697,18 +708,35 @@ __device__ __forceinline__ void rank_pair(const Seg &sg, const WA &A, const int 
 // and leaves -- before touching any state -- as soon as a step needs anything else (another class,
 // a degenerate read, a key behind a window, an unplaced window, the partial last step), and the
 // outer loop that gives exactly that step to the general per-chunk code and re-enters.
-template <bool WEIGHTED, int R, bool FLIP>
+// PF (the plain kernel): the NEXT step of the fast loop travels by LDS-DMA (global_load_lds_dwordx3, no register destination)
+// into 4 KB of LDS of the wave's own while the current step is being worked on in registers.  Without it a wave has bytes in
+// flight only between issuing a step's loads and their arrival -- about 60 % of the time; a wave's rate is bytes in flight /
+// latency, and the launch is short of resident waves to cover for that (8 per SIMD is the hardware's limit, a second register
+// set would cost three of them).
+template <bool WEIGHTED, int R, bool FLIP, bool PF = false>
 __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, const CountArgs &a)
 {
+  static_assert(!PF || (R == 4 && !WEIGHTED), "the LDS prefetch is built for steps of 4 x 64 unweighted reads");
+  // per wave: one step of triples as global_load_lds_dwordx3 lays them down -- lane l's 12 bytes at 16 l (a 16-byte pitch, the
+  // fourth dword untouched; probed on the chip, scripts/dma_probe.hip): 1 KB per 64-read chunk
+  __shared__ __attribute__((aligned(16))) int ldsT[PF ? 4 : 1][PF ? 256 * R : 4];
   __shared__ int ldsK[FLIP ? 8 : 1][FLIP ? 256 : 1];           // per wave: the keys of a step (walk_flip4)
   __shared__ int ldsP[(FLIP && WEIGHTED) ? 8 : 1][(FLIP && WEIGHTED) ? 264 : 1];   // and the prefix sums of their weights (walk_flipw4)
   const int wid = rfl(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + rfl(threadIdx.x >> 6);
-  const i64 first = wave * (i64)a.chunksPerWave * 64;          // first read of this wave's span
+  // this wave's span from the launch's schedule (SpanSchedule): long spans first, the short ones of the tail last
+  int sw0 = a.sched.wave0[0], sc0 = a.sched.chunk0[0], scp = a.sched.cpw[0];
+#pragma unroll
+  for (int i = 1; i < SpanSchedule::kMax; ++i)
+    if (wave >= a.sched.wave0[i]) { sw0 = a.sched.wave0[i]; sc0 = a.sched.chunk0[i]; scp = a.sched.cpw[i]; }
+  const i64 first = ((i64)sc0 + (wave - sw0) * scp) * 64;      // first read of this wave's span
   if (first >= n) return;
-  i64 cnt = n - first; if (cnt > (i64)a.chunksPerWave * 64) cnt = (i64)a.chunksPerWave * 64;
+  i64 cnt = n - first; if (cnt > (i64)scp * 64) cnt = (i64)scp * 64;
   const int nMine = (int)cnt;                                  // reads in this span
+#ifdef GTX_WAVE_TRACE
+  const u64 trT0 = __builtin_amdgcn_s_memrealtime(); u64 trT1 = 0;
+#endif
   const int nSteps = (nMine + 64 * R - 1) / (64 * R);
   const int nFull = nMine / (64 * R);                          // steps with all R x 64 reads present
 
@@ -732,11 +760,47 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
   Tri t[R];
   int tw[WEIGHTED ? R : 1];                                    // the weights of step s (weighted fast path)
   bool have = false;                                           // t (and tw) hold step s
+  int dmaStep = -1;                                            // PF: the step whose triples are in, or on their way to, ldsT[wid]
+  auto dma_step = [&](int step) {
+    if constexpr (PF) {
+      const char *p = base + (size_t)step * (768 * R) + loff;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p + 768 * r),
+                                         (__attribute__((address_space(3))) void *)&ldsT[wid][256 * r], 12, 0, 2);   // aux 2 = nt
+    }
+  };
   if (fastOk && nFull > 0) {
-    // the common start: the first step is all of one class with reference regions -- place both windows at once
+    // the common start: the first step is all of one class with reference regions -- place both windows at once.
+    // The scalar load of the span's first read goes out first: when a launch begins every wave asks for its 3 KB at once, and
+    // what is asked for behind them waits for 24 MB.
+    const int *fr = (const int *)(reads + first);
+    const int fc0 = fr[0], fs0 = fr[1];
+    __builtin_amdgcn_sched_barrier(0);                           // (left alone hipcc issues the scalar load behind the vector loads)
 #pragma unroll
     for (int r = 0; r < R; ++r) { t[r] = load_tri(base + 768 * r + loff); if constexpr (WEIGHTED) tw[r] = wbase[64 * r + lane]; }
     have = true;
+    const int fc = rfl(fc0), fs = rfl(fs0);
+    if constexpr (PF) { if (nFull > 1) { dma_step(1); dmaStep = 1; } }
+    // While those loads are on their way: the span's FIRST read by scalar loads (their path does not queue behind the CU's
+    // streaming loads), its class record and the two ranks of the cell its start lies in (PlaceTable) -- lower bounds of the
+    // ranks of every key that is not below the cell -- and both windows loaded there.  Three short scalar round trips and one
+    // vector one, under the step's own load, instead of the four vector round trips of rank_pair behind it (12 us median
+    // under load, a quarter of a wave's life).  Nothing here is trusted: the step's real keys decide below.
+    int preA = 0, preB = 0, preCls = -1; Seg preSeg; preSeg.start = 0; preSeg.end = 0; preSeg.cls = -1;
+    {
+      if ((unsigned)fc < (unsigned)a.nClasses) {
+        const int4 pc = a.place.cls[fc];
+        preSeg.start = rfl(pc.x); preSeg.end = rfl(pc.y); preSeg.cls = fc;
+        if (preSeg.start != preSeg.end) {
+          int cell = (fs > 0 ? fs : 0) >> a.place.shift; cell = cell < rfl(pc.w) - 1 ? cell : rfl(pc.w) - 1;
+          const int *rk = a.place.rank + 2 * ((i64)rfl(pc.z) + cell);
+          preA = rfl(rk[0]); preB = rfl(rk[1]); preCls = fc;
+          st.A.W = st.A.load_window(preSeg, preA, lane); st.A.Wn = st.A.load_window(preSeg, preA + kSlots, lane);
+          st.B.W = st.B.load_window(preSeg, preB, lane); st.B.Wn = st.B.load_window(preSeg, preB + kSlots, lane);
+        }
+      }
+    }
     const int c0 = rdlane(t[0].c, 0);
     int odd = 0, dg = 0, ks[R], ke[R];
 #pragma unroll
@@ -745,15 +809,27 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
       dg |= __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(t[r].e, zl), t[r].s);
     }
     if ((unsigned)c0 < (unsigned)a.nClasses && !__ballot((odd != 0) | (dg < 0))) {
-      st.sg.start = rfl(a.segStart[c0]); st.sg.end = rfl(a.segStart[c0 + 1]); st.sg.cls = c0;
+      if (c0 == preCls) st.sg = preSeg;
+      else { st.sg.start = rfl(a.segStart[c0]); st.sg.end = rfl(a.segStart[c0 + 1]); st.sg.cls = c0; }
       if (st.sg.start != st.sg.end) {
-        int pA, pB;
-        rank_pair(st.sg, st.A, a.topE, wave_min(min_of<R>(ks)), st.B, a.topS, wave_min(min_of<R>(ke)), lane, pA, pB);
-        st.A.place(st.sg, pA, lane); st.B.place(st.sg, pB, lane);
+        const int kA = wave_min(min_of<R>(ks)), kB = wave_min(min_of<R>(ke));
+        // the boundaries of a window that sort before the key are a prefix of its lanes: lane 0 among them = the rank is not
+        // below the window, lane 63 not among them = it is inside; then the slot is their number - 1
+        const u64 mA = __ballot(st.A.before(st.A.W, kA)), mB = __ballot(st.B.before(st.B.W, kB));
+        if (c0 == preCls && (mA & 1) && (mB & 1) && (i64)mA >= 0 && (i64)mB >= 0) {
+          st.A.place_loaded(preA, __popcll(mA) - 1); st.B.place_loaded(preB, __popcll(mB) - 1);
+        } else {
+          int pA, pB;
+          rank_pair(st.sg, st.A, a.topE, kA, st.B, a.topS, kB, lane, pA, pB);
+          st.A.place(st.sg, pA, lane); st.B.place(st.sg, pB, lane);
+        }
         st.validA = st.validB = true;
       }
     }
   }
+#ifdef GTX_WAVE_TRACE
+  trT1 = __builtin_amdgcn_s_memrealtime();
+#endif
   while (s < nSteps) {
     // ---------------- fast loop ----------------
     // No software prefetch: a second register set (two-step ping-pong) takes the kernel from 58 to 91 VGPRs
@@ -809,7 +885,21 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
         for (int r = 0; r < R; ++r) { tt[r] = load_tri(p + 768 * r); if constexpr (WEIGHTED) tw[r] = wbase[(size_t)step * (64 * R) + 64 * r + lane]; }
       };
       while (s < nFull) {
-        if (!have) load_step(t, s);
+        if constexpr (PF) {
+          if (!have) {
+            if (dmaStep != s) dma_step(s);                            // (only behind a step that went through the general code twice over)
+            // nothing orders a ds_read behind a pending LDS-DMA except the issuing wave's vmcnt (hipcc does not insert it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            typedef int v3i __attribute__((ext_vector_type(3)));     // 16 bytes in memory, 3 registers: ds_read_b96
+            const v3i *L = (const v3i *)&ldsT[wid][4 * lane];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const v3i v = L[64 * r]; t[r].c = v.x; t[r].s = v.y; t[r].e = v.z; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the buffer is about to be overwritten
+            if (s + 1 < nFull) { dma_step(s + 1); dmaStep = s + 1; }
+          }
+        } else {
+          if (!have) load_step(t, s);
+        }
         have = true;
         if (!fast_step(t)) break;
         ++s; have = false;
@@ -849,6 +939,14 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
     if (st.nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)st.nDegen); atomicMin((i64 *)&a.info->first_degenerate, st.firstDegen + a.indexBase); }
     if (st.firstUnsorted != INT64_MAX) atomicMin((i64 *)&a.info->first_unsorted, st.firstUnsorted + a.indexBase);
   }
+#ifdef GTX_WAVE_TRACE
+  if (a.trace && lane == 0) {
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    u64 *t = a.trace + wave * 4;
+    t[0] = trT0; t[1] = trT1; t[2] = __builtin_amdgcn_s_memrealtime(); t[3] = ((u64)hw << 32) | xcc;
+  }
+#endif
 }
 
 // Residency is set by the scalar registers: 256-thread blocks are admitted per CU by floor(800 / (ceil(sgpr/16)*16 + 16)) --
@@ -856,9 +954,14 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
 // compiler takes 96-106 for this kernel; capped, it parks a dozen rarely used scalars in the lanes of one VGPR.
 // 100 M x 1 M: 6 -> 8 waves per SIMD, 0.240 -> 0.222 ms.
 template <bool WEIGHTED, int R>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void count_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void count_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
 {
   count_walk_body<WEIGHTED, R, false>(reads, weights, n, a);
+}
+// experiment (GTX_PF=1): the next step prefetched through LDS
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void count_walk_kernel_pf(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
+{
+  count_walk_body<false, 4, false, true>(reads, weights, n, a);
 }
 // weighted reads: steps of 4 x 64 with the weights' prefix sums in LDS (walk_flipw4); the general code takes what does not qualify
 __global__ __launch_bounds__(256) void count_walk_kernel_weighted(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
@@ -1612,23 +1715,85 @@ int search_sample_shift(i64 nValid)
 
 int scan_tiles(i64 len) { return (int)((len + kTile - 1) / kTile); }
 
+// Schedule of a launch over nChunks 64-read chunks, `cpw` chunks per wave in the main segment (all spans multiples of `r`),
+// `slots` = resident waves of the chip.  A wave lives p + c * tau (placement + c chunks at the chip's rate shared by all
+// slots; p / tau ~ 8 chunks measured), and a slot frees once per life.
+//  * tail (default for launches of three rounds or more): a wave dispatched when the launch has time T left should take T's
+//    worth -- levels cpw-r, cpw-2r, ... down to 8 chunks, each dealt to about as many waves as free up while the level is
+//    current, slots * r / (cpw + 8), times 5/4 (measured: 100 M reads, 512 / 640 / 800 waves per level within 1 % of each
+//    other, all 3-4 % ahead of equal spans; same-box A/B, scripts/ab_count.py).
+//  * head (off by default): levels 12, 12+r, ... below cpw spread the ends of the first round, whose waves all start together,
+//    over a wave's life.  The dips in the wave time line (scripts/wave_trace.py) go, and so does the first round's burst at
+//    full occupancy: no net gain measured.
+// GTX_SCHED: "none" | "lin:<waves per head level>:<waves per tail level>[:<shortest span>]" | "h=<c>x<w>,...;t=<c>x<w>,..."
+// (chunks x waves, in launch order) for experiments.
+SpanSchedule span_schedule(i64 nChunks, int cpw, int r, i64 slots)
+{
+  SpanSchedule s;
+  for (int i = 0; i < SpanSchedule::kMax; ++i) { s.wave0[i] = INT32_MAX; s.chunk0[i] = 0; s.cpw[i] = cpw; }
+  struct SegSpec { int cpw; i64 waves; };
+  std::vector<SegSpec> head, tail;
+  auto up = [&](i64 c) { return (int)((c + r - 1) / r * r); };
+  auto linear = [&](i64 perHead, i64 perTail, int minSpan = 8) {
+    if (perHead > 0) for (int c = up(12); c < cpw; c += r) head.push_back({c, (perHead + 3) / 4 * 4});
+    if (perTail > 0) for (int c = cpw - r; c >= minSpan; c -= r) tail.push_back({c, (perTail + 3) / 4 * 4});
+  };
+  auto parse = [&](const char *p, std::vector<SegSpec> &out) {
+    while (*p && *p != ';') {
+      char *q; const long c = strtol(p, &q, 10); if (q == p || *q != 'x') break;
+      p = q + 1; const long long w = strtoll(p, &q, 10); if (q == p) break;
+      if (c > 0 && w > 0) out.push_back({up(c), (i64)(w + 3) / 4 * 4});
+      p = *q == ',' ? q + 1 : q;
+    }
+    return p;
+  };
+  const char *spec = getenv("GTX_SCHED");
+  if (spec && !strncmp(spec, "lin:", 4)) { long long a = 0, b = 0; int ms = 8; sscanf(spec + 4, "%lld:%lld:%d", &a, &b, &ms); linear(a, b, ms > 0 ? ms : 8); }
+  else if (spec && !strcmp(spec, "none")) {}
+  else if (spec) {
+    const char *p = spec;
+    while (*p) {
+      if (!strncmp(p, "h=", 2)) p = parse(p + 2, head); else if (!strncmp(p, "t=", 2)) p = parse(p + 2, tail); else break;
+      if (*p == ';') ++p;
+    }
+  } else if (nChunks >= 3 * slots * (i64)cpw) {
+    linear(0, slots * r * 5 / (4 * (cpw + 8)));
+  }
+  auto chunksOf = [](const std::vector<SegSpec> &v) { i64 t = 0; for (auto &g : v) t += g.cpw * g.waves; return t; };
+  while ((int)(head.size() + tail.size()) > SpanSchedule::kMax - 1) { if (!head.empty()) head.erase(head.begin()); else tail.pop_back(); }
+  if ((chunksOf(head) + chunksOf(tail)) * 3 > nChunks * 2) head.clear();
+  if (chunksOf(tail) * 3 > nChunks * 2) tail.clear();
+  int k = 0; i64 wave = 0, chunk = 0;
+  for (auto &g : head) { s.wave0[k] = (int)wave; s.chunk0[k] = (int)chunk; s.cpw[k] = g.cpw; wave += g.waves; chunk += g.waves * g.cpw; ++k; }
+  const i64 tailChunks = chunksOf(tail);
+  const i64 mainWaves = tail.empty() ? (nChunks - chunk + cpw - 1) / cpw : (nChunks - chunk - tailChunks) / cpw;
+  s.wave0[k] = (int)wave; s.chunk0[k] = (int)chunk; s.cpw[k] = cpw; wave += mainWaves; chunk += mainWaves * cpw; ++k;
+  for (size_t i = 0; i < tail.size(); ++i) {
+    i64 w = tail[i].waves;
+    if (i + 1 == tail.size()) w = (nChunks - chunk + tail[i].cpw - 1) / tail[i].cpw;   // the last level takes what is left
+    s.wave0[k] = (int)wave; s.chunk0[k] = (int)chunk; s.cpw[k] = tail[i].cpw; wave += w; chunk += w * tail[i].cpw; ++k;
+  }
+  s.nSeg = k; s.nWaves = wave;
+  return s;
+}
+
 hipError_t launch_count(const void *reads, const void *weights, i64 n, const CountArgs &a, bool sortedHint, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
   if (sortedHint) {
-    const i64 nChunks = (n + 63) >> 6;
-    const i64 waves = (nChunks + a.chunksPerWave - 1) / a.chunksPerWave;
-    static const int wpb = getenv("GTX_WAVES_PER_BLOCK") ? atoi(getenv("GTX_WAVES_PER_BLOCK")) : 4;
+    const i64 waves = a.sched.nWaves;
+    static const int wpb = getenv("GTX_WAVES_PER_BLOCK") ? std::min(4, std::max(1, atoi(getenv("GTX_WAVES_PER_BLOCK")))) : 4;   // (the kernels size their LDS for 4)
     const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
     const unsigned bs = 64u * wpb;
     // a.prefetch = reads per lane per step (R)
     static const bool wfast = !(getenv("GTX_WEIGHTED_FAST") && atoi(getenv("GTX_WEIGHTED_FAST")) == 0);
-    if (weights && wfast && a.chunksPerWave % 4 == 0) count_walk_kernel_weighted<<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    if (weights && wfast) count_walk_kernel_weighted<<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (weights) count_walk_kernel<true, 2><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.prefetch <= 1) count_walk_kernel<false, 1><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.prefetch == 2) count_walk_kernel<false, 2><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.prefetch == 3) count_walk_kernel<false, 3><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.flip) count_walk_kernel_flip<<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (getenv("GTX_PF") && atoi(getenv("GTX_PF"))) count_walk_kernel_pf<<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else count_walk_kernel<false, 4><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   } else {
     // one 1024-thread block per CU (the LDS top level fills most of the CU's 160 KB)

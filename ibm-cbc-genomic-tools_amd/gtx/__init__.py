@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgtx.so")
+LIB_PATH = os.environ.get("GTX_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libgtx.so")   # GTX_LIB_PATH: diagnostic builds (make trace)
 
 READS_SORTED = 1
 CHECK_SORTED = 2
