@@ -262,6 +262,8 @@ GenomicRegionBED::GenomicRegionBED(char *inp, long int n_line)
 // ---------------------------------------------------------------------------------------------------
 // GenomicRegionSet
 // ---------------------------------------------------------------------------------------------------
+void StdoutIsOurs();   // (below, with the GPU start-up)
+
 GenomicRegionSet::GenomicRegionSet(char *file, unsigned long int buffer_size, bool verbose, bool load_in_memory, bool hide_header)
 {
   this->file = file == NULL ? NULL : CopyString(file); this->file_ptr = NULL;
@@ -353,7 +355,7 @@ void GenomicRegionSet::Init()
   if (!src) { fprintf(stderr, "%s\n", err.c_str()); exit(1); }
   char *line = src->Next();
   while (line && (strncmp(line, "browser ", 8) == 0 || strncmp(line, "track ", 6) == 0)) {
-    if (!hide_header) printf("%s\n", line);
+    if (!hide_header) { StdoutIsOurs(); printf("%s\n", line); }
     line = src->Next();
   }
   if (!line) { format = "EMPTY"; n_regions = 0; }
@@ -588,6 +590,20 @@ static void JoinStartUp()
 {
   if (g_group_future.valid()) g_group_future.wait();
   if (g_pool_future.valid()) g_pool_future.wait();
+}
+
+// Descriptor 1 points at stderr while the library brings RCCL communicators up on the start-up thread (RCCL prints a banner):
+// nothing may reach stdout before that is over.  Only groups of more than one GPU (or the single-member RCCL self-test) make
+// communicators.
+void StdoutIsOurs()
+{
+  static bool checked = false;
+  if (checked) return;
+  checked = true;
+  int n = g_ngpu;
+  if (n <= 0) { const char *e = getenv("GTX_NGPU"); n = e ? atoi(e) : 1; }
+  const char *f = getenv("GTX_GROUP_FORCE_RCCL"), *x = getenv("GTX_GROUP_SELF_EXCHANGE");
+  if ((n > 1 || (f && atoi(f)) || (x && atoi(x))) && g_group_future.valid()) g_group_future.wait();
 }
 
 void GtxWarmUp()

@@ -34,6 +34,9 @@ struct gtx_ctx {
   // direct placement at the start of a span (gtx::PlaceTable): per class {segment start, end, first cell, cells}; per cell the rank
   // of the cell's first position in the ends array and in the starts array
   int4 *d_placeCls = nullptr; int *d_placeRank = nullptr; int placeShift = 0;
+  std::vector<int32_t> h_seg;                        // [nClasses+1] class segments of the sorted boundary arrays (host copy)
+  // a group member's share of the finalize step (gtxi_set_share): tiles of its classes, its regions in the group's compact order
+  bool shareOn = false; int *d_shareTiles = nullptr; int nShareTiles = 0; int *d_shareRegions = nullptr; int64_t nShareRegions = 0, shareOffset = 0;
   // unsorted reads, bucket path (gtx_bucket.hip): table built with the references, scratch sized by the largest call
   void *d_clsCell = nullptr, *d_cellTab = nullptr; int nCells = 0, cellShift = 0;   // direct-address bucket lookup (BucketTable)
   int *d_bktT = nullptr; void *d_clsCellT = nullptr, *d_cellTabT = nullptr; int nBT = 0, nCellsT = 0, cellShiftT = 0;   // the same tables over the coverage thresholds (cover_prepare)
@@ -76,6 +79,7 @@ struct gtx_ctx {
   long long stageSeq = 0; bool directPending = false;   // a DMA may still be reading the page-locked buffer of the last call
   int copyThreads = 8;                  // host threads that move a pageable batch into the pinned slot (GTX_COPY_THREADS)
   u64 *d_out = nullptr; size_t capOut = 0;
+  char *d_scratch = nullptr; size_t capScratch = 0;   // gtxi_scratch
 
   // scan state
   u64 *d_micro = nullptr; size_t capMicro = 0;
@@ -163,7 +167,7 @@ void gtx_destroy(gtx_ctx *c)
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
   dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab); dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;
-  dfree(c->d_placeCls); dfree(c->d_placeRank);
+  dfree(c->d_placeCls); dfree(c->d_placeRank); dfree(c->d_shareTiles); dfree(c->d_shareRegions);
   dfree(c->d_bktCnt); dfree(c->d_bktS); dfree(c->d_clsCellS); dfree(c->d_cellTabS); dfree(c->d_scanParts); dfree(c->d_scanInfo); c->nBS = 0;
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
@@ -175,7 +179,7 @@ void gtx_destroy(gtx_ctx *c)
     if (c->evRes[k]) (void)hipEventDestroy(c->evRes[k]);
   }
   if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
-  dfree(c->d_out); dfree(c->d_micro); dfree(c->d_scanTab); dfree(c->d_scanBounds); dfree(c->d_scanFlag); dfree(c->d_resReads); dfree(c->d_resWeights);
+  dfree(c->d_out); dfree(c->d_scratch); dfree(c->d_micro); dfree(c->d_scanTab); dfree(c->d_scanBounds); dfree(c->d_scanFlag); dfree(c->d_resReads); dfree(c->d_resWeights);
   for (auto &p : c->d_cov) dfree(p);
   dfree(c->d_sortedT); dfree(c->d_segT); dfree(c->d_topT); dfree(c->d_posTE); dfree(c->d_posTS); dfree(c->d_classBaseT);
   dfree(c->d_refS); dfree(c->d_refE); dfree(c->d_refC); dfree(c->d_specialRefs); dfree(c->d_specialIdx); dfree(c->d_specialOut); dfree(c->d_side); dfree(c->d_sideCount);
@@ -432,6 +436,8 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
     }
   }
   c->nRefs = m; c->nValid = nv; c->nClasses = nClasses; c->histLen = histLen;
+  c->h_seg = seg;
+  c->shareOn = false; dfree(c->d_shareTiles); dfree(c->d_shareRegions); c->nShareTiles = 0; c->nShareRegions = 0; c->shareOffset = 0;
   return GTX_OK;
 }
 
@@ -612,10 +618,13 @@ static int count_begin(gtx_ctx *c)
   return GTX_OK;
 }
 
-static int count_end(gtx_ctx *c, void *d_hits)
+// share: the context is a group member -- finalize its classes only, d_hits receives its regions in the group's compact order
+static int count_end(gtx_ctx *c, void *d_hits, bool share = false)
 {
+  gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions};
   HIPCHK(c, gtx::launch_finalize(c->d_histA, c->d_histB, c->histLen, c->d_partA, c->d_partB, c->tileSumsValid, c->d_prefA, c->d_prefB,
-                                 c->d_posE, c->d_posS, c->d_classBase, c->nRefs, (u64 *)d_hits, c->d_info + (c->infoCur ^ 1), c->stream));
+                                 c->d_posE, c->d_posS, c->d_classBase, c->nRefs, (u64 *)d_hits, c->d_info + (c->infoCur ^ 1), c->stream,
+                                 share ? &fs : nullptr));
   { int rc = merge_end(c, d_hits); if (rc) return rc; }
   c->histDirty = false;
   c->infoCur ^= 1;                                // the block just used stays readable until the call after next
@@ -802,15 +811,18 @@ int gtx_count_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int6
 }
 
 // closes the open stream call: finalize into the context's own output vector in HBM (enqueued, not waited for)
-int gtxi_count_finish(gtx_ctx *c, void **d_out)
+// share != 0 (a group member with gtxi_set_share): only its classes are finalized, *d_out = its piece of the group's compact vector
+int gtxi_count_finish(gtx_ctx *c, void **d_out, int share)
 {
   if (!c->streamOpen) return fail(c, GTX_E_STATE, "gtx_count_end: gtx_count_begin has not been called");
+  if (share && !c->shareOn) return fail(c, GTX_E_STATE, "gtxi_count_finish: no share set");
   HIPCHK(c, hipSetDevice(c->device));
   c->streamOpen = false;
   int rc = ensure_out(c, (size_t)c->nRefs); if (rc) return rc;
-  rc = count_end(c, c->d_out); if (rc) return rc;
+  u64 *dst = share ? c->d_out + c->shareOffset : c->d_out;
+  rc = count_end(c, dst, share != 0); if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + (c->infoCur ^ 1), sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
-  *d_out = c->d_out;
+  *d_out = dst;
   return GTX_OK;
 }
 
@@ -826,7 +838,7 @@ int gtx_count_end(gtx_ctx *c, uint64_t *hits, gtx_count_info *info)
   if (!c) return GTX_E_ARG;
   if (c->streamOpen && c->nRefs > 0 && !hits) return fail(c, GTX_E_ARG, "gtx_count_end: null output");
   void *d = nullptr;
-  int rc = gtxi_count_finish(c, &d); if (rc) return rc;
+  int rc = gtxi_count_finish(c, &d, 0); if (rc) return rc;
   if (c->nRefs > 0) HIPCHK(c, hipMemcpyAsync(hits, d, sizeof(u64) * c->nRefs, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipStreamSynchronize(c->copyStream));
@@ -1421,6 +1433,85 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
   if (extent > 0) HIPCHK(c, hipMemcpyAsync(out, d, (size_t)extent * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipStreamSynchronize(c->copyStream));
+  return GTX_OK;
+}
+
+// A group member's share: the classes `owned` (flags per class).  tiles = the 1024-slot histogram tiles that hold a slot of an
+// owned class or the slot just below its first (class c has slots seg[c]+c-1 .. seg[c+1]+c: the gather reads the prefix at the
+// slot below as the class's base); regions = `regions[0..nRegions)`, the file indices of the member's regions in the group's
+// compact order, its piece beginning at compact position `offset`.
+int gtxi_set_share(gtx_ctx *c, const uint8_t *owned, int32_t nClasses, const int32_t *regions, int64_t nRegions, int64_t offset)
+{
+  if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtxi_set_share: gtx_set_refs has not been called");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int nTilesAll = gtx::scan_tiles(c->histLen);
+  std::vector<uint8_t> mark(nTilesAll > 0 ? nTilesAll : 1, 0);
+  for (int cl = 0; cl < c->nClasses && cl < nClasses; cl++) {
+    if (!owned[cl] || c->h_seg[cl] == c->h_seg[cl + 1]) continue;
+    const int64_t lo = std::max<int64_t>(0, (int64_t)c->h_seg[cl] + cl - 1), hi = (int64_t)c->h_seg[cl + 1] + cl;   // slots lo..hi
+    for (int64_t t = lo >> 10; t <= (hi >> 10) && t < nTilesAll; t++) mark[t] = 1;
+  }
+  std::vector<int32_t> tiles;
+  for (int t = 0; t < nTilesAll; t++) if (mark[t]) tiles.push_back(t);
+  dfree(c->d_shareTiles); dfree(c->d_shareRegions);
+  HIPCHK(c, hipMalloc(&c->d_shareTiles, sizeof(int32_t) * (tiles.size() + 1)));
+  HIPCHK(c, hipMalloc(&c->d_shareRegions, sizeof(int32_t) * (size_t)(nRegions + 1)));
+  if (!tiles.empty()) HIPCHK(c, hipMemcpy(c->d_shareTiles, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice));
+  if (nRegions > 0) HIPCHK(c, hipMemcpy(c->d_shareRegions, regions, sizeof(int32_t) * (size_t)nRegions, hipMemcpyHostToDevice));
+  c->nShareTiles = (int)tiles.size(); c->nShareRegions = nRegions; c->shareOffset = offset; c->shareOn = true;
+  return ensure_out(c, (size_t)c->nRefs);
+}
+
+// gtx_count_device for a group member: the reads (of the member's classes, resident on its device) are counted and the member's
+// regions finalized into its piece of the compact vector, c->d_out + shareOffset.  Enqueued on the context's stream.
+int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, void **d_piece, int64_t *pieceLen)
+{
+  if (!c->shareOn) return fail(c, GTX_E_STATE, "gtxi_count_device_share: no share set");
+  if (n < 0 || (n > 0 && !d_reads)) return fail(c, GTX_E_ARG, "gtx_group_count_device: bad argument");
+  if (flags & GTX_ZERO_LENGTH_OK) return fail(c, GTX_E_ARG, "gtx_group_count_device: GTX_ZERO_LENGTH_OK (sorted-merge semantics with their host-side corrections) is served by the host-buffer group calls only");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = count_begin(c); if (rc) return rc;
+  c->profThis = c->prof && (c->profEvery <= 1 || (c->profSeq++ % c->profEvery) == 0);
+  if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
+  const bool streaming = (flags & (GTX_READS_SORTED | GTX_CHECK_SORTED)) != 0;
+  if (!streaming) c->tileSumsValid = false;
+  if (n > 0) {
+    if (streaming) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), true, c->stream));
+    else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n)); if (rc) return rc; }
+  }
+  if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  rc = count_end(c, c->d_out + c->shareOffset, true); if (rc) return rc;
+  if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
+  *d_piece = c->d_out + c->shareOffset; *pieceLen = c->nShareRegions;
+  return GTX_OK;
+}
+
+void *gtxi_out_buffer(gtx_ctx *c) { return c->d_out; }
+int gtxi_ensure_out(gtx_ctx *c, int64_t n)
+{
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((size_t)n > c->capOut) HIPCHK(c, hipStreamSynchronize(c->stream));      // (the old vector may still be read)
+  return ensure_out(c, (size_t)std::max<int64_t>(n, 0));
+}
+// a second device buffer of the context (grown, never shrunk): where a group's member 0 assembles a result
+int gtxi_scratch(gtx_ctx *c, size_t bytes, void **p)
+{
+  HIPCHK(c, hipSetDevice(c->device));
+  if (bytes > c->capScratch) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dfree(c->d_scratch); c->capScratch = 0;
+    HIPCHK(c, hipMalloc(&c->d_scratch, bytes));
+    c->capScratch = bytes;
+  }
+  *p = c->d_scratch;
+  return GTX_OK;
+}
+
+// a DMA out of the caller's page-locked buffer may still be in flight (stage_batches returns with it enqueued): wait for it
+int gtxi_wait_direct(gtx_ctx *c)
+{
+  if (c->directPending) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->copyStream)); c->directPending = false; }
   return GTX_OK;
 }
 

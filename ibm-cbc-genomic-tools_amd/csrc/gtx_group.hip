@@ -2,12 +2,19 @@
 //
 // Two regions can overlap only on one chromosome [and strand] (GenomicInterval::OverlapsWith,
 // gtools/genomic_intervals.cpp:624-630), so the reads and regions of one class are an independent unit of work: classes
-// are dealt to the GPUs (longest-processing-time packing of a per-class load), every GPU holds the whole reference set and
-// counts the reads of its classes into a full-length vector, and ONE RCCL reduce(sum) of that uint64 vector over xGMI
-// yields the result -- the vectors are disjoint by class, so the sum is the single-GPU vector bit for bit.  The sliding
-// windows of genomic_scans are per chromosome and strand as well: the same split, the same reduce of the window vector.
-// One process drives all devices (the reference's tools are single processes): a context per device, asynchronous
-// enqueues from the caller's thread, librccl resolved at run time (only a group of more than one device needs it).
+// are dealt to the members of a group (longest-processing-time packing of a per-class load), every member holds the whole
+// reference set (20 MB) and counts the reads of ITS classes.  What a member does after its streaming kernel shrinks with its
+// share: it finalizes only the histogram tiles of its classes and only its regions, into its piece of a COMPACT vector -- the
+// regions ordered by (owner of their class, position in the file) -- and the pieces travel to member 0 over xGMI with one
+// grouped RCCL send / receive per member (the reduce of north_star with its addends known to be disjoint: a sum of the members'
+// zero-padded full vectors would move and add N times the bytes).  Member 0 puts the compact vector into file order.  The
+// sliding windows of genomic_scans are per class as well: a member scans its classes into a packed vector of its own and the
+// per-class pieces travel the same way.
+//
+// A group is either ONE process driving all devices (gtx_group_create: a context per device, asynchronous enqueues from the
+// caller's thread -- the reference's tools are single processes) or one process per device (gtx_group_create_rank: the same
+// object holding only the local member, the communicator made from an id the caller's launcher hands around -- the shape of
+// `python -m torch.distributed.run bench.py`).  librccl is resolved at run time; a group of one needs none.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdint.h>
@@ -28,10 +35,14 @@ namespace {
 struct Rccl {
   void *lib = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   bool load(std::string *err)
   {
@@ -39,46 +50,83 @@ struct Rccl {
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
     if (!lib) { *err = std::string("gtx_group: cannot load librccl: ") + dlerror(); return false; }
     CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+    GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
     GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
     Reduce = (decltype(Reduce))dlsym(lib, "ncclReduce");
+    Send = (decltype(Send))dlsym(lib, "ncclSend");
+    Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
     GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Reduce || !GetErrorString) { *err = "gtx_group: librccl lacks an expected symbol"; return false; }
+    if (!CommInitAll || !CommInitRank || !GetUniqueId || !CommDestroy || !GroupStart || !GroupEnd || !Reduce || !Send || !Recv || !GetErrorString) {
+      *err = "gtx_group: librccl lacks an expected symbol"; return false;
+    }
     return true;
   }
 };
 
+// RCCL announces its version with a printf on the process's stdout when the first communicator comes up, whatever NCCL_DEBUG
+// says (checked: it does under NCCL_DEBUG=WARN); the tools' stdout is their result.  Descriptor 1 points at stderr while a
+// communicator is being made.  The swap is process-wide: a caller that has other threads writing to stdout must keep them
+// from flushing it until gtx_group_create / gtx_group_create_rank has returned (include/gtx.h; the tools hold their header
+// lines back, csrc/genomic_intervals.cpp: StdoutIsOurs).
+struct StdoutAside {
+  int saved;
+  StdoutAside() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+  ~StdoutAside() { fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+};
+
 thread_local std::string g_group_create_error;
+static_assert(sizeof(ncclUniqueId) == GTX_GROUP_ID_BYTES, "include/gtx.h states the size of the communicator id");
 
 // rehearsal on one device (GTX_GROUP_REHEARSE=1: all members may sit on the same GPU, which RCCL refuses): the members'
-// vectors are summed by this kernel instead of ncclReduce.  Exercises the routing and the finish on a one-GPU box.
+// full vectors of the legacy finish are summed by this kernel instead of ncclReduce
 __global__ void rehearse_add_kernel(unsigned long long *__restrict__ root, const unsigned long long *__restrict__ other, long long n)
 {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) root[i] += other[i];
 }
 
+// member 0: the compact vector (regions ordered by owner, then file position) into file order
+__global__ __launch_bounds__(256) void unpermute_kernel(const unsigned long long *__restrict__ compact, const int *__restrict__ perm, long long m,
+                                                        unsigned long long *__restrict__ hits)
+{
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) hits[perm[j]] = compact[j];
+}
+
 }  // namespace
 
 struct gtx_group {
-  std::vector<gtx_ctx *> ctx;
+  int nm = 0;                              // members of the group (all processes together)
+  int rank = -1;                           // >= 0: one process per member, this process holds member `rank` only
+  std::vector<gtx_ctx *> ctx;              // the local members' contexts (all of them, or one)
   std::vector<int> dev;
-  std::vector<ncclComm_t> comm;            // empty for a group of one (unless GTX_GROUP_FORCE_RCCL=1)
+  std::vector<ncclComm_t> comm;            // per local member; empty for a group of one (unless GTX_GROUP_FORCE_RCCL=1)
   Rccl rccl;
   std::string err;
   std::vector<int32_t> owner;              // class -> member
   std::vector<int64_t> memberReads;        // reads routed to each member in the open call
   bool countOpen = false, coverOpen = false;
   bool rehearse = false;                   // GTX_GROUP_REHEARSE=1
-  int64_t nRefs = 0;
+  bool selfExchange = false;               // GTX_GROUP_SELF_EXCHANGE=1 (test hook): member 0's own piece travels through RCCL to itself
+  int64_t nRefs = 0; uint32_t refFlags = 0; int32_t nClasses = 0;
+  std::vector<int32_t> refClass;           // class of every reference region (file order)
+  // compact layout (gtx_group_plan): piece of member m = compact positions segOff[m] .. segOff[m+1]
+  bool planValid = false; std::vector<int64_t> segOff; std::vector<int32_t> perm;
+  int *d_perm = nullptr; unsigned long long *d_selfTmp = nullptr; size_t capSelfTmp = 0;
+  hipEvent_t evPiece = nullptr;            // rehearsal: a member's piece is ready
   // scratch of the router for interleaved input
   std::vector<std::vector<int32_t>> partTri, partW;
+
+  int local(int m) const { return rank >= 0 ? (m == rank ? 0 : -1) : m; }     // index into ctx / comm, -1 = another process's
+  int member(int li) const { return rank >= 0 ? rank : li; }
 };
 
 #define GCHK_HIP(g, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (g)->err = std::string(#call) + ": " + hipGetErrorString(e_); return GTX_E_HIP; } } while (0)
 #define GCHK_NCCL(g, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { (g)->err = std::string(#call) + ": " + (g)->rccl.GetErrorString(r_); return GTX_E_HIP; } } while (0)
-#define GCHK_CTX(g, i, call) do { int rc_ = (call); if (rc_ != GTX_OK) { (g)->err = std::string("member ") + std::to_string(i) + ": " + gtx_last_error((g)->ctx[i]); return rc_; } } while (0)
+#define GCHK_CTX(g, i, call) do { int rc_ = (call); if (rc_ != GTX_OK) { (g)->err = std::string("member ") + std::to_string((g)->member(i)) + ": " + gtx_last_error((g)->ctx[i]); return rc_; } } while (0)
 
 static int gfail(gtx_group *g, int code, const char *msg) { g->err = msg; return code; }
 
@@ -88,7 +136,9 @@ gtx_group *gtx_group_create(int n, const int *device_ids)
 {
   if (n < 1) { g_group_create_error = "gtx_group_create: need at least one device"; return nullptr; }
   gtx_group *g = new gtx_group();
+  g->nm = n;
   { const char *rh = getenv("GTX_GROUP_REHEARSE"); g->rehearse = rh && atoi(rh); }
+  { const char *se = getenv("GTX_GROUP_SELF_EXCHANGE"); g->selfExchange = se && atoi(se); }
   for (int i = 0; i < n; i++) {
     const int d = device_ids ? device_ids[i] : i;
     for (int j = 0; j < i && !g->rehearse; j++) if (g->dev[j] == d) { g_group_create_error = "gtx_group_create: a device is listed twice"; gtx_group_destroy(g); return nullptr; }
@@ -97,17 +147,11 @@ gtx_group *gtx_group_create(int n, const int *device_ids)
     g->ctx.push_back(c); g->dev.push_back(d);
   }
   const char *force = getenv("GTX_GROUP_FORCE_RCCL");
-  if (!g->rehearse && (n > 1 || (force && atoi(force)))) {
+  if (!g->rehearse && (n > 1 || (force && atoi(force)) || g->selfExchange)) {
     if (!g->rccl.load(&g_group_create_error)) { gtx_group_destroy(g); return nullptr; }
     g->comm.resize(n);
-    // RCCL announces its version on the process's stdout when the first communicator comes up; the tools' stdout is
-    // their result.  The descriptor points at stderr for the duration of the call.
-    fflush(stdout);
-    const int saved = dup(1);
-    if (saved >= 0) dup2(2, 1);
-    ncclResult_t r = g->rccl.CommInitAll(g->comm.data(), n, g->dev.data());
-    fflush(stdout);
-    if (saved >= 0) { dup2(saved, 1); close(saved); }
+    ncclResult_t r;
+    { StdoutAside aside; r = g->rccl.CommInitAll(g->comm.data(), n, g->dev.data()); }
     if (r != ncclSuccess) { g_group_create_error = std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(r); g->comm.clear(); gtx_group_destroy(g); return nullptr; }
   }
   g->memberReads.assign(n, 0);
@@ -115,20 +159,66 @@ gtx_group *gtx_group_create(int n, const int *device_ids)
   return g;
 }
 
+int gtx_group_unique_id(void *id_out)
+{
+  if (!id_out) return GTX_E_ARG;
+  Rccl r;
+  if (!r.load(&g_group_create_error)) return GTX_E_HIP;
+  ncclUniqueId id;
+  ncclResult_t rc = r.GetUniqueId(&id);
+  if (rc != ncclSuccess) { g_group_create_error = std::string("ncclGetUniqueId: ") + r.GetErrorString(rc); return GTX_E_HIP; }
+  memcpy(id_out, &id, sizeof id);
+  return GTX_OK;
+}
+
+gtx_group *gtx_group_create_rank(int device_id, int rank, int world, const void *unique_id)
+{
+  if (world < 1 || rank < 0 || rank >= world) { g_group_create_error = "gtx_group_create_rank: bad rank / world size"; return nullptr; }
+  if (world > 1 && !unique_id) { g_group_create_error = "gtx_group_create_rank: a group of more than one process needs the id of gtx_group_unique_id"; return nullptr; }
+  gtx_group *g = new gtx_group();
+  g->nm = world; g->rank = rank;
+  { const char *se = getenv("GTX_GROUP_SELF_EXCHANGE"); g->selfExchange = se && atoi(se) && world == 1; }
+  gtx_ctx *c = gtx_create(device_id);
+  if (!c) { g_group_create_error = gtx_last_error(nullptr); delete g; return nullptr; }
+  g->ctx.push_back(c); g->dev.push_back(device_id);
+  if (world > 1 || (unique_id && g->selfExchange)) {
+    if (!g->rccl.load(&g_group_create_error)) { gtx_group_destroy(g); return nullptr; }
+    ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
+    g->comm.resize(1);
+    ncclResult_t r;
+    { StdoutAside aside; r = g->rccl.CommInitRank(&g->comm[0], world, id, rank); }     // (on the device of the calling thread: gtx_create has set it)
+    if (r != ncclSuccess) { g_group_create_error = std::string("ncclCommInitRank: ") + g->rccl.GetErrorString(r); g->comm.clear(); gtx_group_destroy(g); return nullptr; }
+  }
+  g->memberReads.assign(world, 0);
+  return g;
+}
+
 void gtx_group_destroy(gtx_group *g)
 {
   if (!g) return;
   for (ncclComm_t c : g->comm) if (c) g->rccl.CommDestroy(c);
+  if (!g->ctx.empty()) {
+    (void)hipSetDevice(g->dev[0]);
+    if (g->d_perm) (void)hipFree(g->d_perm);
+    if (g->d_selfTmp) (void)hipFree(g->d_selfTmp);
+    if (g->evPiece) (void)hipEventDestroy(g->evPiece);
+  }
   for (gtx_ctx *c : g->ctx) gtx_destroy(c);
   delete g;
 }
 
-int gtx_group_size(const gtx_group *g) { return g ? (int)g->ctx.size() : 0; }
-gtx_ctx *gtx_group_ctx(gtx_group *g, int member) { return g && member >= 0 && member < (int)g->ctx.size() ? g->ctx[member] : nullptr; }
+int gtx_group_size(const gtx_group *g) { return g ? g->nm : 0; }
+int gtx_group_rank(const gtx_group *g) { return g ? g->rank : -1; }
+gtx_ctx *gtx_group_ctx(gtx_group *g, int member)
+{
+  if (!g || member < 0 || member >= g->nm) return nullptr;
+  const int li = g->local(member);
+  return li >= 0 ? g->ctx[li] : nullptr;
+}
 const char *gtx_group_last_error(const gtx_group *g) { return g ? g->err.c_str() : g_group_create_error.c_str(); }
 
 // longest-processing-time packing: classes by decreasing load, each to the member with the least load so far
-// (ties: lowest class id first, lowest member first -- deterministic)
+// (ties: lowest class id first, lowest member first -- deterministic, so every process of a group computes the same)
 void gtx_lpt_assign(const int64_t *load, int32_t n_classes, int n_members, int32_t *owner_out)
 {
   std::vector<int32_t> order(n_classes);
@@ -142,11 +232,28 @@ void gtx_lpt_assign(const int64_t *load, int32_t n_classes, int n_members, int32
   }
 }
 
+// the compact order of a group's result: regions by (owner of their class, position in the file); regions of no class (a
+// placeholder, or an id beyond the assignment) belong to member 0.  Pure host code.
+int gtx_group_plan(const int32_t *ref_class, int64_t stride, int64_t n_refs, const int32_t *owner, int32_t n_classes, int n_members,
+                   int64_t *seg_offset, int32_t *perm)
+{
+  if (n_refs < 0 || n_members < 1 || (n_refs > 0 && (!ref_class || !perm)) || !seg_offset || (n_classes > 0 && !owner) || stride < 1) return GTX_E_ARG;
+  std::vector<int64_t> cnt(n_members + 1, 0);
+  auto own = [&](int64_t k) { const int32_t c = ref_class[k * stride]; const int o = (uint32_t)c < (uint32_t)n_classes ? owner[c] : 0; return o >= 0 && o < n_members ? o : 0; };
+  for (int64_t k = 0; k < n_refs; k++) cnt[own(k) + 1]++;
+  for (int m = 0; m < n_members; m++) cnt[m + 1] += cnt[m];
+  for (int m = 0; m <= n_members; m++) seg_offset[m] = cnt[m];
+  std::vector<int64_t> at(cnt.begin(), cnt.end() - 1);
+  for (int64_t k = 0; k < n_refs; k++) perm[at[own(k)]++] = (int32_t)k;
+  return GTX_OK;
+}
+
 int gtx_group_assign(gtx_group *g, const int64_t *class_load, int32_t n_classes, int32_t *owner_out)
 {
   if (!g || n_classes < 0 || (n_classes > 0 && !class_load)) return g ? gfail(g, GTX_E_ARG, "gtx_group_assign: bad argument") : GTX_E_ARG;
   g->owner.resize(n_classes);
-  gtx_lpt_assign(class_load, n_classes, (int)g->ctx.size(), g->owner.data());
+  gtx_lpt_assign(class_load, n_classes, g->nm, g->owner.data());
+  g->planValid = false;
   if (owner_out) memcpy(owner_out, g->owner.data(), sizeof(int32_t) * n_classes);
   return GTX_OK;
 }
@@ -161,17 +268,143 @@ int gtx_group_set_refs(gtx_group *g, const int32_t *tri, int64_t m, int32_t n_cl
   rc[0] = gtx_set_refs_ex(g->ctx[0], tri, m, n_classes, flags);
   for (auto &t : th) t.join();
   for (int i = 0; i < n; i++) GCHK_CTX(g, i, rc[i]);
-  g->nRefs = m;
-  if (g->owner.empty() && n_classes > 0) {
-    // no assignment given: load = the span of a class's reference regions, a stand-in for the chromosome length
-    int32_t nc = n_classes;
-    if (nc <= 0) { for (int64_t k = 0; k < m; k++) nc = std::max(nc, tri[3 * k] + 1); }
+  g->nRefs = m; g->refFlags = flags; g->planValid = false;
+  int32_t nc = n_classes;
+  if (nc <= 0) { nc = 1; for (int64_t k = 0; k < m; k++) nc = std::max(nc, tri[3 * k] + 1); }
+  g->nClasses = nc;
+  g->refClass.resize((size_t)m);
+  for (int64_t k = 0; k < m; k++) g->refClass[k] = tri[3 * k];
+  if ((int32_t)g->owner.size() != nc) {
+    // no assignment given for these classes: load = the span of a class's reference regions, a stand-in for the chromosome length
     std::vector<int64_t> lo(nc, INT64_MAX), hi(nc, INT64_MIN), load(nc, 0);
     for (int64_t k = 0; k < m; k++) { const int32_t c = tri[3 * k]; if (c < 0 || c >= nc) continue; lo[c] = std::min<int64_t>(lo[c], tri[3 * k + 1]); hi[c] = std::max<int64_t>(hi[c], tri[3 * k + 2]); }
     for (int32_t c = 0; c < nc; c++) load[c] = hi[c] >= lo[c] ? hi[c] - lo[c] + 1 : 0;
     g->owner.resize(nc);
-    gtx_lpt_assign(load.data(), nc, n, g->owner.data());
+    gtx_lpt_assign(load.data(), nc, g->nm, g->owner.data());
   }
+  return GTX_OK;
+}
+
+}  // extern "C"
+
+// the compact layout and every local member's share of the finalize step, (re)made when the reference set or the assignment changed
+static int ensure_plan(gtx_group *g)
+{
+  if (g->planValid) return GTX_OK;
+  const int64_t m = g->nRefs;
+  g->segOff.assign(g->nm + 1, 0); g->perm.assign((size_t)std::max<int64_t>(m, 1), 0);
+  int rc = gtx_group_plan(g->refClass.data(), 1, m, g->owner.data(), (int32_t)g->owner.size(), g->nm, g->segOff.data(), g->perm.data());
+  if (rc) return gfail(g, rc, "gtx_group: planning the compact layout failed");
+  std::vector<uint8_t> owned(std::max<size_t>(g->owner.size(), 1));
+  for (size_t li = 0; li < g->ctx.size(); li++) {
+    const int mem = g->member((int)li);
+    for (size_t c = 0; c < g->owner.size(); c++) owned[c] = g->owner[c] == mem;
+    GCHK_CTX(g, li, gtxi_set_share(g->ctx[li], owned.data(), (int32_t)g->owner.size(), g->perm.data() + g->segOff[mem], g->segOff[mem + 1] - g->segOff[mem], g->segOff[mem]));
+  }
+  if (g->local(0) >= 0) {
+    GCHK_HIP(g, hipSetDevice(g->dev[g->local(0)]));
+    if (g->d_perm) { (void)hipFree(g->d_perm); g->d_perm = nullptr; }
+    GCHK_HIP(g, hipMalloc(&g->d_perm, sizeof(int32_t) * (size_t)std::max<int64_t>(m, 1)));
+    if (m > 0) GCHK_HIP(g, hipMemcpy(g->d_perm, g->perm.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice));
+    if (!g->evPiece) GCHK_HIP(g, hipEventCreateWithFlags(&g->evPiece, hipEventDisableTiming));
+  }
+  g->planValid = true;
+  return GTX_OK;
+}
+
+// The pieces of the compact vector travel to member 0: piece[li] / len of every local member (already finalized on its stream);
+// member 0 receives at root + segOff[m] (its own piece is in place).  One grouped RCCL call per process; asynchronous.
+static int gather_pieces(gtx_group *g, const std::vector<void *> &piece, unsigned long long *root)
+{
+  const int l0 = g->local(0);
+  if (l0 >= 0) GCHK_HIP(g, hipSetDevice(g->dev[l0]));
+  if (g->rehearse) {                                       // one device, no RCCL: copies on member 0's stream behind the members' events
+    for (size_t li = 0; li < g->ctx.size(); li++) {
+      const int mem = g->member((int)li); const int64_t len = g->segOff[mem + 1] - g->segOff[mem];
+      if (mem == 0 || len == 0) continue;
+      GCHK_HIP(g, hipEventRecord(g->evPiece, gtxi_stream(g->ctx[li])));
+      GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[l0]), g->evPiece, 0));
+      GCHK_HIP(g, hipMemcpyAsync(root + g->segOff[mem], piece[li], sizeof(uint64_t) * (size_t)len, hipMemcpyDeviceToDevice, gtxi_stream(g->ctx[l0])));
+    }
+    return GTX_OK;
+  }
+  if (g->comm.empty()) return GTX_OK;
+  const int64_t len0 = g->segOff[1] - g->segOff[0];
+  if (g->selfExchange && l0 >= 0 && len0 > 0) {            // test hook: member 0's piece leaves and comes back through RCCL
+    GCHK_HIP(g, hipSetDevice(g->dev[l0]));
+    if ((size_t)len0 > g->capSelfTmp) { if (g->d_selfTmp) (void)hipFree(g->d_selfTmp); g->d_selfTmp = nullptr; GCHK_HIP(g, hipMalloc(&g->d_selfTmp, sizeof(uint64_t) * (size_t)len0)); g->capSelfTmp = (size_t)len0; }
+    GCHK_HIP(g, hipMemcpyAsync(g->d_selfTmp, root + g->segOff[0], sizeof(uint64_t) * (size_t)len0, hipMemcpyDeviceToDevice, gtxi_stream(g->ctx[l0])));
+    GCHK_HIP(g, hipMemsetAsync(root + g->segOff[0], 0xff, sizeof(uint64_t) * (size_t)len0, gtxi_stream(g->ctx[l0])));
+  }
+  GCHK_NCCL(g, g->rccl.GroupStart());
+  ncclResult_t r = ncclSuccess;
+  for (size_t li = 0; li < g->ctx.size() && r == ncclSuccess; li++) {
+    const int mem = g->member((int)li); const int64_t len = g->segOff[mem + 1] - g->segOff[mem];
+    if (mem != 0 && len > 0) r = g->rccl.Send(piece[li], (size_t)len, ncclUint64, 0, g->comm[li], gtxi_stream(g->ctx[li]));
+  }
+  if (l0 >= 0) {
+    for (int mem = 1; mem < g->nm && r == ncclSuccess; mem++) {
+      const int64_t len = g->segOff[mem + 1] - g->segOff[mem];
+      if (len > 0) r = g->rccl.Recv(root + g->segOff[mem], (size_t)len, ncclUint64, mem, g->comm[l0], gtxi_stream(g->ctx[l0]));
+    }
+    if (g->selfExchange && len0 > 0 && r == ncclSuccess) {
+      r = g->rccl.Send(g->d_selfTmp, (size_t)len0, ncclUint64, 0, g->comm[l0], gtxi_stream(g->ctx[l0]));
+      if (r == ncclSuccess) r = g->rccl.Recv(root + g->segOff[0], (size_t)len0, ncclUint64, 0, g->comm[l0], gtxi_stream(g->ctx[l0]));
+    }
+  }
+  if (r != ncclSuccess) { g->rccl.GroupEnd(); g->err = std::string("ncclSend/ncclRecv: ") + g->rccl.GetErrorString(r); return GTX_E_HIP; }
+  GCHK_NCCL(g, g->rccl.GroupEnd());
+  return GTX_OK;
+}
+
+// member 0: compact -> file order into d_hits (enqueued on its stream)
+static int unpermute(gtx_group *g, const unsigned long long *root, void *d_hits)
+{
+  const int l0 = g->local(0);
+  if (l0 < 0 || g->nRefs <= 0) return GTX_OK;
+  GCHK_HIP(g, hipSetDevice(g->dev[l0]));
+  unpermute_kernel<<<(unsigned)((g->nRefs + 255) / 256), 256, 0, gtxi_stream(g->ctx[l0])>>>(root, g->d_perm, g->nRefs, (unsigned long long *)d_hits);
+  GCHK_HIP(g, hipGetLastError());
+  return GTX_OK;
+}
+
+extern "C" {
+
+int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void *const *d_weights, const int64_t *n_reads, uint32_t flags, void *d_hits)
+{
+  if (!g) return GTX_E_ARG;
+  if (!d_reads || !n_reads) return gfail(g, GTX_E_ARG, "gtx_group_count_device: bad argument");
+  if (g->local(0) >= 0 && g->nRefs > 0 && !d_hits) return gfail(g, GTX_E_ARG, "gtx_group_count_device: member 0 needs the output vector");
+  int rc = ensure_plan(g); if (rc) return rc;
+  std::vector<void *> piece(g->ctx.size(), nullptr);
+  for (size_t li = 0; li < g->ctx.size(); li++) {
+    int64_t len = 0;
+    g->memberReads[g->member((int)li)] = n_reads[li];
+    GCHK_CTX(g, li, gtxi_count_device_share(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, &piece[li], &len));
+  }
+  const int l0 = g->local(0);
+  unsigned long long *root = l0 >= 0 ? (unsigned long long *)gtxi_out_buffer(g->ctx[l0]) : nullptr;
+  rc = gather_pieces(g, piece, root); if (rc) return rc;
+  return unpermute(g, root, d_hits);
+}
+
+int gtx_group_sync(gtx_group *g)
+{
+  if (!g) return GTX_E_ARG;
+  for (size_t li = 0; li < g->ctx.size(); li++) GCHK_CTX(g, li, gtx_sync(g->ctx[li]));
+  return GTX_OK;
+}
+
+int gtx_group_last_info(gtx_group *g, gtx_count_info *info)
+{
+  if (!g || !info) return GTX_E_ARG;
+  gtx_count_info tot; tot.first_unsorted = -1; tot.first_degenerate = -1; tot.n_no_class = 0; tot.n_degenerate = 0; tot.n_unplaced = 0;
+  for (size_t li = 0; li < g->ctx.size(); li++) {
+    gtx_count_info one;
+    GCHK_CTX(g, li, gtx_last_info(g->ctx[li], &one));
+    tot.n_no_class += one.n_no_class; tot.n_degenerate += one.n_degenerate; tot.n_unplaced += one.n_unplaced;
+  }
+  *info = tot;
   return GTX_OK;
 }
 
@@ -180,7 +413,7 @@ int gtx_group_set_refs(gtx_group *g, const int32_t *tri, int64_t m, int32_t n_cl
 // ---- routing -------------------------------------------------------------------------------------------------------------
 // A batch is cut into maximal runs of reads with one owner (sorted input: a handful per batch) and every run goes to its
 // member as it is -- a contiguous piece of the caller's buffer.  Input whose owners interleave (more than kMaxRuns runs)
-// is partitioned on the host, order kept inside every member's share.
+// is partitioned on the host by a few threads, order kept inside every member's share.
 static constexpr size_t kMaxRuns = 4096;
 
 static inline int owner_of(const gtx_group *g, int32_t cls) { return (uint32_t)cls < g->owner.size() ? g->owner[cls] : 0; }
@@ -219,33 +452,69 @@ static bool find_runs(const gtx_group *g, const int32_t *tri, int64_t n, std::ve
   return !hopeless && runs->size() <= kMaxRuns;
 }
 
+// interleaved owners: every member's reads gathered in stream order -- two passes over T slices of the batch (count per
+// (slice, member), then every slice copies into its own ranges of the members' buffers)
+static void partition_by_owner(gtx_group *g, const int32_t *tri, const int32_t *w, int64_t n)
+{
+  const int nm = g->nm;
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, n / (1 << 18)));
+  std::vector<std::vector<int64_t>> cnt(T, std::vector<int64_t>(nm, 0));
+  auto slice = [&](int t, bool place, const std::vector<std::vector<int64_t>> *at) {
+    const int64_t a = n * t / T, b = n * (t + 1) / T;
+    std::vector<int64_t> pos(nm, 0);
+    if (place) pos = (*at)[t];
+    for (int64_t i = a; i < b; i++) {
+      const int m = owner_of(g, tri[3 * i]);
+      if (!place) { cnt[t][m]++; continue; }
+      int32_t *dst = g->partTri[m].data() + 3 * pos[m];
+      dst[0] = tri[3 * i]; dst[1] = tri[3 * i + 1]; dst[2] = tri[3 * i + 2];
+      if (w) g->partW[m][pos[m]] = w[i];
+      pos[m]++;
+    }
+  };
+  { std::vector<std::thread> th; for (int t = 1; t < T; t++) th.emplace_back(slice, t, false, nullptr); slice(0, false, nullptr); for (auto &x : th) x.join(); }
+  std::vector<std::vector<int64_t>> at(T, std::vector<int64_t>(nm, 0));
+  for (int m = 0; m < nm; m++) {
+    int64_t run = 0;
+    for (int t = 0; t < T; t++) { at[t][m] = run; run += cnt[t][m]; }
+    g->partTri[m].resize((size_t)run * 3); g->partW[m].resize(w ? (size_t)run : 0);
+  }
+  { std::vector<std::thread> th; for (int t = 1; t < T; t++) th.emplace_back(slice, t, true, &at); slice(0, true, &at); for (auto &x : th) x.join(); }
+}
+
+// Every member's DMA out of the caller's previous page-locked batch must be done before the caller may refill it: the members
+// that get a piece of THIS batch wait by themselves (stage_batches), the others would not -- include/gtx.h promises the
+// caller its buffer back "when the next call has returned".
+static int wait_direct_all(gtx_group *g)
+{
+  for (size_t li = 0; li < g->ctx.size(); li++) GCHK_CTX(g, li, gtxi_wait_direct(g->ctx[li]));
+  return GTX_OK;
+}
+
 template <class Add>
 static int route(gtx_group *g, const int32_t *tri, const int32_t *w, int64_t n, Add add)
 {
-  const int nm = (int)g->ctx.size();
+  const int nm = g->nm;
+  int rc = wait_direct_all(g); if (rc) return rc;
   if (n <= 0) return GTX_OK;
   if (nm == 1) { g->memberReads[0] += n; return add(0, tri, w, n); }
   std::vector<Run> runs;
   if (find_runs(g, tri, n, &runs)) {
-    for (const Run &r : runs) { g->memberReads[r.owner] += r.b - r.a; int rc = add(r.owner, tri + 3 * r.a, w ? w + r.a : nullptr, r.b - r.a); if (rc) return rc; }
+    for (const Run &r : runs) { g->memberReads[r.owner] += r.b - r.a; rc = add(r.owner, tri + 3 * r.a, w ? w + r.a : nullptr, r.b - r.a); if (rc) return rc; }
     return GTX_OK;
   }
-  for (int m = 0; m < nm; m++) { g->partTri[m].clear(); g->partW[m].clear(); }
-  for (int64_t i = 0; i < n; i++) {
-    const int m = owner_of(g, tri[3 * i]);
-    g->partTri[m].insert(g->partTri[m].end(), tri + 3 * i, tri + 3 * i + 3);
-    if (w) g->partW[m].push_back(w[i]);
-  }
+  partition_by_owner(g, tri, w, n);
   for (int m = 0; m < nm; m++) {
     const int64_t cnt = (int64_t)(g->partTri[m].size() / 3);
     if (!cnt) continue;
     g->memberReads[m] += cnt;
-    int rc = add(m, g->partTri[m].data(), w ? g->partW[m].data() : nullptr, cnt); if (rc) return rc;
+    rc = add(m, g->partTri[m].data(), w ? g->partW[m].data() : nullptr, cnt); if (rc) return rc;
   }
   return GTX_OK;
 }
 
-// RCCL reduce(sum) of the members' uint64 vectors to member 0, each on its own stream
+// legacy finish (coverage; count on a reference set with sorted-merge semantics, whose inverted intervals are matched into the
+// full vector): RCCL reduce(sum) of the members' full uint64 vectors to member 0, each on its own stream
 static int reduce_to_root(gtx_group *g, std::vector<void *> &d, int64_t count)
 {
   const int n = (int)g->ctx.size();
@@ -271,10 +540,25 @@ static int finish(gtx_group *g, bool coverage, uint64_t *out, gtx_count_info *in
 {
   const int n = (int)g->ctx.size();
   std::vector<void *> d(n, nullptr);
-  for (int i = 0; i < n; i++) GCHK_CTX(g, i, coverage ? gtxi_coverage_finish(g->ctx[i], &d[i]) : gtxi_count_finish(g->ctx[i], &d[i]));
-  int rc = reduce_to_root(g, d, g->nRefs); if (rc) return rc;
+  // count on a plain reference set: every member finalizes its own classes into its piece of the compact vector
+  const bool pieces = !coverage && !(g->refFlags & GTX_REFS_KEEP_ZERO_LENGTH);
+  if (pieces) { int rc = ensure_plan(g); if (rc) return rc; }
+  for (int i = 0; i < n; i++) GCHK_CTX(g, i, coverage ? gtxi_coverage_finish(g->ctx[i], &d[i]) : gtxi_count_finish(g->ctx[i], &d[i], pieces ? 1 : 0));
   GCHK_HIP(g, hipSetDevice(g->dev[0]));
-  if (g->nRefs > 0) GCHK_HIP(g, hipMemcpyAsync(out, d[0], sizeof(uint64_t) * g->nRefs, hipMemcpyDeviceToHost, gtxi_stream(g->ctx[0])));
+  if (pieces) {
+    unsigned long long *root = (unsigned long long *)gtxi_out_buffer(g->ctx[0]);
+    int rc = gather_pieces(g, d, root); if (rc) return rc;
+    // compact -> file order on the way out: the host puts the copy in order (no second device vector)
+    if (g->nRefs > 0) {
+      std::vector<uint64_t> compact((size_t)g->nRefs);
+      GCHK_HIP(g, hipMemcpyAsync(compact.data(), root, sizeof(uint64_t) * g->nRefs, hipMemcpyDeviceToHost, gtxi_stream(g->ctx[0])));
+      GCHK_HIP(g, hipStreamSynchronize(gtxi_stream(g->ctx[0])));
+      for (int64_t j = 0; j < g->nRefs; j++) out[g->perm[j]] = compact[j];
+    }
+  } else {
+    int rc = reduce_to_root(g, d, g->nRefs); if (rc) return rc;
+    if (g->nRefs > 0) GCHK_HIP(g, hipMemcpyAsync(out, d[0], sizeof(uint64_t) * g->nRefs, hipMemcpyDeviceToHost, gtxi_stream(g->ctx[0])));
+  }
   gtx_count_info tot; tot.first_unsorted = -1; tot.first_degenerate = -1; tot.n_no_class = 0; tot.n_degenerate = 0; tot.n_unplaced = 0;
   for (int i = 0; i < n; i++) {
     GCHK_CTX(g, i, gtx_sync(g->ctx[i]));
@@ -285,11 +569,14 @@ static int finish(gtx_group *g, bool coverage, uint64_t *out, gtx_count_info *in
   return GTX_OK;
 }
 
+#define NEED_ALL_LOCAL(g, what) do { if ((g)->rank >= 0 && (g)->nm > 1) return gfail(g, GTX_E_STATE, what ": the host-buffer calls need a group that holds all its members (gtx_group_create); a rank of a multi-process group has the *_device calls"); } while (0)
+
 extern "C" {
 
 int gtx_group_count_begin(gtx_group *g)
 {
   if (!g) return GTX_E_ARG;
+  NEED_ALL_LOCAL(g, "gtx_group_count_begin");
   for (size_t i = 0; i < g->ctx.size(); i++) GCHK_CTX(g, i, gtx_count_begin(g->ctx[i]));
   std::fill(g->memberReads.begin(), g->memberReads.end(), 0);
   g->countOpen = true;
@@ -320,6 +607,7 @@ int gtx_group_count_end(gtx_group *g, uint64_t *hits, gtx_count_info *info)
 int gtx_group_coverage_begin(gtx_group *g)
 {
   if (!g) return GTX_E_ARG;
+  NEED_ALL_LOCAL(g, "gtx_group_coverage_begin");
   for (size_t i = 0; i < g->ctx.size(); i++) GCHK_CTX(g, i, gtx_coverage_begin(g->ctx[i]));
   std::fill(g->memberReads.begin(), g->memberReads.end(), 0);
   g->coverOpen = true;
@@ -349,65 +637,167 @@ int gtx_group_coverage_end(gtx_group *g, uint64_t *cov, gtx_count_info *info)
 int gtx_group_member_reads(const gtx_group *g, int64_t *reads_out)
 {
   if (!g || !reads_out) return GTX_E_ARG;
-  for (size_t i = 0; i < g->ctx.size(); i++) reads_out[i] = g->memberReads[i];
+  for (int i = 0; i < g->nm; i++) reads_out[i] = g->memberReads[i];
   return GTX_OK;
+}
+
+}  // extern "C"
+
+// ---- scans ---------------------------------------------------------------------------------------------------------------
+// A member scans the classes it owns into a PACKED vector of its own (the other classes get length 0: no micro-windows, no
+// windows, no memset of theirs), and the per-class pieces travel to member 0's vector in the caller's layout.
+struct ScanShare { std::vector<int32_t> len; std::vector<int64_t> off; int64_t extent = 0; };
+
+static void scan_assign(gtx_group *g, const int32_t *class_len, int32_t n_classes)
+{
+  if ((int32_t)g->owner.size() == n_classes) return;
+  std::vector<int64_t> load(n_classes);                          // no assignment given for these classes: by class length
+  for (int32_t c = 0; c < n_classes; c++) load[c] = class_len[c] > 0 ? class_len[c] : 0;
+  g->owner.resize(n_classes);
+  gtx_lpt_assign(load.data(), n_classes, g->nm, g->owner.data());
+  g->planValid = false;
+}
+
+static ScanShare scan_share(const gtx_group *g, int mem, const int32_t *class_len, int32_t n_classes, int32_t step, int32_t size)
+{
+  ScanShare s; s.len.assign(n_classes, 0); s.off.assign(n_classes, 0);
+  for (int32_t c = 0; c < n_classes; c++) {
+    if (g->owner[c] != mem) continue;
+    s.len[c] = class_len[c]; s.off[c] = s.extent;
+    s.extent += gtx_scan_n_windows(class_len[c] < 0 ? 0 : class_len[c], step, size);
+  }
+  return s;
+}
+
+// the per-class pieces of the members' packed vectors (piece[li], layout share[li]) to root (layout class_offsets) on member 0
+static int gather_windows(gtx_group *g, const std::vector<void *> &piece, const std::vector<ScanShare> &share, const int32_t *class_len, int32_t n_classes,
+                          int32_t step, int32_t size, const int64_t *class_offsets, unsigned long long *root)
+{
+  const int l0 = g->local(0);
+  auto nwin = [&](int32_t c) { return gtx_scan_n_windows(class_len[c] < 0 ? 0 : class_len[c], step, size); };
+  if (l0 >= 0) GCHK_HIP(g, hipSetDevice(g->dev[l0]));
+  // member 0's own classes: copies on its device
+  if (l0 >= 0)
+    for (int32_t c = 0; c < n_classes; c++) {
+      if (g->owner[c] != 0 || nwin(c) == 0) continue;
+      GCHK_HIP(g, hipMemcpyAsync(root + class_offsets[c], (const unsigned long long *)piece[l0] + share[l0].off[c], sizeof(uint64_t) * (size_t)nwin(c),
+                                 hipMemcpyDeviceToDevice, gtxi_stream(g->ctx[l0])));
+    }
+  if (g->rehearse) {
+    for (size_t li = 0; li < g->ctx.size(); li++) {
+      const int mem = g->member((int)li);
+      if (mem == 0) continue;
+      GCHK_HIP(g, hipEventRecord(g->evPiece, gtxi_stream(g->ctx[li])));
+      GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[l0]), g->evPiece, 0));
+      for (int32_t c = 0; c < n_classes; c++)
+        if (g->owner[c] == mem && nwin(c) > 0)
+          GCHK_HIP(g, hipMemcpyAsync(root + class_offsets[c], (const unsigned long long *)piece[li] + share[li].off[c], sizeof(uint64_t) * (size_t)nwin(c),
+                                     hipMemcpyDeviceToDevice, gtxi_stream(g->ctx[l0])));
+    }
+    return GTX_OK;
+  }
+  if (g->comm.empty()) return GTX_OK;
+  GCHK_NCCL(g, g->rccl.GroupStart());
+  ncclResult_t r = ncclSuccess;
+  for (int32_t c = 0; c < n_classes && r == ncclSuccess; c++) {          // class order on both sides: sends and receives of a pair match up
+    const int mem = g->owner[c];
+    if (mem == 0 || nwin(c) == 0) continue;
+    const int li = g->local(mem);
+    if (li >= 0) r = g->rccl.Send((const unsigned long long *)piece[li] + share[li].off[c], (size_t)nwin(c), ncclUint64, 0, g->comm[li], gtxi_stream(g->ctx[li]));
+    if (l0 >= 0 && r == ncclSuccess) r = g->rccl.Recv(root + class_offsets[c], (size_t)nwin(c), ncclUint64, mem, g->comm[l0], gtxi_stream(g->ctx[l0]));
+  }
+  if (r != ncclSuccess) { g->rccl.GroupEnd(); g->err = std::string("ncclSend/ncclRecv: ") + g->rccl.GetErrorString(r); return GTX_E_HIP; }
+  GCHK_NCCL(g, g->rccl.GroupEnd());
+  return GTX_OK;
+}
+
+extern "C" {
+
+int gtx_group_scan_device(gtx_group *g, const void *const *d_reads, const void *const *d_weights, const int64_t *n_reads, const int32_t *class_len,
+                          int32_t n_classes, int32_t win_step, int32_t win_size, char preprocess, uint32_t flags, void *d_windows, const int64_t *class_offsets)
+{
+  if (!g) return GTX_E_ARG;
+  if (!d_reads || !n_reads || n_classes < 1 || !class_len || !class_offsets) return gfail(g, GTX_E_ARG, "gtx_group_scan_device: bad argument");
+  if (win_step <= 0 || win_size <= 0 || win_size % win_step) return gfail(g, GTX_E_ARG, "gtx_group_scan_device: window size must be a positive multiple of window step");
+  scan_assign(g, class_len, n_classes);
+  if (g->local(0) >= 0 && !g->evPiece) { GCHK_HIP(g, hipSetDevice(g->dev[g->local(0)])); GCHK_HIP(g, hipEventCreateWithFlags(&g->evPiece, hipEventDisableTiming)); }
+  std::vector<ScanShare> share(g->ctx.size());
+  std::vector<void *> piece(g->ctx.size(), nullptr);
+  for (size_t li = 0; li < g->ctx.size(); li++) {
+    const int mem = g->member((int)li);
+    share[li] = scan_share(g, mem, class_len, n_classes, win_step, win_size);
+    g->memberReads[mem] = n_reads[li];
+    GCHK_CTX(g, li, gtxi_ensure_out(g->ctx[li], share[li].extent));
+    piece[li] = gtxi_out_buffer(g->ctx[li]);
+    GCHK_CTX(g, li, gtx_scan_device(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], share[li].len.data(), n_classes, win_step, win_size,
+                                    preprocess, flags, piece[li], share[li].off.data()));
+  }
+  if (g->local(0) >= 0 && !d_windows) {
+    int64_t extent = 0;
+    for (int32_t c = 0; c < n_classes; c++) extent += gtx_scan_n_windows(class_len[c] < 0 ? 0 : class_len[c], win_step, win_size);
+    if (extent > 0) return gfail(g, GTX_E_ARG, "gtx_group_scan_device: member 0 needs the output vector");
+  }
+  return gather_windows(g, piece, share, class_len, n_classes, win_step, win_size, class_offsets, (unsigned long long *)d_windows);
 }
 
 int gtx_group_scan(gtx_group *g, const int32_t *reads, const int32_t *weights, int64_t n, const int32_t *class_len, int32_t n_classes,
                    int32_t win_step, int32_t win_size, char preprocess, uint32_t flags, uint64_t *windows_out, const int64_t *class_offsets)
 {
   if (!g) return GTX_E_ARG;
+  NEED_ALL_LOCAL(g, "gtx_group_scan");
   if (n < 0 || (n > 0 && !reads) || n_classes < 1 || !class_len || !class_offsets) return gfail(g, GTX_E_ARG, "gtx_group_scan: bad argument");
-  const int nm = (int)g->ctx.size();
-  if ((int32_t)g->owner.size() != n_classes) {
-    // no assignment given for these classes: by class length
-    std::vector<int64_t> load(n_classes);
-    for (int32_t c = 0; c < n_classes; c++) load[c] = class_len[c] > 0 ? class_len[c] : 0;
-    g->owner.resize(n_classes);
-    gtx_lpt_assign(load.data(), n_classes, nm, g->owner.data());
+  const int nm = g->nm;
+  { int rc = wait_direct_all(g); if (rc) return rc; }
+  if (nm == 1) {
+    g->memberReads[0] = n;
+    void *d = nullptr; int64_t extent = 0;
+    GCHK_CTX(g, 0, gtxi_scan_enqueue(g->ctx[0], reads, weights, n, class_len, n_classes, win_step, win_size, preprocess, flags, class_offsets, &d, &extent));
+    if (extent > 0 && !windows_out) return gfail(g, GTX_E_ARG, "gtx_group_scan: null output");
+    GCHK_HIP(g, hipSetDevice(g->dev[0]));
+    if (extent > 0) GCHK_HIP(g, hipMemcpyAsync(windows_out, d, sizeof(uint64_t) * extent, hipMemcpyDeviceToHost, gtxi_stream(g->ctx[0])));
+    GCHK_CTX(g, 0, gtx_sync(g->ctx[0]));
+    return GTX_OK;
   }
+  scan_assign(g, class_len, n_classes);
+  if (!g->evPiece) { GCHK_HIP(g, hipSetDevice(g->dev[0])); GCHK_HIP(g, hipEventCreateWithFlags(&g->evPiece, hipEventDisableTiming)); }
   std::fill(g->memberReads.begin(), g->memberReads.end(), 0);
   // every member scans its share (a scan is one call per member: the shares are gathered first)
-  std::vector<std::vector<Run>> share(nm);
   std::vector<Run> runs;
   bool contiguous = true;
-  if (nm > 1 && n > 0) {
+  if (n > 0) {
     contiguous = find_runs(g, reads, n, &runs);
     std::vector<int> seen(nm, 0);
     for (const Run &r : runs) { if (seen[r.owner]++) contiguous = false; }
   }
-  std::vector<void *> d(nm, nullptr);
-  int64_t extent = 0;
-  if (nm == 1) {
-    g->memberReads[0] = n;
-    GCHK_CTX(g, 0, gtxi_scan_enqueue(g->ctx[0], reads, weights, n, class_len, n_classes, win_step, win_size, preprocess, flags, class_offsets, &d[0], &extent));
-  } else if (contiguous) {
-    std::vector<Run> mine(nm, Run{0, 0, 0});
-    for (const Run &r : runs) mine[r.owner] = r;
-    for (int m = 0; m < nm; m++) {
-      const Run &r = mine[m];
-      g->memberReads[m] = r.b - r.a;
-      GCHK_CTX(g, m, gtxi_scan_enqueue(g->ctx[m], reads + 3 * r.a, weights ? weights + r.a : nullptr, r.b - r.a, class_len, n_classes, win_step, win_size,
-                                        preprocess, flags, class_offsets, &d[m], &extent));
-    }
-  } else {
-    for (int m = 0; m < nm; m++) { g->partTri[m].clear(); g->partW[m].clear(); }
-    for (int64_t i = 0; i < n; i++) {
-      const int m = owner_of(g, reads[3 * i]);
-      g->partTri[m].insert(g->partTri[m].end(), reads + 3 * i, reads + 3 * i + 3);
-      if (weights) g->partW[m].push_back(weights[i]);
-    }
-    for (int m = 0; m < nm; m++) {
-      const int64_t cnt = (int64_t)(g->partTri[m].size() / 3);
-      g->memberReads[m] = cnt;
-      GCHK_CTX(g, m, gtxi_scan_enqueue(g->ctx[m], g->partTri[m].data(), weights ? g->partW[m].data() : nullptr, cnt, class_len, n_classes, win_step, win_size,
-                                        preprocess, flags, class_offsets, &d[m], &extent));
-    }
+  if (!contiguous) partition_by_owner(g, reads, weights, n);
+  std::vector<Run> mine(nm, Run{0, 0, 0});
+  if (contiguous) for (const Run &r : runs) mine[r.owner] = r;
+  std::vector<ScanShare> share(nm);
+  std::vector<void *> piece(nm, nullptr);
+  int64_t extent = 0, total = 0;
+  for (int32_t c = 0; c < n_classes; c++) {
+    const int64_t w = gtx_scan_n_windows(class_len[c] < 0 ? 0 : class_len[c], win_step, win_size);
+    extent = std::max<int64_t>(extent, class_offsets[c] + w); total += w;
   }
-  if (extent > 0 && !windows_out) return gfail(g, GTX_E_ARG, "gtx_group_scan: null output");
-  int rc = reduce_to_root(g, d, extent); if (rc) return rc;
+  if (total > 0 && !windows_out) return gfail(g, GTX_E_ARG, "gtx_group_scan: null output");
+  for (int m = 0; m < nm; m++) {
+    share[m] = scan_share(g, m, class_len, n_classes, win_step, win_size);
+    const int32_t *r = contiguous ? reads + 3 * mine[m].a : g->partTri[m].data();
+    const int32_t *w = !weights ? nullptr : contiguous ? weights + mine[m].a : g->partW[m].data();
+    const int64_t cnt = contiguous ? mine[m].b - mine[m].a : (int64_t)(g->partTri[m].size() / 3);
+    g->memberReads[m] = cnt;
+    int64_t ext = 0;
+    GCHK_CTX(g, m, gtxi_scan_enqueue(g->ctx[m], r, w, cnt, share[m].len.data(), n_classes, win_step, win_size, preprocess, flags, share[m].off.data(), &piece[m], &ext));
+  }
+  // member 0 assembles the caller's layout in a second vector of its own, then the classes go out range by range (the layout may have gaps)
   GCHK_HIP(g, hipSetDevice(g->dev[0]));
-  if (extent > 0) GCHK_HIP(g, hipMemcpyAsync(windows_out, d[0], sizeof(uint64_t) * extent, hipMemcpyDeviceToHost, gtxi_stream(g->ctx[0])));
+  unsigned long long *root = nullptr;
+  GCHK_CTX(g, 0, gtxi_scratch(g->ctx[0], sizeof(uint64_t) * (size_t)std::max<int64_t>(extent, 1), (void **)&root));
+  int rc = gather_windows(g, piece, share, class_len, n_classes, win_step, win_size, class_offsets, root); if (rc) return rc;
+  for (int32_t c = 0; c < n_classes; c++) {
+    const int64_t w = gtx_scan_n_windows(class_len[c] < 0 ? 0 : class_len[c], win_step, win_size);
+    if (w > 0) GCHK_HIP(g, hipMemcpyAsync(windows_out + class_offsets[c], root + class_offsets[c], sizeof(uint64_t) * (size_t)w, hipMemcpyDeviceToHost, gtxi_stream(g->ctx[0])));
+  }
   for (int i = 0; i < nm; i++) GCHK_CTX(g, i, gtx_sync(g->ctx[i]));
   return GTX_OK;
 }

@@ -169,11 +169,14 @@ int scan_tiles(long long len);
 hipError_t launch_count(const void *reads, const void *weights, long long n, const CountArgs &a, bool sortedHint, hipStream_t st);
 // tileSumsValid: the streaming kernel kept tileA/tileB up to date (the search kernel does not).
 // Leaves histA/histB and the tile sums zeroed for the next call.
+// share (may be null): the finalize step of a group member -- only the histogram tiles that cover the classes it owns (a class
+// has slots seg+cls-1 .. segEnd+cls; other tiles hold no counts) and only its regions, written in the group's compact order
+struct FinalizeShare { const int *tileList; int nTiles; const int *regionList; long long nRegions; };
 hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB, long long histLen,
                            unsigned long long *tileA, unsigned long long *tileB, bool tileSumsValid,
                            unsigned long long *prefA, unsigned long long *prefB,
                            const int *posE, const int *posS, const int *classBase, long long m,
-                           unsigned long long *hits, DevInfo *nextInfo, hipStream_t st);
+                           unsigned long long *hits, DevInfo *nextInfo, hipStream_t st, const FinalizeShare *share = nullptr);
 hipError_t launch_coverage(const void *reads, const void *weights, long long n, const CoverArgs &a, hipStream_t st);
 hipError_t launch_coverage_finalize(const CoverArgs &a, long long histLen, const CoverGather &g, long long m,
                                     unsigned long long *cov, DevInfo *nextInfo, hipStream_t st);

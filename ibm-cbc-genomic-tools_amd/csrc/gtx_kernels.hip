@@ -1405,13 +1405,15 @@ __device__ __forceinline__ u64 block_sum(u64 v, u64 *lds)
   return s;
 }
 
+// tileList (may be null): the tiles to work on -- a member of a group only has counts in the tiles of the classes it owns
 __global__ __launch_bounds__(256) void tile_sums_kernel(const u64 *__restrict__ ha, const u64 *__restrict__ hb, i64 len,
-                                                        u64 *__restrict__ pa, u64 *__restrict__ pb)
+                                                        u64 *__restrict__ pa, u64 *__restrict__ pb, const int *__restrict__ tileList)
 {
   // grid (tiles, 2): blockIdx.y picks the histogram; thread t owns 4 consecutive slots (two 16-byte loads)
   __shared__ u64 lds[4];
   const u64 *__restrict__ h = blockIdx.y ? hb : ha;
-  const i64 i0 = (i64)blockIdx.x * kTile + (i64)threadIdx.x * 4;
+  const int tileIdx = tileList ? tileList[blockIdx.x] : (int)blockIdx.x;
+  const i64 i0 = (i64)tileIdx * kTile + (i64)threadIdx.x * 4;
   u64 s = 0;
   if (i0 + 4 <= len) {
     const ulonglong2 x = *(const ulonglong2 *)(h + i0), y = *(const ulonglong2 *)(h + i0 + 2);
@@ -1420,13 +1422,13 @@ __global__ __launch_bounds__(256) void tile_sums_kernel(const u64 *__restrict__ 
     for (int k = 0; k < 4; k++) if (i0 + k < len) s += h[i0 + k];
   }
   s = block_sum(s, lds);
-  if (threadIdx.x == 0) (blockIdx.y ? pb : pa)[blockIdx.x] = s;
+  if (threadIdx.x == 0) (blockIdx.y ? pb : pa)[tileIdx] = s;
 }
 
 // grid (tiles, 2): blockIdx.y picks the histogram (A or B) -- twice the blocks, half the work per block
 __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha, u64 *__restrict__ hb, i64 len,
                                                             const u64 *__restrict__ ta, const u64 *__restrict__ tb,
-                                                            u64 *__restrict__ pa, u64 *__restrict__ pb)
+                                                            u64 *__restrict__ pa, u64 *__restrict__ pb, const int *__restrict__ tileList)
 {
   __shared__ u64 lds[4];
   __shared__ u64 wsum[4];
@@ -1434,7 +1436,7 @@ __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha
   const u64 *__restrict__ ts = blockIdx.y ? tb : ta;
   u64 *__restrict__ p = blockIdx.y ? pb : pa;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int tile = blockIdx.x;
+  const int tile = tileList ? tileList[blockIdx.x] : (int)blockIdx.x;   // (tiles not in the list hold no counts: their sums are 0)
   // thread t owns 4 consecutive slots (two 16-byte loads); issued first, used last
   const i64 i0 = (i64)tile * kTile + (i64)threadIdx.x * 4;
   const bool full = i0 + 4 <= len;                   // (32-byte aligned: the histograms come from hipMalloc, i0 is a multiple of 4)
@@ -1471,12 +1473,16 @@ __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha
 __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict__ pa, const u64 *__restrict__ pb,
                                                           const int *__restrict__ posE, const int *__restrict__ posS,
                                                           const int *__restrict__ classBase, i64 m, u64 *__restrict__ hits,
-                                                          u64 *__restrict__ ta, u64 *__restrict__ tb, int nTiles, DevInfo *nextInfo)
+                                                          u64 *__restrict__ ta, u64 *__restrict__ tb, int nTiles, DevInfo *nextInfo,
+                                                          const int *__restrict__ regionList)
 {
+  // regionList (may be null): m entries, hits[j] = the count of region regionList[j] -- a group member's own regions, compact
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < nTiles) { ta[k] = 0; tb[k] = 0; }         // the tile sums have been consumed: clean for the next call
   if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; nextInfo->n_unplaced = 0; }
   if (k >= m) return;
+  const i64 outIdx = k;
+  if (regionList) k = regionList[k];
   int pe = posE[k];
   u64 h = 0;
   if (pe >= 0) {
@@ -1484,7 +1490,7 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict_
     u64 ba = cb >= 0 ? pa[cb] : 0, bb = cb >= 0 ? pb[cb] : 0;
     h = (pa[pe] - ba) - (pb[posS[k]] - bb);
   }
-  hits[k] = h;
+  hits[outIdx] = h;
 }
 
 __global__ __launch_bounds__(256) void gather_coverage_kernel(CoverGather g, i64 m, u64 *__restrict__ cov, int nTiles, DevInfo *nextInfo)
@@ -1815,20 +1821,25 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
 hipError_t launch_tile_sums(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, hipStream_t st)
 {
   const int nb = scan_tiles(histLen);
-  if (nb > 0) tile_sums_kernel<<<dim3(nb, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB);
+  if (nb > 0) tile_sums_kernel<<<dim3(nb, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, nullptr);
   return hipGetLastError();
 }
 
 hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, bool tileSumsValid, u64 *prefA, u64 *prefB,
-                           const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, DevInfo *nextInfo, hipStream_t st)
+                           const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, DevInfo *nextInfo, hipStream_t st,
+                           const FinalizeShare *share)
 {
   const int nb = scan_tiles(histLen);
-  if (nb > 0) {
-    if (!tileSumsValid) tile_sums_kernel<<<dim3(nb, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB);
-    finalize_scan_kernel<<<dim3(nb, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB);
+  const int nbRun = share ? share->nTiles : nb;                // a group member: the tiles of its classes, its regions (compact)
+  const int *tl = share ? share->tileList : nullptr;
+  if (nbRun > 0) {
+    if (!tileSumsValid) tile_sums_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, tl);
+    finalize_scan_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB, tl);
   }
-  const i64 work = (m > nb ? m : nb) > 0 ? (m > nb ? m : nb) : 1;
-  gather_hits_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(prefA, prefB, posE, posS, classBase, m, hits, tileA, tileB, nb, nextInfo);
+  const i64 mm = share ? share->nRegions : m;
+  const i64 work = (mm > nb ? mm : nb) > 0 ? (mm > nb ? mm : nb) : 1;
+  gather_hits_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(prefA, prefB, posE, posS, classBase, mm, hits, tileA, tileB, nb, nextInfo,
+                                                                     share ? share->regionList : nullptr);
   return hipGetLastError();
 }
 
@@ -1847,7 +1858,7 @@ hipError_t launch_coverage_finalize(const CoverArgs &a, i64 histLen, const Cover
 {
   const int nb = scan_tiles(histLen);
   for (int q = 0; q < 4 && nb > 0; q += 2)
-    finalize_scan_kernel<<<dim3(nb, 2), 256, 0, st>>>(a.hist[q], a.hist[q + 1], histLen, a.part[q], a.part[q + 1], g.pref[q], g.pref[q + 1]);
+    finalize_scan_kernel<<<dim3(nb, 2), 256, 0, st>>>(a.hist[q], a.hist[q + 1], histLen, a.part[q], a.part[q + 1], g.pref[q], g.pref[q + 1], nullptr);
   const i64 work = (m > nb ? m : nb) > 0 ? (m > nb ? m : nb) : 1;
   gather_coverage_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(g, m, cov, nb, nextInfo);
   return hipGetLastError();

@@ -18,6 +18,7 @@ ZERO_LENGTH_OK = 4
 GAPS_FORMULA = 8
 READS_UNSORTED = 16
 REFS_KEEP_ZERO_LENGTH = 1
+GROUP_ID_BYTES = 128
 
 _lib = None
 
@@ -74,6 +75,16 @@ ABI = {
     "gtx_group_size": (ctypes.c_int, [ctypes.c_void_p]),
     "gtx_group_ctx": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     "gtx_group_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "gtx_group_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_group_create_rank": (ctypes.c_void_p, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "gtx_group_rank": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_group_plan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_group_count_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "gtx_group_scan_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_group_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_group_last_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_group_assign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "gtx_lpt_assign": (None, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int, ctypes.c_void_p]),
     "gtx_group_set_refs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32]),
@@ -265,6 +276,17 @@ class Engine:
         return a.value, b.value
 
 
+def group_plan(ref_class, owner, n_members):
+    """(seg_offset[n_members+1], perm[n_refs]) of gtx_group_plan: the compact order of a group's result (pure host code)."""
+    rc = np.ascontiguousarray(ref_class, dtype=np.int32)
+    ow = np.ascontiguousarray(owner, dtype=np.int32)
+    seg = np.zeros(n_members + 1, dtype=np.int64)
+    perm = np.zeros(max(len(rc), 1), dtype=np.int32)
+    if load().gtx_group_plan(_ptr(rc), 1, len(rc), _ptr(ow), len(ow), int(n_members), _ptr(seg), _ptr(perm)) != 0:
+        raise GtxError("gtx_group_plan: bad argument")
+    return seg, perm[:len(rc)]
+
+
 def lpt_assign(class_load, n_members):
     """class -> member by longest-processing-time packing (gtx_lpt_assign: pure host code, no GPU needed)."""
     class_load = np.ascontiguousarray(class_load, dtype=np.int64)
@@ -276,14 +298,66 @@ def lpt_assign(class_load, n_members):
 class Group:
     """gtx_group: one context per device, classes dealt to the members, RCCL reduce of the result vector."""
 
-    def __init__(self, devices):
+    def __init__(self, devices=None, rank=None, world=None, device=None, unique_id=None):
+        """Group(devices): one process drives all members.  Group(rank=r, world=w, device=d, unique_id=bytes): this process holds
+        member r of a group of w processes (unique_id from Group.unique_id() on rank 0, handed around by the launcher)."""
         self.lib = load()
-        ids = np.ascontiguousarray(devices, dtype=np.int32)
-        self.g = self.lib.gtx_group_create(len(ids), _ptr(ids))
+        if rank is None:
+            ids = np.ascontiguousarray(devices, dtype=np.int32)
+            self.g = self.lib.gtx_group_create(len(ids), _ptr(ids))
+            self.n, self.n_local, self.rank = len(ids), len(ids), -1
+        else:
+            buf = None if unique_id is None else ctypes.create_string_buffer(bytes(unique_id), GROUP_ID_BYTES)
+            self.g = self.lib.gtx_group_create_rank(int(device), int(rank), int(world), buf)
+            self.n, self.n_local, self.rank = int(world), 1, int(rank)
         if not self.g:
             raise GtxError(self.lib.gtx_group_last_error(None).decode())
-        self.n = len(ids)
         self.n_refs = 0
+
+    @staticmethod
+    def unique_id():
+        """GROUP_ID_BYTES bytes for Group(rank=...) (rank 0 makes it; librccl is loaded for it)."""
+        lib = load()
+        buf = ctypes.create_string_buffer(GROUP_ID_BYTES)
+        if lib.gtx_group_unique_id(buf) != 0:
+            raise GtxError(lib.gtx_group_last_error(None).decode())
+        return buf.raw
+
+    def ctx(self, member):
+        return self.lib.gtx_group_ctx(self.g, int(member))
+
+    def set_stream(self, member, stream_handle):
+        c = self.ctx(member)
+        if not c:
+            raise GtxError("member %d is not local" % member)
+        if self.lib.gtx_set_stream(c, ctypes.c_void_p(int(stream_handle))) != 0:
+            raise GtxError("gtx_set_stream failed")
+
+    def _ptr_array(self, ptrs):
+        return (ctypes.c_void_p * self.n_local)(*[None if p is None else int(p) for p in ptrs])
+
+    def count_device(self, d_reads, n_reads, d_hits, d_weights=None, flags=READS_SORTED):
+        """d_reads / n_reads / d_weights: one entry per LOCAL member (raw device addresses); d_hits: n_refs uint64 on member 0's device."""
+        n = np.ascontiguousarray(n_reads, dtype=np.int64)
+        w = None if d_weights is None else self._ptr_array(d_weights)
+        self._chk(self.lib.gtx_group_count_device(self.g, self._ptr_array(d_reads), w, _ptr(n), int(flags), _ptr(d_hits)))
+
+    def scan_device(self, d_reads, n_reads, class_len, win_step, win_size, d_windows, preprocess="1", d_weights=None, flags=0):
+        cl = np.ascontiguousarray(class_len, dtype=np.int32)
+        off, tot = scan_layout(cl, win_step, win_size)
+        n = np.ascontiguousarray(n_reads, dtype=np.int64)
+        w = None if d_weights is None else self._ptr_array(d_weights)
+        self._chk(self.lib.gtx_group_scan_device(self.g, self._ptr_array(d_reads), w, _ptr(n), _ptr(cl), len(cl), int(win_step), int(win_size),
+                                                 preprocess.encode()[0:1], int(flags), _ptr(d_windows), _ptr(off)))
+        return off, tot
+
+    def sync(self):
+        self._chk(self.lib.gtx_group_sync(self.g))
+
+    def last_info(self):
+        info = CountInfo()
+        self._chk(self.lib.gtx_group_last_info(self.g, ctypes.byref(info)))
+        return info.as_dict()
 
     def close(self):
         if getattr(self, "g", None):

@@ -213,42 +213,82 @@ int gtx_scan_device(gtx_ctx *ctx, const void *d_read_triples, const void *d_weig
 /* ---- several GPUs of one node ------------------------------------------------------------ */
 
 /* Two regions overlap only inside one class (genomic_intervals.cpp:624-630), so a class is an independent unit of work.
- * A group is one context per device; classes are dealt to the members (longest-processing-time packing of a per-class
- * load), every member holds the whole reference set and counts the reads of ITS classes into a full-length vector, and
- * one RCCL reduce(sum) over xGMI of that uint64 vector to member 0 yields the result (the members' vectors are disjoint
- * by class, so the sum is the one-GPU vector bit for bit).  genomic_scans windows are per class too: same split, same
- * reduce of the window vector.  One process and one caller thread drive all members; calls enqueue and return.
- * What the reference's single loop over queries (genomic_intervals.cpp:5304-5317) becomes on a node. */
+ * A group has one member (context) per device; classes are dealt to the members (longest-processing-time packing of a
+ * per-class load), every member holds the whole reference set and counts the reads of ITS classes.  What follows a member's
+ * streaming kernel shrinks with its share: it finalizes only the histogram tiles of its classes and only its regions, into
+ * its piece of a COMPACT vector (regions ordered by owner of their class, then position in the file: gtx_group_plan), the
+ * pieces travel to member 0 over xGMI -- one grouped RCCL send / receive per member: the reduce(sum) of the per-region
+ * vector with its addends known to be disjoint by class -- and member 0 puts them into file order.  genomic_scans windows
+ * are per class too: a member scans its classes into a packed vector of its own, the per-class pieces travel the same way.
+ * A group is ONE process and one caller thread driving all members (gtx_group_create; calls enqueue and return), or one
+ * process per member (gtx_group_create_rank).  What the reference's single loop over queries
+ * (genomic_intervals.cpp:5304-5317) becomes on a node. */
 typedef struct gtx_group gtx_group;
 
 /* device_ids == NULL: devices 0 .. n_devices-1.  NULL on failure (gtx_group_last_error(NULL) has the text).  librccl is
- * loaded at run time, for groups of more than one device only. */
+ * loaded at run time, for groups of more than one device only.  RCCL prints a version banner on stdout when a communicator
+ * comes up: descriptor 1 points at stderr for the duration of that step, so a caller with other threads writing to stdout
+ * keeps them from flushing it until gtx_group_create / gtx_group_create_rank has returned. */
 gtx_group  *gtx_group_create(int n_devices, const int *device_ids);
+/* One process per member: rank 0 obtains an id (GTX_GROUP_ID_BYTES bytes, an ncclUniqueId) and hands it to the others by
+ * whatever launched them; every process then creates its member.  The object holds the local member only; the calls that
+ * take per-member arrays (gtx_group_count_device, gtx_group_scan_device) take arrays of ONE entry, results arrive on rank
+ * 0, and every rank makes the same calls in the same order.  The host-buffer calls need a group that holds all its members. */
+#define GTX_GROUP_ID_BYTES 128
+int         gtx_group_unique_id(void *id_out /* GTX_GROUP_ID_BYTES */);
+gtx_group  *gtx_group_create_rank(int device_id, int rank, int world_size, const void *unique_id /* may be NULL for a world of one */);
 void        gtx_group_destroy(gtx_group *g);
-int         gtx_group_size(const gtx_group *g);
-gtx_ctx    *gtx_group_ctx(gtx_group *g, int member);
+int         gtx_group_size(const gtx_group *g);     /* members, all processes together */
+int         gtx_group_rank(const gtx_group *g);     /* -1: the group holds all its members */
+gtx_ctx    *gtx_group_ctx(gtx_group *g, int member);   /* NULL for another process's member */
 const char *gtx_group_last_error(const gtx_group *g);
 
 /* class -> member by LPT packing of class_load (e.g. reads per class, or chromosome lengths); owner_out (n_classes, may be
  * NULL) receives the assignment.  Without this call gtx_group_set_refs assigns by the span of each class's reference
- * regions and gtx_group_scan by class_len.  gtx_lpt_assign is the packing itself (no group, no GPU). */
+ * regions and the scans by class_len.  gtx_lpt_assign is the packing itself (no group, no GPU; deterministic, so the ranks
+ * of a multi-process group all compute the same). */
 int  gtx_group_assign(gtx_group *g, const int64_t *class_load, int32_t n_classes, int32_t *owner_out);
 void gtx_lpt_assign(const int64_t *class_load, int32_t n_classes, int n_members, int32_t *owner_out);
+/* The compact order of a group's result (no group, no GPU): ref_class[k * stride] = class of region k (stride 3 reads the
+ * class column of packed triples); perm[j] = file position of the region at compact position j, member m's piece =
+ * positions seg_offset[m] .. seg_offset[m+1]; regions of no class (a placeholder, an id beyond the assignment) are member 0's. */
+int  gtx_group_plan(const int32_t *ref_class, int64_t stride, int64_t n_refs, const int32_t *owner, int32_t n_classes, int n_members,
+                    int64_t *seg_offset /* n_members + 1 */, int32_t *perm /* n_refs */);
 
-/* gtx_set_refs_ex on every member. */
+/* gtx_set_refs_ex on every local member. */
 int gtx_group_set_refs(gtx_group *g, const int32_t *ref_triples, int64_t n_refs, int32_t n_classes, uint32_t flags);
+
+/* The reads of every member already resident in ITS device's HBM (member m: the reads of the classes it owns -- reads of
+ * other classes would be counted into tiles nobody finalizes): d_reads / d_weights / n_reads are indexed by local member
+ * (d_weights may be NULL).  Per member the streaming kernel and the finalize step of its share, the pieces to member 0, the
+ * result in file order in d_hits (n_refs uint64 on member 0's device; ignored on other ranks).  Everything is enqueued on the
+ * members' streams (gtx_set_stream of gtx_group_ctx); gtx_group_sync waits.  GTX_CHECK_SORTED is ignored,
+ * GTX_ZERO_LENGTH_OK refused (the sorted merge's host-side corrections live in the host-buffer calls).
+ * gtx_group_last_info: the sums over the local members (first_unsorted / first_degenerate are not tracked: -1). */
+int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void *const *d_weights, const int64_t *n_reads,
+                           uint32_t flags, void *d_hits);
+int gtx_group_scan_device(gtx_group *g, const void *const *d_reads, const void *const *d_weights, const int64_t *n_reads,
+                          const int32_t *class_len, int32_t n_classes, int32_t win_step, int32_t win_size, char preprocess,
+                          uint32_t flags, void *d_windows /* member 0's device, layout class_offsets */, const int64_t *class_offsets);
+int gtx_group_sync(gtx_group *g);
+int gtx_group_last_info(gtx_group *g, gtx_count_info *info);
 
 /* The streaming count / coverage calls of a single context, on the group: every read goes to the owner of its class (reads
  * of no known class to member 0).  Sorted input is cut into a few contiguous runs per batch; interleaved input is
- * partitioned on the host.  info: the sums over the members; first_unsorted / first_degenerate are not tracked (-1), and
- * GTX_CHECK_SORTED is ignored. */
+ * partitioned on the host.  Page-locked batches (gtx_host_alloc) follow the single-context rule: a batch must stay
+ * untouched until the group's next host-buffer call has returned (the call waits for every member's copy of the previous
+ * batch, also of members that get nothing of the new one).  count on a plain reference set ends with the pieces of the
+ * compact vector as above; coverage, and count on a GTX_REFS_KEEP_ZERO_LENGTH set (whose inverted intervals are matched
+ * into the full vector), with one ncclReduce(sum) of the members' full vectors.  info: the sums over the members;
+ * first_unsorted / first_degenerate are not tracked (-1), and GTX_CHECK_SORTED is ignored. */
 int gtx_group_count_begin(gtx_group *g);
 int gtx_group_count_add(gtx_group *g, const int32_t *read_triples, const int32_t *weights, int64_t n_reads, uint32_t flags);
 int gtx_group_count_end(gtx_group *g, uint64_t *hits_out /* n_refs */, gtx_count_info *info /* may be NULL */);
 int gtx_group_coverage_begin(gtx_group *g);
 int gtx_group_coverage_add(gtx_group *g, const int32_t *read_triples, const int32_t *weights, int64_t n_reads, uint32_t flags);
 int gtx_group_coverage_end(gtx_group *g, uint64_t *cov_out /* n_refs */, gtx_count_info *info /* may be NULL */);
-/* gtx_scan on the group (arguments as gtx_scan). */
+/* gtx_scan on the group (arguments as gtx_scan; with more than one member only the classes' own ranges of windows_out are
+ * written, whatever class_offsets leaves between them is not touched). */
 int gtx_group_scan(gtx_group *g, const int32_t *read_triples, const int32_t *weights, int64_t n_reads,
                    const int32_t *class_len, int32_t n_classes, int32_t win_step, int32_t win_size, char preprocess,
                    uint32_t flags, uint64_t *windows_out, const int64_t *class_offsets);

@@ -155,3 +155,64 @@ def test_two_ranks_share_one_fixed_read_set(tmp_path):
     reads = _reads_of(np.arange(24), per_chrom, 9)
     want = orc.count(refs, reads, algo=orc.SORTED_MERGE)
     np.testing.assert_array_equal(np.load(out).view(np.uint64), want)
+
+
+# ---- round 3: the product's own N > 1 scheme -- every member finalizes its classes into its piece of a compact vector
+# (gtx_group_plan), the pieces travel to member 0, member 0 puts them into file order.  Here: the planning function of libgtx.so
+# (pure host code) in two gloo ranks, the per-rank counting by the CPU oracle, the pieces moved with gloo send / recv.
+def _piece_worker(rank, world, port, out):
+    import gtx
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(9)
+        refs = synth.genome_intervals(5000, 61, 50, 3000)
+        refs = refs[rng.permutation(len(refs))]                          # file order is not class order
+        reads = synth.genome_intervals(60000, 62, 30, 200)
+        owner = gtx.lpt_assign(np.bincount(reads[:, 0], minlength=24), world)     # deterministic: every rank computes the same
+        seg, perm = gtx.group_plan(refs[:, 0], owner, world)
+        mine = reads[owner[reads[:, 0]] == rank]
+        full = orc.count(refs, mine, algo=orc.BIN_INDEX)                 # this rank's reads only
+        piece = torch.from_numpy(full[perm[seg[rank]:seg[rank + 1]]].astype(np.int64))    # ... and only its own regions travel
+        assert int(full.sum()) == int(piece.sum())                       # its reads hit no region of another member's classes
+        if rank == 0:
+            compact = torch.zeros(len(refs), dtype=torch.int64)
+            compact[seg[0]:seg[1]] = piece
+            for r in range(1, world):
+                buf = torch.zeros(int(seg[r + 1] - seg[r]), dtype=torch.int64)
+                dist.recv(buf, src=r)
+                compact[seg[r]:seg[r + 1]] = buf
+            hits = np.zeros(len(refs), dtype=np.uint64)
+            hits[perm] = compact.numpy().view(np.uint64)
+            np.save(out, hits)
+        else:
+            dist.send(piece, dst=0)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pieces_of_the_compact_vector_two_and_three_ranks(tmp_path):
+    rng = np.random.default_rng(9)
+    refs = synth.genome_intervals(5000, 61, 50, 3000)
+    refs = refs[rng.permutation(len(refs))]
+    reads = synth.genome_intervals(60000, 62, 30, 200)
+    want = orc.count(refs, reads, algo=orc.BIN_INDEX)
+    for world in (2, 3):
+        out = str(tmp_path / ("pieces_%d.npy" % world))
+        mp.spawn(_piece_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        np.testing.assert_array_equal(np.load(out), want)
+
+
+def test_group_plan_is_a_permutation_by_owner():
+    import gtx
+    rng = np.random.default_rng(4)
+    cls = rng.integers(-1, 30, size=5000).astype(np.int32)               # -1: placeholders; 24..29: beyond the assignment
+    owner = rng.integers(0, 5, size=24).astype(np.int32)
+    seg, perm = gtx.group_plan(cls, owner, 5)
+    assert seg[0] == 0 and seg[-1] == len(cls) and np.all(np.diff(seg) >= 0)
+    assert np.array_equal(np.sort(perm), np.arange(len(cls)))
+    own = np.where((cls >= 0) & (cls < 24), owner[np.clip(cls, 0, 23)], 0)
+    for m in range(5):
+        piece = perm[seg[m]:seg[m + 1]]
+        assert np.all(own[piece] == m) and np.all(np.diff(piece) > 0)        # its regions, in file order

@@ -154,3 +154,157 @@ def test_cli_ngpu(tmp_path):
     one = run("genomic_scans", sargs, {})
     assert len(one) > 1000
     assert run("genomic_scans", [sargs[0], "--ngpu", "3"] + sargs[1:], {"GTX_GROUP_REHEARSE": "1"}) == one
+
+
+# ---- round 3: HBM-resident group calls, members finalize their own share, pieces to member 0 -----------------------------
+def _member_reads(reads, owner, nm):
+    """the reads of every member's classes, on the device (torch), in stream order"""
+    import torch
+    own = owner[np.clip(reads[:, 0], 0, len(owner) - 1)]
+    parts = [np.ascontiguousarray(reads[own == m]) for m in range(nm)]
+    return parts, [torch.from_numpy(p).cuda() for p in parts]
+
+
+def test_device_resident_count_pieces_to_member_zero(rehearsal_group):
+    """gtx_group_count_device: per member streaming kernel + finalize of ITS classes only + its piece of the compact vector to
+    member 0 + file order there.  Reference file in no class order, so the compact order is a real permutation."""
+    import torch
+    g = rehearsal_group
+    rng = np.random.default_rng(11)
+    refs = synth.genome_intervals(50_000, 93, 50, 2000)
+    refs = refs[rng.permutation(len(refs))]                       # file order != class order
+    refs[17, 0] = -1                                              # a placeholder region: count 0, belongs to member 0's piece
+    reads = synth.genome_intervals(900_000, 94, 50, 51)
+    g.set_refs(refs, synth.n_classes())
+    owner = g.assign(np.bincount(reads[:, 0], minlength=24))
+    parts, dev = _member_reads(reads, owner, 3)
+    hits = torch.zeros(len(refs), dtype=torch.int64, device="cuda")
+    for flags, shuffle in ((gtx.READS_SORTED, False), (0, True)):
+        if shuffle:
+            parts = [p[rng.permutation(len(p))] for p in parts]
+            dev = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in parts]
+        hits.fill_(-1)
+        g.count_device([d.data_ptr() for d in dev], [len(p) for p in parts], hits.data_ptr(), flags=flags)
+        g.sync()
+        want = np.insert(orc.count(np.delete(refs, 17, axis=0), reads, algo=orc.BIN_INDEX), 17, 0)   # (the oracle takes no placeholders)
+        np.testing.assert_array_equal(hits.cpu().numpy().view(np.uint64), want)
+        assert g.last_info()["n_no_class"] == 0
+        np.testing.assert_array_equal(g.member_reads(), [len(p) for p in parts])
+    # a second call right behind the first (histograms and tile sums are left clean per member), weighted
+    w = rng.integers(0, 7, size=len(reads)).astype(np.int32)
+    own = owner[reads[:, 0]]
+    parts = [np.ascontiguousarray(reads[own == m]) for m in range(3)]
+    wparts = [np.ascontiguousarray(w[own == m]) for m in range(3)]
+    dev = [torch.from_numpy(p).cuda() for p in parts]; wdev = [torch.from_numpy(p).cuda() for p in wparts]
+    g.count_device([d.data_ptr() for d in dev], [len(p) for p in parts], hits.data_ptr(), d_weights=[d.data_ptr() for d in wdev])
+    g.sync()
+    np.testing.assert_array_equal(hits.cpu().numpy().view(np.uint64), np.insert(orc.count(np.delete(refs, 17, axis=0), reads, w), 17, 0))
+    # and the host-buffer calls still see a clean state afterwards
+    got, _ = g.count([(reads, None)])
+    np.testing.assert_array_equal(got, np.insert(orc.count(np.delete(refs, 17, axis=0), reads, algo=orc.BIN_INDEX), 17, 0))
+
+
+def test_device_resident_scan_pieces_to_member_zero(rehearsal_group):
+    import torch
+    g = rehearsal_group
+    reads = synth.genome_intervals(500_000, 95, 50, 51)
+    owner = g.assign(np.bincount(reads[:, 0], minlength=24))
+    parts, dev = _member_reads(reads, owner, 3)
+    for step, size, flags in ((1000, 1000, 0), (25, 500, gtx.READS_SORTED), (1000, 3000, gtx.READS_SORTED)):
+        off, tot = gtx.scan_layout(synth.CHROM_LEN, step, size)
+        out = torch.full((tot,), -1, dtype=torch.int64, device="cuda")
+        g.scan_device([d.data_ptr() for d in dev], [len(p) for p in parts], synth.CHROM_LEN, step, size, out.data_ptr(), flags=flags)
+        g.sync()
+        want, _ = orc.scan(reads, synth.CHROM_LEN, step, size)
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+def test_page_locked_batches_refilled_behind_the_next_call(rehearsal_group):
+    """include/gtx.h: a gtx_host_alloc batch must stay untouched until the group's next host-buffer call has returned -- also when
+    that call gives the member that is still copying nothing (the wait used to be the member's own next call)."""
+    g = rehearsal_group
+    refs = synth.genome_intervals(20_000, 96, 50, 2000)
+    reads = synth.genome_intervals(1_200_000, 97, 50, 51)
+    g.set_refs(refs, synth.n_classes())
+    g.assign(np.bincount(reads[:, 0], minlength=24))
+    lib = g.lib
+    cap = 400_000
+    bufs = []
+    import ctypes
+    for _ in range(2):
+        p = lib.gtx_host_alloc(g.ctx(0), cap * 12)
+        bufs.append((p, np.frombuffer((ctypes.c_char * (cap * 12)).from_address(p), dtype=np.int32).reshape(cap, 3)))
+    g._chk(lib.gtx_group_count_begin(g.g))
+    k = 0
+    for a in range(0, len(reads), cap):
+        b = min(a + cap, len(reads))
+        p, arr = bufs[k & 1]
+        arr[:b - a] = reads[a:b]
+        g._chk(lib.gtx_group_count_add(g.g, ctypes.c_void_p(p), None, b - a, gtx.READS_SORTED))
+        if k >= 1:
+            bufs[(k - 1) & 1][1][:] = -7                         # the batch before this one is ours again: scribble over it
+        k += 1
+    out = np.zeros(len(refs), dtype=np.uint64)
+    info = gtx.CountInfo()
+    g._chk(lib.gtx_group_count_end(g.g, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(info)))
+    np.testing.assert_array_equal(out, orc.count(refs, reads, algo=orc.SORTED_MERGE))
+    for p, _ in bufs:
+        lib.gtx_host_free(g.ctx(0), ctypes.c_void_p(p))
+
+
+def test_no_class_count_given_spreads_the_members():
+    """gtx_group_set_refs with n_classes = 0: the class count is derived and the default assignment still deals the classes out"""
+    os.environ["GTX_GROUP_REHEARSE"] = "1"
+    try:
+        g = gtx.Group([0, 0])
+    finally:
+        del os.environ["GTX_GROUP_REHEARSE"]
+    refs = synth.genome_intervals(20_000, 98, 50, 2000)
+    reads = synth.genome_intervals(200_000, 99, 50, 51)
+    g.set_refs(refs, 0)
+    hits, _ = g.count([(reads, None)])
+    np.testing.assert_array_equal(hits, orc.count(refs, reads, algo=orc.SORTED_MERGE))
+    assert g.member_reads().min() > 40_000
+    g.close()
+
+
+def _through_rccl(make_group):
+    import torch
+    g = make_group()
+    refs = synth.genome_intervals(30_000, 101, 50, 2000)
+    refs = refs[np.random.default_rng(2).permutation(len(refs))]
+    reads = synth.genome_intervals(400_000, 102, 50, 51)
+    g.set_refs(refs, synth.n_classes())
+    dev = torch.from_numpy(reads).cuda()
+    hits = torch.full((len(refs),), -1, dtype=torch.int64, device="cuda")
+    g.count_device([dev.data_ptr()], [len(reads)], hits.data_ptr())
+    g.sync()
+    np.testing.assert_array_equal(hits.cpu().numpy().view(np.uint64), orc.count(refs, reads, algo=orc.BIN_INDEX))
+    got, _ = g.count([(reads, None)]) if g.rank < 0 else (None, None)
+    if got is not None:
+        np.testing.assert_array_equal(got, orc.count(refs, reads, algo=orc.BIN_INDEX))
+    g.close()
+
+
+def test_pieces_travel_through_ncclsend_ncclrecv():
+    """one member, its piece sent to itself and received back through RCCL (GTX_GROUP_SELF_EXCHANGE=1: the region is overwritten
+    with 0xff first, so a transfer that does not happen shows) -- in a group that holds its members, and as rank 0 of a world of
+    one made from a communicator id"""
+    os.environ["GTX_GROUP_SELF_EXCHANGE"] = "1"
+    try:
+        _through_rccl(lambda: gtx.Group([0]))
+        uid = gtx.Group.unique_id()
+        assert len(uid) == gtx.GROUP_ID_BYTES
+        _through_rccl(lambda: gtx.Group(rank=0, world=1, device=0, unique_id=uid))
+    finally:
+        del os.environ["GTX_GROUP_SELF_EXCHANGE"]
+
+
+def test_rccl_leaves_stdout_alone(tmp_path):
+    """the tools' stdout is their result: RCCL's banner (printed whatever NCCL_DEBUG says) must not reach it"""
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['GTX_GROUP_FORCE_RCCL'] = '1'\n"
+            "import gtx; g = gtx.Group([0]); g.close(); print('RESULT')" % os.path.join(ROOT, "ibm-cbc-genomic-tools_amd"))
+    env = dict(os.environ); env.pop("NCCL_DEBUG", None)
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode().strip() == "RESULT", r.stdout.decode()
