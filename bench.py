@@ -5,13 +5,15 @@ One step = one pass of the hot path (gtx_count_device: streaming count kernel + 
 synthetic 50 bp reads, sorted by (chromosome, start), already resident in HBM, against 1M reference intervals spread
 over the 24 hg38 chromosomes, strand ignored (`genomic_overlaps count -S -i`).
 
-N GPUs = one process per GPU (torch.distributed / RCCL).  ONE global read set -- N x 100M reads (default, "weak": the work
-per GPU stays ~fixed as N grows) or --reads in total (--scaling strong) -- is apportioned to the chromosomes in proportion
-to their length; the chromosomes are dealt to the ranks by the product's own longest-processing-time packing
-(gtx_lpt_assign of libgtx.so) of the per-chromosome read counts, so the ranks' shares are NOT equal: the line carries
-`reads_per_rank` and `imbalance` (max / mean), and `value` = all reads / the slowest rank's time.  Every rank counts its
-chromosomes' reads against the replicated reference set and the per-region uint64 vector is reduced (sum) to rank 0 over
-xGMI each step -- vectors of different ranks are disjoint by chromosome, so the sum is the one-GPU vector.
+N GPUs = one process per GPU, each holding ONE member of a gtx_group (gtx_group_create_rank of libgtx.so: the product's own
+multi-GPU code; torch.distributed only hands the communicator id around and provides the barrier).  ONE global read set --
+--reads in total (default for N > 1, "strong": the fixed 100M x 1M shape of BASELINE.json; 1 G x 2 M with --reads 1000000000
+--refs 2000000) or N x --reads (--scaling weak) -- is apportioned to the chromosomes in proportion to their length; the
+chromosomes are dealt to the members by the product's longest-processing-time packing (gtx_group_assign) of the per-chromosome
+read counts, so the shares are NOT equal: the line carries `reads_per_rank` and `imbalance` (max / mean), and `value` = all
+reads / the slowest rank's time.  Per step every member runs the streaming kernel over its reads, finalizes the histogram
+tiles and regions of ITS classes only, and its piece of the compact result vector travels to member 0 over xGMI (grouped
+ncclSend / ncclRecv, on a stream of its own under the next step's kernels); member 0 restores file order.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the streaming count kernel of rank 0: algorithmic bytes (12 B per read)
 / its mean duration measured with HIP events on the launch stream inside the timed loop.  `cpu_baseline` is the CPU
@@ -22,6 +24,7 @@ text / a packed region file to its last output line) -- reported beside `value`,
 """
 import argparse
 import json
+import types
 import os
 import sys
 import time
@@ -173,23 +176,40 @@ def measure_text_to_stdout(n, m):
     return res
 
 
-def bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads, reads_per_rank):
-    """BASELINE config 4: sliding-window read counts (1 kb windows) over the reads of this rank's chromosomes;
-    the per-window vectors of the ranks are disjoint by chromosome and are combined with one all-reduce(sum)."""
+def bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads, reads_per_rank, grp=None, locals_=(), per_chrom=None, owner=None):
+    """BASELINE config 4: sliding-window read counts (1 kb windows).  N > 1: the product's gtx_group_scan_device -- every member
+    scans the chromosomes it owns into a packed vector of its own and the per-chromosome pieces travel to member 0 (grouped
+    ncclSend / ncclRecv); `grp` is this process's view of the group (None: a rehearsal rank that only keeps the barriers company)."""
     step_bp, size_bp = 1000, 1000
     off, tot = gtx.scan_layout(synth.CHROM_LEN, step_bp, size_bp)
     out = torch.zeros(tot, dtype=torch.int64, device=device)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    if DIST_ON:
+        mreads = []
+        if grp is not None:
+            grp.assign(per_chrom)
+            for m in locals_:
+                if not rehearse:
+                    grp.set_stream(m, torch.cuda.current_stream().cuda_stream)
+                ch = np.nonzero(owner == m)[0].astype(np.int64)
+                mreads.append(make_reads_on_device(0, ch, 1000, device, per=per_chrom[ch]))
+            eng = types.SimpleNamespace(profile=lambda on: grp.profile(locals_[0], on), profile_last=lambda b: grp.profile_last(locals_[0], b),
+                                        profiled_calls=lambda: grp.profiled_calls(locals_[0]), sync=grp.sync)
+            n = mreads[0].shape[0]
+        else:
+            eng = types.SimpleNamespace(profile=lambda on: None, profile_last=lambda b: (float("nan"), 0.0), profiled_calls=lambda: 0, sync=lambda: None)
+        ptrs, ns = [r.data_ptr() for r in mreads], [r.shape[0] for r in mreads]
+    else:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
-        eng.scan_device(reads.data_ptr(), n, synth.CHROM_LEN, step_bp, size_bp, out.data_ptr(), flags=gtx.READS_SORTED)
-        if DIST_ON:
-            if rehearse:
-                h = out.cpu(); dist.all_reduce(h, op=dist.ReduceOp.SUM); out.copy_(h)
-            else:
-                dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        if not DIST_ON:
+            eng.scan_device(reads.data_ptr(), n, synth.CHROM_LEN, step_bp, size_bp, out.data_ptr(), flags=gtx.READS_SORTED)
+        elif grp is not None:
+            grp.scan_device(ptrs, ns, synth.CHROM_LEN, step_bp, size_bp, out.data_ptr(), flags=gtx.READS_SORTED)
 
     def fence():
+        if DIST_ON:
+            eng.sync()
         torch.cuda.synchronize()
         if DIST_ON:
             dist.barrier()
@@ -204,11 +224,20 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads,
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    k_ms = float(np.mean([eng.profile_last(b)[0] for b in range(eng.profiled_calls())]))
+    k_ms = float(np.mean([eng.profile_last(b)[0] for b in range(eng.profiled_calls())])) if eng.profiled_calls() else float("nan")
     if DIST_ON:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if os.environ.get("GTX_BENCH_VERIFY") == "1":
+            from oracle import orc
+            mine = np.zeros(tot, dtype=np.int64)
+            for r in (mreads if grp is not None else []):
+                mine += orc.scan(r.cpu().numpy(), synth.CHROM_LEN, step_bp, size_bp, algo=1)[0].view(np.int64)
+            want = torch.from_numpy(mine) if rehearse else torch.from_numpy(mine).to(device)
+            dist.all_reduce(want, op=dist.ReduceOp.SUM)
+            if rank == 0 and not torch.equal(out.cpu(), want.cpu()):
+                sys.exit("PARITY FAILURE: the group's windows on member 0 differ from the oracle's scan of all members' reads")
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         from oracle import orc
@@ -231,7 +260,7 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": "BASELINE config 4: genomic_scans counts -i -w 1000 -d 1000 over %d 50bp reads in total, hg38 chromosome "
-                                   "shards (LPT), all-reduce(sum) of the %d-window vector" % (total_reads, tot), "total_reads": total_reads,
+                                   "shards (LPT, gtx_group), the owners' per-chromosome pieces of the %d-window vector to member 0 (ncclSend/ncclRecv)" % (total_reads, tot), "total_reads": total_reads,
                        "reads_per_rank": reads_per_rank, "imbalance": max(reads_per_rank) / (sum(reads_per_rank) / world), "windows": tot},
             "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "scan_hist_kernel", "kernel_ms": k_ms,
@@ -332,6 +361,126 @@ def bench_perm(args, rank, world, local, device, rehearse):
         dist.destroy_process_group()
 
 
+def make_group(rank, world, local, device, rehearse, force_dist):
+    """this process's view of the gtx_group of a multi-GPU run: (group or None, the members it drives)"""
+    if rehearse:                                                      # one GPU, gloo: rank 0 drives all members on device 0
+        if rank != 0:
+            return None, []
+        os.environ["GTX_GROUP_REHEARSE"] = "1"
+        return gtx.Group([0] * world), list(range(world))
+    if force_dist:
+        os.environ["GTX_GROUP_SELF_EXCHANGE"] = "1"                  # the piece of the only member goes out and comes back through RCCL
+    uid = torch.zeros(gtx.GROUP_ID_BYTES, dtype=torch.uint8, device=device)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(gtx.Group.unique_id()), dtype=torch.uint8))
+    dist.broadcast(uid, src=0)
+    return gtx.Group(rank=rank, world=world, device=local, unique_id=bytes(uid.cpu().numpy().tobytes())), [rank]
+
+
+def bench_count_group(args, rank, world, local, device, rehearse, force_dist):
+    """N > 1 (and the single-rank self-test GTX_BENCH_FORCE_DIST=1): every process holds one member of a gtx_group and the product's
+    own multi-GPU step runs -- gtx_group_count_device.  GTX_BENCH_REHEARSE=1 (one GPU, gloo): rank 0 drives a rehearsal group of
+    `world` members on device 0 through the same calls, the other ranks only keep the barriers company."""
+    refs = synth.genome_intervals(args.refs, 43, 50, 2000)
+    n_members = world
+    total_reads = args.reads * (world if args.scaling == "weak" else 1)
+    per_chrom = synth.apportion(total_reads, synth.CHROM_LEN)
+    flags = gtx.READS_SORTED
+    grp, locals_ = make_group(rank, world, local, device, rehearse, force_dist)
+    owner = gtx.lpt_assign(per_chrom, n_members)
+    reads_per_rank = [int(per_chrom[owner == r].sum()) for r in range(n_members)]
+    kernel_ms, elapsed, hits_final, member_reads = [], 0.0, None, None
+    if grp is not None:
+        assert np.array_equal(grp.assign(per_chrom), owner)
+        grp.set_refs(refs, synth.n_classes())
+        stream = torch.cuda.current_stream()
+        reads = []
+        for m in locals_:
+            grp.set_stream(m, stream.cuda_stream) if not rehearse else None
+            ch = np.nonzero(owner == m)[0].astype(np.int64)
+            reads.append(make_reads_on_device(0, ch, 1000, device, per=per_chrom[ch]))
+            assert reads[-1].shape[0] == reads_per_rank[m]
+        ptrs, ns = [r.data_ptr() for r in reads], [r.shape[0] for r in reads]
+        hits_pp = [torch.zeros(len(refs), dtype=torch.int64, device=device) for _ in range(2)]
+        step_no = [0]
+
+        def step():
+            b = step_no[0] & 1
+            step_no[0] += 1
+            grp.count_device(ptrs, ns, hits_pp[b].data_ptr(), flags=flags)
+    else:
+        def step():
+            pass
+
+    def fence():
+        if grp is not None:
+            grp.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    fence()
+    if grp is not None:
+        grp.profile(locals_[0], PROFILE_EVERY if args.steps >= PROFILE_EVERY else 1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if grp is not None:
+        kernel_ms = [grp.profile_last(locals_[0], b)[0] for b in range(grp.profiled_calls(locals_[0]))]
+        grp.profile(locals_[0], False)
+        hits_final = hits_pp[(step_no[0] - 1) & 1]
+        member_reads = [int(x) for x in grp.member_reads()]
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if os.environ.get("GTX_BENCH_VERIFY") == "1":
+        # the result on member 0 must be the one-process count of all members' reads (CPU oracle, summed over the ranks)
+        from oracle import orc
+        mine = np.zeros(len(refs), dtype=np.int64)
+        if grp is not None:
+            for r in reads:
+                mine += orc.count(refs, r.cpu().numpy(), algo=orc.SORTED_MERGE).view(np.int64)
+        tot = torch.from_numpy(mine) if rehearse else torch.from_numpy(mine).to(device)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        if rank == 0 and not torch.equal(hits_final.cpu(), tot.cpu()):
+            sys.exit("PARITY FAILURE: the group's result on member 0 differs from the oracle's count of all members' reads")
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else None
+        n0 = reads_per_rank[0]
+        achieved = 12.0 * n0 / (k_ms * 1e-3) / 1e9 if k_ms else None
+        emit({
+            "metric": "overlap-counted reads/sec, 100M reads x 1M ref intervals",
+            "value": total_reads * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: %d 50bp reads in total, sorted by (chrom,start), x %d ref intervals over 24 hg38 "
+                                   "chromosomes, strand ignored (genomic_overlaps count -S -i); reads resident in HBM" % (total_reads, len(refs)),
+                       "total_reads": total_reads, "refs": len(refs), "reads_per_rank": reads_per_rank,
+                       "imbalance": max(reads_per_rank) / (sum(reads_per_rank) / n_members),
+                       "parallelism": "%s scaling through the product's gtx_group (libgtx.so): one process per GPU = one member each "
+                                      "(gtx_group_create_rank), chromosomes dealt to the %d members by LPT packing of their read counts, reference "
+                                      "set replicated; per step gtx_group_count_device: streaming kernel + finalize of the member's own classes, "
+                                      "pieces of the compact vector to member 0" % (args.scaling, n_members),
+                       "reduce": ("one-GPU rehearsal of the group code (not a measurement)" if rehearse else
+                                  "grouped ncclSend/ncclRecv of each member's piece of the uint64 count vector to member 0 over xGMI, on a stream of "
+                                  "its own under the next step's kernels; member 0 restores file order") +
+                                 (" [single-rank self-test: the piece goes out and back through RCCL]" if force_dist else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                         "kernel": "count_walk_kernel (member 0's launch over its %d reads)" % n0, "kernel_ms": k_ms,
+                         "kernel_samples": len(kernel_ms), "algorithmic_bytes": 12.0 * n0},
+            "cpu_baseline": None,
+        })
+    if grp is not None:
+        grp.close()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,15 +493,17 @@ def main():
                     help="count = BASELINE config 3 (the headline metric); scans = config 4: genomic_scans counts -i -w 1000 -d 1000; "
                          "permutation_test = the shuffle part of config 5")
     ap.add_argument("--shuffles", type=int, default=10000, help="permutation_test: shuffles per GPU per step")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = N x --reads in total (default), strong = --reads in total; either way ONE global read set, "
-                         "sharded by chromosome with the product's LPT packing")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: strong = --reads in total (default for the count workload: the fixed shape BASELINE.json names), weak = N x "
+                         "--reads in total; either way ONE global read set, sharded by chromosome with the product's LPT packing")
     ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the host_to_result / text_to_stdout measurements")
     ap.add_argument("--two-streams", action="store_true",
                     help="count, N=1: after the timed region also time the same steps alternating two contexts on two HIP streams "
                          "(extra 'two_streams' object; off by default so that a kernel trace of the default command sees only the timed steps)")
     args = ap.parse_args()
 
+    if args.scaling is None:
+        args.scaling = "strong" if args.workload == "count" else "weak"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -386,6 +537,8 @@ def main():
 
     if args.workload == "permutation_test":
         return bench_perm(args, rank, world, local, device, rehearse)
+    if args.workload == "count" and DIST_ON:
+        return bench_count_group(args, rank, world, local, device, rehearse, force_dist)
 
     # ---- workload -------------------------------------------------------------------------------
     refs = synth.genome_intervals(args.refs, 43, 50, 2000)                 # 1M refs, all chromosomes, every rank
@@ -395,6 +548,12 @@ def main():
     per_chrom = synth.apportion(total_reads, synth.CHROM_LEN)
     owner = gtx.lpt_assign(per_chrom, world)
     reads_per_rank = [int(per_chrom[owner == r].sum()) for r in range(world)]
+    if args.workload == "scans" and DIST_ON:
+        grp, locals_ = make_group(rank, world, local, device, rehearse, force_dist)
+        bench_scans(args, None, None, 0, rank, world, device, rehearse, total_reads, reads_per_rank, grp, locals_, per_chrom, owner)
+        if grp is not None:
+            grp.close()
+        return
     my_chroms = np.nonzero(owner == rank)[0].astype(np.int64)
     reads = make_reads_on_device(0, my_chroms, 1000, device, per=per_chrom[my_chroms])
     n = reads.shape[0]

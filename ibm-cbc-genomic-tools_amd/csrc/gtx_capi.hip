@@ -34,6 +34,7 @@ struct gtx_ctx {
   // direct placement at the start of a span (gtx::PlaceTable): per class {segment start, end, first cell, cells}; per cell the rank
   // of the cell's first position in the ends array and in the starts array
   int4 *d_placeCls = nullptr; int *d_placeRank = nullptr; int placeShift = 0;
+  int4 *d_placeClsT = nullptr; int *d_placeRankT = nullptr; int placeShiftT = 0;      // ... over the coverage thresholds (cover_prepare)
   std::vector<int32_t> h_seg;                        // [nClasses+1] class segments of the sorted boundary arrays (host copy)
   // a group member's share of the finalize step (gtxi_set_share): tiles of its classes, its regions in the group's compact order
   bool shareOn = false; int *d_shareTiles = nullptr; int nShareTiles = 0; int *d_shareRegions = nullptr; int64_t nShareRegions = 0, shareOffset = 0;
@@ -115,6 +116,42 @@ static int fail(gtx_ctx *c, int code, const char *msg) { c->err = msg; return co
 
 template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
+// direct placement (gtx::PlaceTable) over two boundary arrays with the class segments `seg` (the same array twice for the
+// coverage thresholds): cells of 2^sh positions, sh the smallest shift that keeps the table at about one cell per eight
+// boundaries; a cell's entries = how many boundaries of the class lie below the cell's first position in either array (cell 0: none)
+static int make_place_table(gtx_ctx *c, const std::vector<int32_t> &seg, const std::vector<int32_t> &arrA, const std::vector<int32_t> &arrB,
+                            int nClasses, int64_t nv, int4 **d_cls, int **d_rank, int *shift)
+{
+  const int64_t budget = std::max<int64_t>(1024, nv / 8) + 2 * (int64_t)nClasses;
+  auto cellsOf = [&](int cl, int sh) -> int64_t {
+    if (seg[cl] == seg[cl + 1]) return 0;
+    const int64_t top = std::max<int64_t>(0, std::max(arrA[seg[cl + 1] - 1], arrB[seg[cl + 1] - 1]));
+    return (top >> sh) + 2;
+  };
+  int sh = 0;
+  for (;; sh++) { int64_t t = 0; for (int cl = 0; cl < nClasses; cl++) t += cellsOf(cl, sh); if (t <= budget || sh >= 31) break; }
+  std::vector<int4> pc(std::max(nClasses, 1));
+  std::vector<int32_t> rank;
+  for (int cl = 0; cl < nClasses; cl++) {
+    const int64_t nc = cellsOf(cl, sh);
+    pc[cl] = make_int4(seg[cl], seg[cl + 1], (int)(rank.size() / 2), (int)nc);
+    int32_t ia = seg[cl], ib = seg[cl];
+    for (int64_t k = 0; k < nc; k++) {
+      const int64_t first = k << sh;                           // cell 0 stands for everything below 2^sh, negative keys included
+      if (k > 0) { while (ia < seg[cl + 1] && arrA[ia] < first) ia++; while (ib < seg[cl + 1] && arrB[ib] < first) ib++; }
+      rank.push_back(ia); rank.push_back(ib);
+    }
+  }
+  rank.push_back(0); rank.push_back(0);
+  dfree(*d_cls); dfree(*d_rank);
+  HIPCHK(c, hipMalloc(d_cls, sizeof(int4) * pc.size()));
+  HIPCHK(c, hipMalloc(d_rank, sizeof(int32_t) * rank.size()));
+  HIPCHK(c, hipMemcpy(*d_cls, pc.data(), sizeof(int4) * pc.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(*d_rank, rank.data(), sizeof(int32_t) * rank.size(), hipMemcpyHostToDevice));
+  *shift = sh;
+  return GTX_OK;
+}
+
 extern "C" {
 
 int gtx_version(void) { return 100; }
@@ -167,7 +204,7 @@ void gtx_destroy(gtx_ctx *c)
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
   dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab); dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;
-  dfree(c->d_placeCls); dfree(c->d_placeRank); dfree(c->d_shareTiles); dfree(c->d_shareRegions);
+  dfree(c->d_placeCls); dfree(c->d_placeRank); dfree(c->d_placeClsT); dfree(c->d_placeRankT); dfree(c->d_shareTiles); dfree(c->d_shareRegions);
   dfree(c->d_bktCnt); dfree(c->d_bktS); dfree(c->d_clsCellS); dfree(c->d_cellTabS); dfree(c->d_scanParts); dfree(c->d_scanInfo); c->nBS = 0;
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
@@ -318,36 +355,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
     HIPCHK(c, hipMemcpy(c->d_topE, topE.data(), sizeof(int32_t) * (nTop + 1), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_topS, topS.data(), sizeof(int32_t) * (nTop + 1), hipMemcpyHostToDevice));
   }
-  {
-    // direct placement (gtx::PlaceTable): cells of 2^sh positions, sh the smallest shift that keeps the table at about one cell
-    // per eight boundaries; a cell's entry = how many boundaries of the class lie below the cell's first position (cell 0: none)
-    const int64_t budget = std::max<int64_t>(1024, nv / 8) + 2 * (int64_t)nClasses;
-    auto cellsOf = [&](int cl, int sh) -> int64_t {
-      if (seg[cl] == seg[cl + 1]) return 0;
-      const int64_t top = std::max<int64_t>(0, sortedE[seg[cl + 1] - 1]);
-      return (top >> sh) + 2;
-    };
-    int sh = 0;
-    for (;; sh++) { int64_t t = 0; for (int cl = 0; cl < nClasses; cl++) t += cellsOf(cl, sh); if (t <= budget || sh >= 31) break; }
-    std::vector<int4> pc(nClasses);
-    std::vector<int32_t> rank;
-    for (int cl = 0; cl < nClasses; cl++) {
-      const int64_t nc = cellsOf(cl, sh);
-      pc[cl] = make_int4(seg[cl], seg[cl + 1], (int)(rank.size() / 2), (int)nc);
-      int32_t ie = seg[cl], is = seg[cl];
-      for (int64_t k = 0; k < nc; k++) {
-        const int64_t first = k << sh;                           // cell 0 stands for everything below 2^sh, negative keys included
-        if (k > 0) { while (ie < seg[cl + 1] && sortedE[ie] < first) ie++; while (is < seg[cl + 1] && sortedS[is] < first) is++; }
-        rank.push_back(ie); rank.push_back(is);
-      }
-    }
-    rank.push_back(0); rank.push_back(0);
-    HIPCHK(c, hipMalloc(&c->d_placeCls, sizeof(int4) * (size_t)std::max(nClasses, 1)));
-    HIPCHK(c, hipMalloc(&c->d_placeRank, sizeof(int32_t) * rank.size()));
-    HIPCHK(c, hipMemcpy(c->d_placeCls, pc.data(), sizeof(int4) * (size_t)nClasses, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_placeRank, rank.data(), sizeof(int32_t) * rank.size(), hipMemcpyHostToDevice));
-    c->placeShift = sh;
-  }
+  { int rc = make_place_table(c, seg, sortedE, sortedS, nClasses, nv, &c->d_placeCls, &c->d_placeRank, &c->placeShift); if (rc) return rc; }
   {
     // bucket table of the unsorted path: cuts of the ends array every bucket_e_size() boundaries, never across classes
     const int kE = gtx::bucket_e_size(), kS = gtx::bucket_s_size();
@@ -473,7 +481,8 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int
   // histograms (tile_sums_kernel, one pass over 16 B per region: 6 us at 1 M regions).  Keeping them up to date costs two
   // more atomics and a wave scan per window flush -- 100 M reads x 1 M regions: kernel 0.218 -> 0.207 ms, step 0.253 ->
   // 0.248 ms; with few regions every wave hits the same handful of counters and the same-address atomics serialise
-  // (10 k regions: 0.28 -> 0.19 ms).  Small batches keep the sums (no extra launch).  GTX_PART_MAX_HIST=0 restores them.
+  // (10 k regions: 0.28 -> 0.19 ms; a group member's 1/8 of 100 M reads over its 3 chromosomes: 0.041 -> 0.103 ms).  Small batches
+  // keep the sums (no extra launch).  GTX_PART_MAX_HIST=0 restores them.
   { static const char *mx = getenv("GTX_PART_MAX_HIST"); const int64_t lim = mx ? atoll(mx) : INT64_MAX;
     if (c->histLen <= lim && nReads >= (1 << 20)) { a.partA = nullptr; a.partB = nullptr; c->tileSumsValid = false; } }
   // span of one wave: long enough to amortise the window placement at its start, short enough that the grid has >= 3
@@ -973,6 +982,7 @@ static int cover_prepare(gtx_ctx *c)
   }
   { int rc = ref_columns(c); if (rc) return rc; }
   { int rc = cover_bucket_tables(c, sortedT, seg); if (rc) return rc; }
+  { int rc = make_place_table(c, seg, sortedT, sortedT, c->nClasses, nt, &c->d_placeClsT, &c->d_placeRankT, &c->placeShiftT); if (rc) return rc; }
   c->covReady = true; c->covDirty = false;
   return GTX_OK;
 }
@@ -991,6 +1001,9 @@ static gtx::CoverArgs cover_args(gtx_ctx *c, int64_t nReads, int64_t indexBase =
   // span per wave: as count_args, a little longer (the start of a span costs more here: 100 M reads: 0.55 ms at 16 chunks, 0.44 at 32,
   // 0.382 at 56, 0.374 at 64, 0.383 at 96)
   a.chunksPerWave = c->chunksPerWave > 0 ? c->chunksPerWave : (int)std::min<int64_t>(64, std::max<int64_t>(8, nChunks / 24576));
+  a.chunksPerWave = (a.chunksPerWave + 3) / 4 * 4;
+  a.sched = gtx::span_schedule(nChunks, a.chunksPerWave, 4, c->waveSlots);
+  a.place.cls = c->d_placeClsT; a.place.rank = c->d_placeRankT; a.place.shift = c->placeShiftT;
   return a;
 }
 
@@ -1460,12 +1473,13 @@ int gtxi_set_share(gtx_ctx *c, const uint8_t *owned, int32_t nClasses, const int
   if (!tiles.empty()) HIPCHK(c, hipMemcpy(c->d_shareTiles, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice));
   if (nRegions > 0) HIPCHK(c, hipMemcpy(c->d_shareRegions, regions, sizeof(int32_t) * (size_t)nRegions, hipMemcpyHostToDevice));
   c->nShareTiles = (int)tiles.size(); c->nShareRegions = nRegions; c->shareOffset = offset; c->shareOn = true;
-  return ensure_out(c, (size_t)c->nRefs);
+  return ensure_out(c, 2 * (size_t)c->nRefs);                    // two compact vectors: gtxi_count_device_share alternates (slot)
 }
 
 // gtx_count_device for a group member: the reads (of the member's classes, resident on its device) are counted and the member's
-// regions finalized into its piece of the compact vector, c->d_out + shareOffset.  Enqueued on the context's stream.
-int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, void **d_piece, int64_t *pieceLen)
+// regions finalized into its piece of compact vector `slot` (0 | 1), c->d_out + slot * nRefs + shareOffset.  Enqueued on the
+// context's stream.
+int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, void **d_piece, int64_t *pieceLen)
 {
   if (!c->shareOn) return fail(c, GTX_E_STATE, "gtxi_count_device_share: no share set");
   if (n < 0 || (n > 0 && !d_reads)) return fail(c, GTX_E_ARG, "gtx_group_count_device: bad argument");
@@ -1481,9 +1495,10 @@ int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weigh
     else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n)); if (rc) return rc; }
   }
   if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  rc = count_end(c, c->d_out + c->shareOffset, true); if (rc) return rc;
+  u64 *dst = c->d_out + (slot & 1) * c->nRefs + c->shareOffset;
+  rc = count_end(c, dst, true); if (rc) return rc;
   if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
-  *d_piece = c->d_out + c->shareOffset; *pieceLen = c->nShareRegions;
+  *d_piece = dst; *pieceLen = c->nShareRegions;
   return GTX_OK;
 }
 

@@ -116,7 +116,10 @@ struct gtx_group {
   // compact layout (gtx_group_plan): piece of member m = compact positions segOff[m] .. segOff[m+1]
   bool planValid = false; std::vector<int64_t> segOff; std::vector<int32_t> perm;
   int *d_perm = nullptr; unsigned long long *d_selfTmp = nullptr; size_t capSelfTmp = 0;
-  hipEvent_t evPiece = nullptr;            // rehearsal: a member's piece is ready
+  hipEvent_t evPiece = nullptr;            // rehearsal (scans): a member's piece is ready
+  // gtx_group_count_device: the pieces travel on a stream of their own per local member, behind an event of the member's
+  // finalize step, into one of two compact vectors in turn -- call k+1's kernels run under call k's exchange
+  std::vector<hipStream_t> xs; std::vector<hipEvent_t> evFinal[2], evXchg[2]; bool xchgUsed[2] = {false, false}; long long seq = 0;
   // scratch of the router for interleaved input
   std::vector<std::vector<int32_t>> partTri, partW;
 
@@ -174,14 +177,17 @@ int gtx_group_unique_id(void *id_out)
 gtx_group *gtx_group_create_rank(int device_id, int rank, int world, const void *unique_id)
 {
   if (world < 1 || rank < 0 || rank >= world) { g_group_create_error = "gtx_group_create_rank: bad rank / world size"; return nullptr; }
-  if (world > 1 && !unique_id) { g_group_create_error = "gtx_group_create_rank: a group of more than one process needs the id of gtx_group_unique_id"; return nullptr; }
+  // GTX_GROUP_NO_EXCHANGE=1 (measurement only): a member of a larger group without a communicator -- what it does locally
+  // (streaming kernel, finalize of its share, member 0's reordering) can be timed on one GPU; nothing travels
+  const char *nx = getenv("GTX_GROUP_NO_EXCHANGE");
+  if (world > 1 && !unique_id && !(nx && atoi(nx))) { g_group_create_error = "gtx_group_create_rank: a group of more than one process needs the id of gtx_group_unique_id"; return nullptr; }
   gtx_group *g = new gtx_group();
   g->nm = world; g->rank = rank;
   { const char *se = getenv("GTX_GROUP_SELF_EXCHANGE"); g->selfExchange = se && atoi(se) && world == 1; }
   gtx_ctx *c = gtx_create(device_id);
   if (!c) { g_group_create_error = gtx_last_error(nullptr); delete g; return nullptr; }
   g->ctx.push_back(c); g->dev.push_back(device_id);
-  if (world > 1 || (unique_id && g->selfExchange)) {
+  if ((world > 1 && unique_id) || (unique_id && g->selfExchange)) {
     if (!g->rccl.load(&g_group_create_error)) { gtx_group_destroy(g); return nullptr; }
     ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
     g->comm.resize(1);
@@ -197,6 +203,11 @@ void gtx_group_destroy(gtx_group *g)
 {
   if (!g) return;
   for (ncclComm_t c : g->comm) if (c) g->rccl.CommDestroy(c);
+  for (size_t li = 0; li < g->xs.size(); li++) {
+    (void)hipSetDevice(g->dev[li]);
+    if (g->xs[li]) { (void)hipStreamSynchronize(g->xs[li]); (void)hipStreamDestroy(g->xs[li]); }
+    for (int k = 0; k < 2; k++) { if (li < g->evFinal[k].size() && g->evFinal[k][li]) (void)hipEventDestroy(g->evFinal[k][li]); if (li < g->evXchg[k].size() && g->evXchg[k][li]) (void)hipEventDestroy(g->evXchg[k][li]); }
+  }
   if (!g->ctx.empty()) {
     (void)hipSetDevice(g->dev[0]);
     if (g->d_perm) (void)hipFree(g->d_perm);
@@ -314,7 +325,7 @@ static int ensure_plan(gtx_group *g)
 
 // The pieces of the compact vector travel to member 0: piece[li] / len of every local member (already finalized on its stream);
 // member 0 receives at root + segOff[m] (its own piece is in place).  One grouped RCCL call per process; asynchronous.
-static int gather_pieces(gtx_group *g, const std::vector<void *> &piece, unsigned long long *root)
+static int gather_pieces(gtx_group *g, const std::vector<void *> &piece, unsigned long long *root, const std::vector<hipStream_t> &st)
 {
   const int l0 = g->local(0);
   if (l0 >= 0) GCHK_HIP(g, hipSetDevice(g->dev[l0]));
@@ -322,9 +333,8 @@ static int gather_pieces(gtx_group *g, const std::vector<void *> &piece, unsigne
     for (size_t li = 0; li < g->ctx.size(); li++) {
       const int mem = g->member((int)li); const int64_t len = g->segOff[mem + 1] - g->segOff[mem];
       if (mem == 0 || len == 0) continue;
-      GCHK_HIP(g, hipEventRecord(g->evPiece, gtxi_stream(g->ctx[li])));
-      GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[l0]), g->evPiece, 0));
-      GCHK_HIP(g, hipMemcpyAsync(root + g->segOff[mem], piece[li], sizeof(uint64_t) * (size_t)len, hipMemcpyDeviceToDevice, gtxi_stream(g->ctx[l0])));
+      if (st[li] != st[l0]) { GCHK_HIP(g, hipEventRecord(g->evPiece, st[li])); GCHK_HIP(g, hipStreamWaitEvent(st[l0], g->evPiece, 0)); }
+      GCHK_HIP(g, hipMemcpyAsync(root + g->segOff[mem], piece[li], sizeof(uint64_t) * (size_t)len, hipMemcpyDeviceToDevice, st[l0]));
     }
     return GTX_OK;
   }
@@ -333,23 +343,23 @@ static int gather_pieces(gtx_group *g, const std::vector<void *> &piece, unsigne
   if (g->selfExchange && l0 >= 0 && len0 > 0) {            // test hook: member 0's piece leaves and comes back through RCCL
     GCHK_HIP(g, hipSetDevice(g->dev[l0]));
     if ((size_t)len0 > g->capSelfTmp) { if (g->d_selfTmp) (void)hipFree(g->d_selfTmp); g->d_selfTmp = nullptr; GCHK_HIP(g, hipMalloc(&g->d_selfTmp, sizeof(uint64_t) * (size_t)len0)); g->capSelfTmp = (size_t)len0; }
-    GCHK_HIP(g, hipMemcpyAsync(g->d_selfTmp, root + g->segOff[0], sizeof(uint64_t) * (size_t)len0, hipMemcpyDeviceToDevice, gtxi_stream(g->ctx[l0])));
-    GCHK_HIP(g, hipMemsetAsync(root + g->segOff[0], 0xff, sizeof(uint64_t) * (size_t)len0, gtxi_stream(g->ctx[l0])));
+    GCHK_HIP(g, hipMemcpyAsync(g->d_selfTmp, root + g->segOff[0], sizeof(uint64_t) * (size_t)len0, hipMemcpyDeviceToDevice, st[l0]));
+    GCHK_HIP(g, hipMemsetAsync(root + g->segOff[0], 0xff, sizeof(uint64_t) * (size_t)len0, st[l0]));
   }
   GCHK_NCCL(g, g->rccl.GroupStart());
   ncclResult_t r = ncclSuccess;
   for (size_t li = 0; li < g->ctx.size() && r == ncclSuccess; li++) {
     const int mem = g->member((int)li); const int64_t len = g->segOff[mem + 1] - g->segOff[mem];
-    if (mem != 0 && len > 0) r = g->rccl.Send(piece[li], (size_t)len, ncclUint64, 0, g->comm[li], gtxi_stream(g->ctx[li]));
+    if (mem != 0 && len > 0) r = g->rccl.Send(piece[li], (size_t)len, ncclUint64, 0, g->comm[li], st[li]);
   }
   if (l0 >= 0) {
     for (int mem = 1; mem < g->nm && r == ncclSuccess; mem++) {
       const int64_t len = g->segOff[mem + 1] - g->segOff[mem];
-      if (len > 0) r = g->rccl.Recv(root + g->segOff[mem], (size_t)len, ncclUint64, mem, g->comm[l0], gtxi_stream(g->ctx[l0]));
+      if (len > 0) r = g->rccl.Recv(root + g->segOff[mem], (size_t)len, ncclUint64, mem, g->comm[l0], st[l0]);
     }
     if (g->selfExchange && len0 > 0 && r == ncclSuccess) {
-      r = g->rccl.Send(g->d_selfTmp, (size_t)len0, ncclUint64, 0, g->comm[l0], gtxi_stream(g->ctx[l0]));
-      if (r == ncclSuccess) r = g->rccl.Recv(root + g->segOff[0], (size_t)len0, ncclUint64, 0, g->comm[l0], gtxi_stream(g->ctx[l0]));
+      r = g->rccl.Send(g->d_selfTmp, (size_t)len0, ncclUint64, 0, g->comm[l0], st[l0]);
+      if (r == ncclSuccess) r = g->rccl.Recv(root + g->segOff[0], (size_t)len0, ncclUint64, 0, g->comm[l0], st[l0]);
     }
   }
   if (r != ncclSuccess) { g->rccl.GroupEnd(); g->err = std::string("ncclSend/ncclRecv: ") + g->rccl.GetErrorString(r); return GTX_E_HIP; }
@@ -358,12 +368,12 @@ static int gather_pieces(gtx_group *g, const std::vector<void *> &piece, unsigne
 }
 
 // member 0: compact -> file order into d_hits (enqueued on its stream)
-static int unpermute(gtx_group *g, const unsigned long long *root, void *d_hits)
+static int unpermute(gtx_group *g, const unsigned long long *root, void *d_hits, hipStream_t st)
 {
   const int l0 = g->local(0);
   if (l0 < 0 || g->nRefs <= 0) return GTX_OK;
   GCHK_HIP(g, hipSetDevice(g->dev[l0]));
-  unpermute_kernel<<<(unsigned)((g->nRefs + 255) / 256), 256, 0, gtxi_stream(g->ctx[l0])>>>(root, g->d_perm, g->nRefs, (unsigned long long *)d_hits);
+  unpermute_kernel<<<(unsigned)((g->nRefs + 255) / 256), 256, 0, st>>>(root, g->d_perm, g->nRefs, (unsigned long long *)d_hits);
   GCHK_HIP(g, hipGetLastError());
   return GTX_OK;
 }
@@ -376,22 +386,55 @@ int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void 
   if (!d_reads || !n_reads) return gfail(g, GTX_E_ARG, "gtx_group_count_device: bad argument");
   if (g->local(0) >= 0 && g->nRefs > 0 && !d_hits) return gfail(g, GTX_E_ARG, "gtx_group_count_device: member 0 needs the output vector");
   int rc = ensure_plan(g); if (rc) return rc;
-  std::vector<void *> piece(g->ctx.size(), nullptr);
-  for (size_t li = 0; li < g->ctx.size(); li++) {
+  const size_t nl = g->ctx.size();
+  if (g->xs.empty()) {
+    g->xs.assign(nl, nullptr);
+    for (int k = 0; k < 2; k++) { g->evFinal[k].assign(nl, nullptr); g->evXchg[k].assign(nl, nullptr); }
+    for (size_t li = 0; li < nl; li++) {
+      GCHK_HIP(g, hipSetDevice(g->dev[li]));
+      GCHK_HIP(g, hipStreamCreateWithFlags(&g->xs[li], hipStreamNonBlocking));
+      for (int k = 0; k < 2; k++) { GCHK_HIP(g, hipEventCreateWithFlags(&g->evFinal[k][li], hipEventDisableTiming)); GCHK_HIP(g, hipEventCreateWithFlags(&g->evXchg[k][li], hipEventDisableTiming)); }
+    }
+  }
+  const int slot = (int)(g->seq++ & 1);
+  std::vector<void *> piece(nl, nullptr);
+  for (size_t li = 0; li < nl; li++) {
     int64_t len = 0;
     g->memberReads[g->member((int)li)] = n_reads[li];
-    GCHK_CTX(g, li, gtxi_count_device_share(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, &piece[li], &len));
+    GCHK_HIP(g, hipSetDevice(g->dev[li]));
+    // compact vector `slot` is free again when the exchange of the call before last is over (a device-side wait)
+    if (g->xchgUsed[slot]) GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[slot][li], 0));
+    GCHK_CTX(g, li, gtxi_count_device_share(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, slot, &piece[li], &len));
+    GCHK_HIP(g, hipEventRecord(g->evFinal[slot][li], gtxi_stream(g->ctx[li])));
+    GCHK_HIP(g, hipStreamWaitEvent(g->xs[li], g->evFinal[slot][li], 0));
   }
   const int l0 = g->local(0);
-  unsigned long long *root = l0 >= 0 ? (unsigned long long *)gtxi_out_buffer(g->ctx[l0]) : nullptr;
-  rc = gather_pieces(g, piece, root); if (rc) return rc;
-  return unpermute(g, root, d_hits);
+  unsigned long long *root = l0 >= 0 ? (unsigned long long *)gtxi_out_buffer(g->ctx[l0]) + (size_t)slot * (size_t)g->nRefs : nullptr;
+  if (g->rehearse && l0 >= 0)                                  // (one device: member 0's exchange stream copies behind every member's finalize)
+    for (size_t li = 0; li < nl; li++) GCHK_HIP(g, hipStreamWaitEvent(g->xs[l0], g->evFinal[slot][li], 0));
+  rc = gather_pieces(g, piece, root, g->xs); if (rc) return rc;
+  rc = unpermute(g, root, d_hits, l0 >= 0 ? g->xs[l0] : nullptr); if (rc) return rc;
+  for (size_t li = 0; li < nl; li++) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipEventRecord(g->evXchg[slot][li], g->xs[li])); }
+  g->xchgUsed[slot] = true;
+  return GTX_OK;
+}
+
+int gtx_group_wait_result(gtx_group *g)
+{
+  if (!g) return GTX_E_ARG;
+  if (g->seq == 0) return GTX_OK;
+  const int slot = (int)((g->seq - 1) & 1);
+  for (size_t li = 0; li < g->ctx.size(); li++) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[slot][li], 0)); }
+  return GTX_OK;
 }
 
 int gtx_group_sync(gtx_group *g)
 {
   if (!g) return GTX_E_ARG;
-  for (size_t li = 0; li < g->ctx.size(); li++) GCHK_CTX(g, li, gtx_sync(g->ctx[li]));
+  for (size_t li = 0; li < g->ctx.size(); li++) {
+    GCHK_CTX(g, li, gtx_sync(g->ctx[li]));
+    if (li < g->xs.size() && g->xs[li]) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamSynchronize(g->xs[li])); }
+  }
   return GTX_OK;
 }
 
@@ -536,9 +579,21 @@ static int reduce_to_root(gtx_group *g, std::vector<void *> &d, int64_t count)
   return GTX_OK;
 }
 
+// the host-buffer calls and the scans work on the members' own streams and on compact vector 0: behind any exchange of an
+// earlier gtx_group_count_device that is still on its way (device-side waits)
+static int wait_exchanges(gtx_group *g)
+{
+  for (int k = 0; k < 2; k++) {
+    if (!g->xchgUsed[k]) continue;
+    for (size_t li = 0; li < g->ctx.size(); li++) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[k][li], 0)); }
+  }
+  return GTX_OK;
+}
+
 static int finish(gtx_group *g, bool coverage, uint64_t *out, gtx_count_info *info)
 {
   const int n = (int)g->ctx.size();
+  { int rc = wait_exchanges(g); if (rc) return rc; }
   std::vector<void *> d(n, nullptr);
   // count on a plain reference set: every member finalizes its own classes into its piece of the compact vector
   const bool pieces = !coverage && !(g->refFlags & GTX_REFS_KEEP_ZERO_LENGTH);
@@ -547,7 +602,9 @@ static int finish(gtx_group *g, bool coverage, uint64_t *out, gtx_count_info *in
   GCHK_HIP(g, hipSetDevice(g->dev[0]));
   if (pieces) {
     unsigned long long *root = (unsigned long long *)gtxi_out_buffer(g->ctx[0]);
-    int rc = gather_pieces(g, d, root); if (rc) return rc;
+    std::vector<hipStream_t> st(n);
+    for (int i = 0; i < n; i++) st[i] = gtxi_stream(g->ctx[i]);
+    int rc = gather_pieces(g, d, root, st); if (rc) return rc;
     // compact -> file order on the way out: the host puts the copy in order (no second device vector)
     if (g->nRefs > 0) {
       std::vector<uint64_t> compact((size_t)g->nRefs);
@@ -720,6 +777,7 @@ int gtx_group_scan_device(gtx_group *g, const void *const *d_reads, const void *
   if (!d_reads || !n_reads || n_classes < 1 || !class_len || !class_offsets) return gfail(g, GTX_E_ARG, "gtx_group_scan_device: bad argument");
   if (win_step <= 0 || win_size <= 0 || win_size % win_step) return gfail(g, GTX_E_ARG, "gtx_group_scan_device: window size must be a positive multiple of window step");
   scan_assign(g, class_len, n_classes);
+  { int rc = wait_exchanges(g); if (rc) return rc; }
   if (g->local(0) >= 0 && !g->evPiece) { GCHK_HIP(g, hipSetDevice(g->dev[g->local(0)])); GCHK_HIP(g, hipEventCreateWithFlags(&g->evPiece, hipEventDisableTiming)); }
   std::vector<ScanShare> share(g->ctx.size());
   std::vector<void *> piece(g->ctx.size(), nullptr);
@@ -759,6 +817,7 @@ int gtx_group_scan(gtx_group *g, const int32_t *reads, const int32_t *weights, i
     return GTX_OK;
   }
   scan_assign(g, class_len, n_classes);
+  { int rc = wait_exchanges(g); if (rc) return rc; }
   if (!g->evPiece) { GCHK_HIP(g, hipSetDevice(g->dev[0])); GCHK_HIP(g, hipEventCreateWithFlags(&g->evPiece, hipEventDisableTiming)); }
   std::fill(g->memberReads.begin(), g->memberReads.end(), 0);
   // every member scans its share (a scan is one call per member: the shares are gathered first)

@@ -78,6 +78,8 @@ struct CountArgs {
 struct CoverArgs {
   const int *sortedT, *segStartT;  // thresholds sorted by (class, value); [nClasses+1] class segments
   const int *topT;                 // every 256th threshold (as CountArgs::topE)
+  PlaceTable place;                // over sortedT (both entries of a cell are the same rank: the two windows walk one array)
+  SpanSchedule sched;
   unsigned long long *hist[4], *part[4];
   DevInfo *info;
   int nClasses, chunksPerWave;

@@ -368,20 +368,8 @@ __device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountA
     st.pc = rdlane(cc, last); st.ps = rdlane(t.s, last);
   }
 
-  // the wave stays with its class while the chunk still has reads of it (interleaved classes: the others
-  // add themselves lane by lane); otherwise it follows the class of the chunk's first read
-  int c0 = rdlane(t.c, 0);
-  if (st.sg.cls >= 0 && (__ballot(t.c == st.sg.cls) & active)) c0 = st.sg.cls;
-  if (c0 != st.sg.cls && (unsigned)c0 < (unsigned)a.nClasses) {
-    if (st.validA) st.A.flush(st.sg, lane);
-    if (st.validB) st.B.flush(st.sg, lane);
-    st.validA = st.validB = false;
-    st.sg.start = rfl(a.segStart[c0]); st.sg.end = rfl(a.segStart[c0 + 1]); st.sg.cls = c0;
-  }
   const u64 degen = __ballot(t.s > t.e + a.zeroLenOk) & active;
   const u64 noclass = __ballot((unsigned)t.c >= (unsigned)a.nClasses) & active;
-  const u64 mine = __ballot(t.c == st.sg.cls) & active & ~degen & ~noclass;
-  const u64 other = active & ~mine & ~degen & ~noclass;      // valid reads of another class
   if (degen | noclass) {
     st.nNoClass += __popcll(noclass);
     u64 dg = degen & ~noclass;
@@ -390,16 +378,47 @@ __device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountA
       side_append(a, t.c, t.s, t.e, w, (dg >> lane) & 1);
     }
   }
-  if (mine && st.sg.start != st.sg.end) {
-    u64 ra = st.A.walk(st.sg, t.s, w, mine, lane, st.validA);
-    u64 rb = st.B.walk(st.sg, t.e, w, mine, lane, st.validB);
-    if (ra) st.A.lanes_add(st.sg, t.s, w, ra, lane);
-    if (rb) st.B.lanes_add(st.sg, t.e, w, rb, lane);
+  // The chunk class by class: the wave stays with its class while the chunk still has reads of it, then follows the class of
+  // the first read left -- sorted reads: the one chunk of a span in which the chromosome changes takes two turns, each through
+  // the register windows (the windows of the new class placed through the cell table, as at the start of a span).  Reads of
+  // further classes (interleaved input) add themselves with two binary searches per lane, as do keys scattered over many windows.
+  u64 todo = active & ~degen & ~noclass;                       // valid reads of known classes
+#pragma unroll 1
+  for (int turn = 0; todo && turn < 2; ++turn) {
+    int c0 = rdlane(t.c, __ffsll((unsigned long long)todo) - 1);
+    if (st.sg.cls >= 0 && (__ballot(t.c == st.sg.cls) & todo)) c0 = st.sg.cls;
+    if (c0 != st.sg.cls) {
+      if (st.validA) st.A.flush(st.sg, lane);
+      if (st.validB) st.B.flush(st.sg, lane);
+      st.validA = st.validB = false;
+      const int4 pc = a.place.cls[c0];                         // {segment start, end, first cell, cells}
+      st.sg.start = rfl(pc.x); st.sg.end = rfl(pc.y); st.sg.cls = c0;
+      if (st.sg.start != st.sg.end) {
+        const u64 m = __ballot(t.c == c0) & todo;
+        const int kA = wave_min(((m >> lane) & 1) ? t.s : kHi), kB = wave_min(((m >> lane) & 1) ? t.e : kHi);
+        int cell = (kA > 0 ? kA : 0) >> a.place.shift; cell = cell < rfl(pc.w) - 1 ? cell : rfl(pc.w) - 1;
+        const int *rk = a.place.rank + 2 * ((i64)rfl(pc.z) + cell);
+        const int pA = rfl(rk[0]), pB = rfl(rk[1]);
+        st.A.W = st.A.load_window(st.sg, pA, lane); st.A.Wn = st.A.load_window(st.sg, pA + kSlots, lane);
+        st.B.W = st.B.load_window(st.sg, pB, lane); st.B.Wn = st.B.load_window(st.sg, pB + kSlots, lane);
+        const u64 mA = __ballot(st.A.before(st.A.W, kA)), mB = __ballot(st.B.before(st.B.W, kB));
+        if ((mA & 1) && (i64)mA >= 0) { st.A.place_loaded(pA, __popcll(mA) - 1); st.validA = true; }
+        if ((mB & 1) && (i64)mB >= 0) { st.B.place_loaded(pB, __popcll(mB) - 1); st.validB = true; }
+      }
+    }
+    const u64 mine = __ballot(t.c == st.sg.cls) & todo;
+    todo &= ~mine;
+    if (mine && st.sg.start != st.sg.end) {
+      u64 ra = st.A.walk(st.sg, t.s, w, mine, lane, st.validA);
+      u64 rb = st.B.walk(st.sg, t.e, w, mine, lane, st.validB);
+      if (ra) st.A.lanes_add(st.sg, t.s, w, ra, lane);
+      if (rb) st.B.lanes_add(st.sg, t.e, w, rb, lane);
+    }
   }
-  if (other) {
+  if (todo) {
     Seg so; so.start = 0; so.end = 0; so.cls = 0;
-    if ((other >> lane) & 1) { so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c; }
-    const u64 has = __ballot(so.start != so.end) & other;          // classes without reference regions: nothing to add
+    if ((todo >> lane) & 1) { so.start = a.segStart[t.c]; so.end = a.segStart[t.c + 1]; so.cls = t.c; }
+    const u64 has = __ballot(so.start != so.end) & todo;           // classes without reference regions: nothing to add
     if (has) { st.A.lanes_add(so, t.s, w, has, lane); st.B.lanes_add(so, t.e, w, has, lane); }
   }
 }
@@ -968,7 +987,7 @@ __global__ __launch_bounds__(256) void count_walk_kernel_weighted(const Tri *__r
 {
   count_walk_body<true, 4, true>(reads, weights, n, a);
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void count_walk_kernel_flip(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void count_walk_kernel_flip(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
 {
   count_walk_body<false, 4, true>(reads, weights, n, a);
 }
@@ -1180,18 +1199,8 @@ template <bool WEIGHTED>
 __device__ __forceinline__ void cov_chunk(CovState<WEIGHTED> &st, const CoverArgs &a, const Tri &t, int w, u64 active, i64 firstIndex, int lane)
 {
   Seg &sg = st.sg;
-  int c0 = rdlane(t.c, 0);
-  if (sg.cls >= 0 && (__ballot(t.c == sg.cls) & active)) c0 = sg.cls;
-  if (c0 != sg.cls && (unsigned)c0 < (unsigned)a.nClasses) {
-    if (st.vs) st.Ws.flush(sg, lane);
-    if (st.ve) st.We.flush(sg, lane);
-    st.vs = st.ve = false;
-    sg.start = rfl(a.segStartT[c0]); sg.end = rfl(a.segStartT[c0 + 1]); sg.cls = c0;
-  }
   const u64 noclass = __ballot((unsigned)t.c >= (unsigned)a.nClasses) & active;
   const u64 degen = __ballot(t.s > t.e) & active & ~noclass;        // zero-length or inverted: contributes nothing
-  const u64 mine = __ballot(t.c == sg.cls) & active & ~degen & ~noclass;
-  const u64 other = active & ~mine & ~degen & ~noclass;
   if (degen | noclass) {
     st.nNoClass += __popcll(noclass);
     const u64 inv = __ballot(t.s > t.e + 1) & degen;                // only these are reported (the packer's business)
@@ -1200,22 +1209,49 @@ __device__ __forceinline__ void cov_chunk(CovState<WEIGHTED> &st, const CoverArg
       side_append(a, t.c, t.s, t.e, w, (inv >> lane) & 1);
     }
   }
-  if (mine && sg.start != sg.end) {
-    u64 r0, r1;
-    if (!WEIGHTED && mine == ~0ull) {
-      r0 = walk_cov_chunk(st.Ws, sg, t.s, lane, st.vs);
-      r1 = walk_cov_chunk(st.We, sg, t.e, lane, st.ve);
-    } else {
-      r0 = st.Ws.walk(sg, t.s, w, mine, lane, st.vs);
-      r1 = st.We.walk(sg, t.e, w, mine, lane, st.ve);
+  // class by class, as walk_chunk: the chunk in which the chromosome changes takes two turns through the register windows, the
+  // new class's windows placed through the cell table
+  u64 todo = active & ~degen & ~noclass;
+#pragma unroll 1
+  for (int turn = 0; todo && turn < 2; ++turn) {
+    int c0 = rdlane(t.c, __ffsll((unsigned long long)todo) - 1);
+    if (sg.cls >= 0 && (__ballot(t.c == sg.cls) & todo)) c0 = sg.cls;
+    if (c0 != sg.cls) {
+      if (st.vs) st.Ws.flush(sg, lane);
+      if (st.ve) st.We.flush(sg, lane);
+      st.vs = st.ve = false;
+      const int4 pc = a.place.cls[c0];
+      sg.start = rfl(pc.x); sg.end = rfl(pc.y); sg.cls = c0;
+      if (sg.start != sg.end) {
+        const u64 m = __ballot(t.c == c0) & todo;
+        const int ks = wave_min(((m >> lane) & 1) ? t.s : kHi), ke = wave_min(((m >> lane) & 1) ? t.e : kHi);
+        int cell = (ks > 0 ? ks : 0) >> a.place.shift; cell = cell < rfl(pc.w) - 1 ? cell : rfl(pc.w) - 1;
+        const int p0 = rfl(a.place.rank[2 * ((i64)rfl(pc.z) + cell)]);
+        st.Ws.W = st.We.W = st.Ws.load_window(sg, p0, lane); st.Ws.Wn = st.We.Wn = st.Ws.load_window(sg, p0 + kSlots, lane);
+        const u64 ms = __ballot(st.Ws.before(st.Ws.W, ks)), me = __ballot(st.We.before(st.We.W, ke));
+        if ((ms & 1) && (i64)ms >= 0) { st.Ws.place_loaded(p0, __popcll(ms) - 1); st.vs = true; }
+        if ((me & 1) && (i64)me >= 0) { st.We.place_loaded(p0, __popcll(me) - 1); st.ve = true; }
+      }
     }
-    if (r0) st.Ws.lanes_add(sg, t.s, w, r0, lane);
-    if (r1) st.We.lanes_add(sg, t.e, w, r1, lane);
+    const u64 mine = __ballot(t.c == sg.cls) & todo;
+    todo &= ~mine;
+    if (mine && sg.start != sg.end) {
+      u64 r0, r1;
+      if (!WEIGHTED && mine == ~0ull) {
+        r0 = walk_cov_chunk(st.Ws, sg, t.s, lane, st.vs);
+        r1 = walk_cov_chunk(st.We, sg, t.e, lane, st.ve);
+      } else {
+        r0 = st.Ws.walk(sg, t.s, w, mine, lane, st.vs);
+        r1 = st.We.walk(sg, t.e, w, mine, lane, st.ve);
+      }
+      if (r0) st.Ws.lanes_add(sg, t.s, w, r0, lane);
+      if (r1) st.We.lanes_add(sg, t.e, w, r1, lane);
+    }
   }
-  if (other) {
+  if (todo) {
     Seg so; so.start = 0; so.end = 0; so.cls = 0;
-    if ((other >> lane) & 1) { so.start = a.segStartT[t.c]; so.end = a.segStartT[t.c + 1]; so.cls = t.c; }
-    const u64 has = __ballot(so.start != so.end) & other;
+    if ((todo >> lane) & 1) { so.start = a.segStartT[t.c]; so.end = a.segStartT[t.c + 1]; so.cls = t.c; }
+    const u64 has = __ballot(so.start != so.end) & todo;
     if (has) { st.Ws.lanes_add(so, t.s, w, has, lane); st.We.lanes_add(so, t.e, w, has, lane); }
   }
 }
@@ -1226,9 +1262,13 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
 {
   const int lane = threadIdx.x & 63;
   const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + rfl(threadIdx.x >> 6);
-  const i64 first = wave * (i64)a.chunksPerWave * 64;
+  int sw0 = a.sched.wave0[0], sc0 = a.sched.chunk0[0], scp = a.sched.cpw[0];      // this wave's span (SpanSchedule)
+#pragma unroll
+  for (int i = 1; i < SpanSchedule::kMax; ++i)
+    if (wave >= a.sched.wave0[i]) { sw0 = a.sched.wave0[i]; sc0 = a.sched.chunk0[i]; scp = a.sched.cpw[i]; }
+  const i64 first = ((i64)sc0 + (wave - sw0) * scp) * 64;
   if (first >= n) return;
-  i64 cnt = n - first; if (cnt > (i64)a.chunksPerWave * 64) cnt = (i64)a.chunksPerWave * 64;
+  i64 cnt = n - first; if (cnt > (i64)scp * 64) cnt = (i64)scp * 64;
   const int nMine = (int)cnt;
 
   __shared__ int ldsK[4][256], ldsP[WEIGHTED ? 1 : 4][WEIGHTED ? 1 : 264];   // per wave: the keys of a step and their prefix sums
@@ -1254,21 +1294,44 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
   if ((!WEIGHTED || a.wfast) && nMine >= 256) {
     // the common start (as in count_walk_body): the first step is all of one class with reference regions -- both
     // windows placed by one paired search instead of two 64-ary searches in a row through the general code
+    // (as count_walk_body: the span's first read by a scalar load ahead of the step's vector loads, its cell's rank, the windows
+    // loaded there while the step is on its way; the step's real keys decide)
+    const int *fr = (const int *)(reads + first);
+    const int fc0 = fr[0], fs0 = fr[1];
+    __builtin_amdgcn_sched_barrier(0);
     Tri t[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) t[r] = load_tri(base + 768 * r);
+    const int fc = rfl(fc0), fs = rfl(fs0);
+    int pre = 0, preCls = -1; Seg preSeg; preSeg.start = 0; preSeg.end = 0; preSeg.cls = -1;
+    if ((unsigned)fc < (unsigned)a.nClasses) {
+      const int4 pc = a.place.cls[fc];
+      preSeg.start = rfl(pc.x); preSeg.end = rfl(pc.y); preSeg.cls = fc;
+      if (preSeg.start != preSeg.end) {
+        int cell = (fs > 0 ? fs : 0) >> a.place.shift; cell = cell < rfl(pc.w) - 1 ? cell : rfl(pc.w) - 1;
+        pre = rfl(a.place.rank[2 * ((i64)rfl(pc.z) + cell)]); preCls = fc;
+        st.Ws.W = st.We.W = st.Ws.load_window(preSeg, pre, lane); st.Ws.Wn = st.We.Wn = st.Ws.load_window(preSeg, pre + kSlots, lane);
+      }
+    }
     const int c0 = rdlane(t[0].c, 0);
     bool odd = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) odd |= t[r].c != c0 || t[r].s > t[r].e;
     if ((unsigned)c0 < (unsigned)a.nClasses && __ballot(odd) == 0) {
-      st.sg.start = rfl(a.segStartT[c0]); st.sg.end = rfl(a.segStartT[c0 + 1]); st.sg.cls = c0;
+      if (c0 == preCls) st.sg = preSeg;
+      else { st.sg.start = rfl(a.segStartT[c0]); st.sg.end = rfl(a.segStartT[c0 + 1]); st.sg.cls = c0; }
       if (st.sg.start != st.sg.end) {
         const int ks[4] = {t[0].s, t[1].s, t[2].s, t[3].s}, ke[4] = {t[0].e, t[1].e, t[2].e, t[3].e};
-        const int *top = a.topT;
-        int ps, pe;
-        rank_pair(st.sg, st.Ws, top, wave_min(min_of<4>(ks)), st.We, top, wave_min(min_of<4>(ke)), lane, ps, pe);
-        st.Ws.place(st.sg, ps, lane); st.We.place(st.sg, pe, lane);
+        const int kS = wave_min(min_of<4>(ks)), kE = wave_min(min_of<4>(ke));
+        const u64 ms = __ballot(st.Ws.before(st.Ws.W, kS)), me = __ballot(st.We.before(st.We.W, kE));
+        if (c0 == preCls && (ms & 1) && (me & 1) && (i64)ms >= 0 && (i64)me >= 0) {
+          st.Ws.place_loaded(pre, __popcll(ms) - 1); st.We.place_loaded(pre, __popcll(me) - 1);
+        } else {
+          const int *top = a.topT;
+          int ps, pe;
+          rank_pair(st.sg, st.Ws, top, kS, st.We, top, kE, lane, ps, pe);
+          st.Ws.place(st.sg, ps, lane); st.We.place(st.sg, pe, lane);
+        }
         st.vs = st.ve = true;
       }
     }
@@ -1846,8 +1909,7 @@ hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 
 hipError_t launch_coverage(const void *reads, const void *weights, i64 n, const CoverArgs &a, hipStream_t st)
 {
   if (n <= 0) return hipSuccess;
-  const i64 nChunks = (n + 63) >> 6;
-  const i64 waves = (nChunks + a.chunksPerWave - 1) / a.chunksPerWave;
+  const i64 waves = a.sched.nWaves;
   const unsigned grid = (unsigned)((waves + 3) / 4);
   if (weights) coverage_walk_kernel<true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   else coverage_walk_kernel<false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);

@@ -84,6 +84,7 @@ ABI = {
     "gtx_group_scan_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_group_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "gtx_group_wait_result": (ctypes.c_int, [ctypes.c_void_p]),
     "gtx_group_last_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_group_assign": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "gtx_lpt_assign": (None, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int, ctypes.c_void_p]),
@@ -351,8 +352,25 @@ class Group:
                                                  preprocess.encode()[0:1], int(flags), _ptr(d_windows), _ptr(off)))
         return off, tot
 
+    def profile(self, member, on=True):
+        if self.lib.gtx_profile_enable(self.ctx(member), int(on)) != 0:
+            raise GtxError("gtx_profile_enable failed")
+
+    def profiled_calls(self, member):
+        return int(self.lib.gtx_profile_count(self.ctx(member)))
+
+    def profile_last(self, member, back=0):
+        a, b = ctypes.c_float(), ctypes.c_float()
+        if self.lib.gtx_profile_read(self.ctx(member), int(back), ctypes.byref(a), ctypes.byref(b)) != 0:
+            raise GtxError("gtx_profile_read failed")
+        return a.value, b.value
+
     def sync(self):
         self._chk(self.lib.gtx_group_sync(self.g))
+
+    def wait_result(self):
+        """the members' streams wait (on the device) for the last count_device's exchange"""
+        self._chk(self.lib.gtx_group_wait_result(self.g))
 
     def last_info(self):
         info = CountInfo()

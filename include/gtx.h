@@ -262,8 +262,12 @@ int gtx_group_set_refs(gtx_group *g, const int32_t *ref_triples, int64_t n_refs,
  * other classes would be counted into tiles nobody finalizes): d_reads / d_weights / n_reads are indexed by local member
  * (d_weights may be NULL).  Per member the streaming kernel and the finalize step of its share, the pieces to member 0, the
  * result in file order in d_hits (n_refs uint64 on member 0's device; ignored on other ranks).  Everything is enqueued on the
- * members' streams (gtx_set_stream of gtx_group_ctx); gtx_group_sync waits.  GTX_CHECK_SORTED is ignored,
- * GTX_ZERO_LENGTH_OK refused (the sorted merge's host-side corrections live in the host-buffer calls).
+ * members' streams (gtx_set_stream of gtx_group_ctx), except that the pieces travel -- and member 0 writes d_hits -- on a
+ * stream of the group's own behind each member's finalize step, into one of two compact vectors in turn: the kernels of the
+ * next call run under the exchange of this one.  d_hits is complete after gtx_group_sync, or, for work enqueued afterwards on
+ * the members' streams, behind gtx_group_wait_result (a device-side wait, the host does not block); until then the caller
+ * leaves d_hits alone (alternate two vectors to keep calls in flight).  GTX_CHECK_SORTED is ignored, GTX_ZERO_LENGTH_OK
+ * refused (the sorted merge's host-side corrections live in the host-buffer calls).
  * gtx_group_last_info: the sums over the local members (first_unsorted / first_degenerate are not tracked: -1). */
 int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void *const *d_weights, const int64_t *n_reads,
                            uint32_t flags, void *d_hits);
@@ -271,6 +275,7 @@ int gtx_group_scan_device(gtx_group *g, const void *const *d_reads, const void *
                           const int32_t *class_len, int32_t n_classes, int32_t win_step, int32_t win_size, char preprocess,
                           uint32_t flags, void *d_windows /* member 0's device, layout class_offsets */, const int64_t *class_offsets);
 int gtx_group_sync(gtx_group *g);
+int gtx_group_wait_result(gtx_group *g);
 int gtx_group_last_info(gtx_group *g, gtx_count_info *info);
 
 /* The streaming count / coverage calls of a single context, on the group: every read goes to the owner of its class (reads
