@@ -677,11 +677,19 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
   std::string text;
   for (GenomicRegion *r = set->Get(); r != NULL; r = set->Next()) {
     GenomicInterval *i = r->I.front();
-    if (r->I.size() > 1) {                                  // a multi-interval region: its envelope under -gaps, else outside the path
-      if (!opt.match_gaps) r->PrintError("multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps)!");
+    if (r->I.size() > 1) {                                  // a multi-interval region: its envelope under -gaps, its intervals one by one for coverage
+      if (!opt.match_gaps && !opt.explode_blocks) r->PrintError("multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps, and coverage / density)!");
       if (!r->IsCompatibleSortedAndNonoverlapping()) r->PrintError("query regions should be compatible, sorted and non-overlapping!");
     }
     char buf[64];
+    if (opt.explode_blocks && r->I.size() > 1) {
+      for (GenomicIntervalSet::iterator b = r->I.begin(); b != r->I.end(); b++) {
+        text += i->CHROMOSOME; text += '\t';
+        snprintf(buf, sizeof buf, "%ld\t%ld\t", (*b)->START - 1, (*b)->STOP); text += buf;
+        text += r->LABEL; text += "\t0\t"; text += i->STRAND; text += '\n';
+      }
+      continue;
+    }
     text += i->CHROMOSOME; text += '\t';
     snprintf(buf, sizeof buf, "%ld\t%ld\t", i->START - 1, r->I.back()->STOP); text += buf;
     text += r->LABEL; text += "\t0\t"; text += i->STRAND; text += '\n';
@@ -773,15 +781,19 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
     guard.msg = buf;
   }
   ChromTable chroms;
+  bool explode = false;                                                             // coverage without -gaps over multi-interval index regions
   const char *last_name = NULL;                                                     // region files repeat a chromosome many times in a row
   for (long int k = 0; k < v; k++) {
     GenomicRegion *r = IndexSet->R[k];
     GenomicInterval *i = r->I.front();
     if (r->I.size() > 1) {
-      // a multi-interval (BED12) region: with -gaps it is matched on its envelope (:5226, :5752, :5278) -- what the device computes;
-      // without, an overlap needs an interval pair (:1167-1172): outside the path
-      if (!match_gaps) r->PrintError("multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps)!");
+      // a multi-interval (BED12) region: with -gaps it is matched on its envelope (:5226, :5752, :5278) -- what the device computes.
+      // Without: coverage is a sum over ALL interval pairs of the two regions (CalcOverlap :1196-1202, pairs that do not overlap
+      // add 0), so the intervals go to the device one by one (`explode`) and a region's value is the sum of its intervals';
+      // count needs "some interval pair overlaps" (:1167-1172), which no sum of independent pieces gives: outside the path
+      if (!match_gaps && !coverage) r->PrintError("multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps, and coverage / density)!");
       if (!r->IsCompatibleSortedAndNonoverlapping()) r->PrintError("index regions should be compatible, sorted and non-overlapping!");   // :5607, :5853
+      if (!match_gaps) explode = true;
     }
     if (!sorted && (i->START > r->I.back()->STOP || r->I.back()->STOP <= 0)) continue;   // :5609, :5659
     if (last_name && strcmp(last_name, i->CHROMOSOME) == 0) continue;
@@ -807,13 +819,33 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
     refs[3 * k] = id + ((strand_aware && i->STRAND == '-') ? n_chrom : 0);
     refs[3 * k + 1] = (int32_t)i->START; refs[3 * k + 2] = (int32_t)STOP;
   }
+  // `explode`: one device region per interval; first_piece[k] .. first_piece[k+1] are region k's
+  std::vector<long int> first_piece;
+  long int MD = M;
+  if (explode) {
+    std::vector<int32_t> pieces;
+    first_piece.assign((size_t)M + 1, 0);
+    for (long int k = 0; k < M; k++) {
+      first_piece[k] = (long int)(pieces.size() / 3);
+      GenomicRegion *r = IndexSet->R[k];
+      if (refs[3 * k] < 0 || r->I.size() == 1) { pieces.insert(pieces.end(), refs.begin() + 3 * k, refs.begin() + 3 * k + 3); continue; }
+      for (GenomicIntervalSet::iterator b = r->I.begin(); b != r->I.end(); b++) {
+        if ((*b)->START >= INT_MAX - 1 || (*b)->STOP >= INT_MAX - 1 || (*b)->START <= INT_MIN + 1 || (*b)->STOP <= INT_MIN + 1)
+          r->PrintError("coordinate does not fit the packed 32-bit representation of the MI355X path!");
+        pieces.push_back(refs[3 * k]); pieces.push_back((int32_t)(*b)->START); pieces.push_back((int32_t)(*b)->STOP);
+      }
+    }
+    first_piece[M] = (long int)(pieces.size() / 3);
+    MD = first_piece[M];
+    refs.swap(pieces);
+  }
   Mark("index packed");
   gtx_group *grp = NULL;
   const int n_classes = std::max(1, n_chrom * (strand_aware ? 2 : 1));
   auto device_side = [&](bool cover) {                              // (on DrainSet's hand-over thread, while the queries are already being packed)
     grp = Devices();
     Mark("device ready");
-    CheckGrp(grp, gtx_group_set_refs(grp, refs.data(), M, n_classes, sorted ? GTX_REFS_KEEP_ZERO_LENGTH : 0));
+    CheckGrp(grp, gtx_group_set_refs(grp, refs.data(), MD, n_classes, sorted ? GTX_REFS_KEEP_ZERO_LENGTH : 0));
     Mark("gtx_set_refs done");
     CheckGrp(grp, cover ? gtx_group_coverage_begin(grp) : gtx_group_count_begin(grp));
   };
@@ -824,6 +856,7 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   opt.chroms = &chroms; opt.strand_aware = strand_aware; opt.sorted_by_strand = by_strand;
   opt.max_label_value = max_label_value; opt.collect_zero_length = !coverage && sorted && zero_length_refs;
   opt.match_gaps = match_gaps;
+  opt.explode_blocks = coverage && !match_gaps;                  // multi-interval queries: their intervals one by one (see the index side)
   if (v < M) opt.guard = &guard;
   std::vector<int32_t> zero_len;
   unsigned long int *hits = new unsigned long int[M > 0 ? M : 1];
@@ -835,6 +868,11 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
                                            sorted ? (GTX_ZERO_LENGTH_OK | (match_gaps ? GTX_GAPS_FORMULA : 0u)) : 0u));
     });
     Mark("queries packed and enqueued");
+    if (explode) {
+      std::vector<uint64_t> part((size_t)std::max<long int>(MD, 1));
+      CheckGrp(grp, gtx_group_coverage_end(grp, part.data(), &info));
+      for (long int k = 0; k < M; k++) { unsigned long int sum = 0; for (long int j = first_piece[k]; j < first_piece[k + 1]; j++) sum += part[j]; hits[k] = sum; }
+    } else
     CheckGrp(grp, gtx_group_coverage_end(grp, (uint64_t *)hits, &info));
     if (info.n_unplaced != 0) { fflush(stdout); fprintf(stderr, "\nError: %ld inverted query regions (start > stop) exceed what the MI355X path sets aside for pairwise matching!\n", (long)info.n_unplaced); exit(1); }
     Mark("coverage on the host");

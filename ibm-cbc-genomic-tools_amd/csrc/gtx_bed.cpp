@@ -542,6 +542,7 @@ struct alignas(128) Piece {          // one thread's share of a block
   int32_t *dtri = nullptr, *dw = nullptr; size_t nd = 0;
   PackError err;
   int64_t label_sum = 0;
+  std::vector<long> cur_blocks;      // explode_blocks: the intervals (start, stop pairs) of the region being handled, empty = its one interval
   // order-check context of the regions in this piece
   bool any = false;
   const char *prev_chrom = nullptr; size_t prev_chrom_len = 0; int prev_id = -2;   // the line before (text still in the block) and its class lookup
@@ -631,7 +632,13 @@ static inline bool HandleRecord(Piece *p, const PackOptions &o, const BedFields 
     if (p->err.set) return false;
     const bool minus = o.strand_aware && f.strand == '-';
     const int32_t cls = (int32_t)(id + (minus ? n_chrom : 0));
-    if (p->dtri) {
+    if (!p->cur_blocks.empty()) {                                        // (never in direct mode: PackPieces)
+      std::vector<int32_t> &dst = minus ? p->tri_minus : p->tri;
+      for (size_t b = 0; b + 1 < p->cur_blocks.size(); b += 2) {
+        dst.push_back(cls); dst.push_back((int32_t)p->cur_blocks[b]); dst.push_back((int32_t)p->cur_blocks[b + 1]);
+        if (weighted) (minus ? p->w_minus : p->w).push_back((int32_t)wv);
+      }
+    } else if (p->dtri) {
       int32_t *d = p->dtri + 3 * p->nd;
       d[0] = cls; d[1] = (int32_t)f.start; d[2] = (int32_t)f.stop;
       if (weighted) p->dw[p->nd] = (int32_t)wv;
@@ -692,17 +699,24 @@ void ParsePiece(Piece *p, const PackOptions &o)
       // a multi-interval region: under -gaps it is matched on its envelope [first interval's start, last interval's stop]
       // (genomic_intervals.cpp:5226, :5752, :5278); its intervals must be sorted and disjoint (:1153-1161, checked at :5709, :5880)
       const bool overlaps = o.mode == PACK_OVERLAPS_SORTED || o.mode == PACK_OVERLAPS_UNSORTED;
-      if (!overlaps || !o.match_gaps || f.n_blocks < 1) { SetErr(&p->err, line_no, "multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps)!"); break; }
+      if (!overlaps || !(o.match_gaps || o.explode_blocks) || f.n_blocks < 1) { SetErr(&p->err, line_no, "multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps, and coverage / density)!"); break; }
       std::vector<long> iv; BedBlocks(f, &iv);
       bool ok = true;
       for (size_t k = 2; k < iv.size(); k += 2) if (iv[k] < iv[k - 2] || iv[k] <= iv[k - 1]) ok = false;
       if (!ok) { SetErr(&p->err, line_no, "query regions should be compatible, sorted and non-overlapping!"); break; }
       f.start = iv.front(); f.stop = iv.back();
+      if (o.explode_blocks && iv.size() > 2) {
+        for (long x : iv) if (x >= INT_MAX - 1 || x <= INT_MIN + 1) { SetErr(&p->err, line_no, "coordinate does not fit the packed 32-bit representation of the MI355X path!"); break; }
+        if (p->err.set) break;
+        p->cur_blocks.swap(iv);
+      }
     }
     if (f.start >= INT_MAX - 1 || f.stop >= INT_MAX - 1 || f.start <= INT_MIN + 1 || f.stop <= INT_MIN + 1) {
       SetErr(&p->err, line_no, "coordinate does not fit the packed 32-bit representation of the MI355X path!"); break;
     }
-    if (!HandleRecord(p, o, f, chrom_len, label_value, line_no)) break;
+    const bool more = HandleRecord(p, o, f, chrom_len, label_value, line_no);
+    p->cur_blocks.clear();
+    if (!more) break;
   }
   if (p->prev_chrom) p->last_chrom = p->prev_chrom;            // (a copy: the seam check of the next block outlives this one's text)
   p->n_lines = line_no - (p->first_line - 1);
@@ -791,7 +805,7 @@ bool BedPacker::PackPieces(void *pieces_ptr, long first_line, PackedBatch *out, 
   const bool sorted_mode = opt_.mode == PACK_OVERLAPS_SORTED || opt_.mode == PACK_SCAN_SORTED;
   long ln = first_line;
   for (int t = 0; t < T; t++) { pieces[t].first_line = ln; ln += pieces[t].n_lines; }
-  const bool direct = !opt_.strand_aware;
+  const bool direct = !opt_.strand_aware && !opt_.explode_blocks;   // (one read per line is what the direct mode makes room for)
   const bool weighted = opt_.max_label_value > 1;
   const size_t base_tri = out->tri.size(), base_w = out->w.size();
   if (direct) {

@@ -139,7 +139,9 @@ struct PackOptions {
   long max_label_value = 1;          // > 1: emit weights = min(max, atol(label))
   bool collect_zero_length = false;  // keep (class, start, weight) of zero-length reads (sorted mode correction)
   bool match_gaps = false;           // overlaps: multi-interval (BED12) regions are matched on their envelope -- what -gaps means
-                                     // (genomic_intervals.cpp:5226, :5752); without it they are outside the path
+                                     // (genomic_intervals.cpp:5226, :5752); without it they are outside the path, unless ...
+  bool explode_blocks = false;       // ... coverage without -gaps: CalcOverlap is a sum over ALL interval pairs (:1196-1202, :5278), so
+                                     // every interval of a region goes out as a read of its own with the region's label value
   int threads = 0;                   // 0 = hardware concurrency
   IndexGuard *guard = nullptr;       // PACK_OVERLAPS_SORTED with an out-of-order index set (forces one thread)
 };

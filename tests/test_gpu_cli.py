@@ -558,6 +558,8 @@ def bed12(tmp_path_factory):
     bad = make_regions(rng, 50, 2_000_000, 400, bed12_frac=1.0)
     bad[20][10], bad[20][11] = "30,30,", "0,10,"                                   # blocks overlap: the region check fails
     bed6(d / "reads12_bad.bed", bad)
+    bed6(d / "exons6.bed", [r[:3] + ["e%d" % i] + r[4:] for i, r in enumerate(make_regions(rng, 3000, 2_000_000, 300, bed12_frac=0.0))])
+    bed6(d / "reads6.bed", make_regions(rng, 40000, 2_000_000, 200, bed12_frac=0.0))
     return d
 
 
@@ -585,9 +587,38 @@ def test_bed12_under_gaps_equals_oracle_cli(bed12, args):
         assert got[2].strip() == want[2].strip()
 
 
-def test_bed12_without_gaps_is_refused_loudly(bed12):
-    """Without -gaps an overlap of multi-interval regions needs an interval pair (genomic_intervals.cpp:1167-1172): not what the
-    device computes -- the tool says so instead of printing envelope counts."""
+# without -gaps: coverage / density are sums over ALL interval pairs of the two regions (CalcOverlap, genomic_intervals.cpp:1196-1202,
+# :5278), so every interval goes to the device as a region / read of its own and a region's value is the sum of its intervals'
+BED12_NOGAPS_RUNS = [
+    ["coverage", "-i", "refs12.bed", "reads12.bed"],
+    ["coverage", "refs12.bed", "reads12.bed"],
+    ["coverage", "-i", "refs12.bed", "reads12_shuffled.bed"],
+    ["coverage", "-S", "-i", "refs12.bed", "reads12.bed"],
+    ["coverage", "-S", "--max-label-value", "3", "refs12.bed", "reads12.bed"],
+    ["density", "-i", "refs12.bed", "reads12.bed"],
+    ["density", "-S", "refs12.bed", "reads12.bed"],
+    ["density", "-i", "exons6.bed", "reads12.bed"],                            # the shape of examples/example01.tcsh:15: spliced reads x exons
+    ["density", "-i", "refs12.bed", "reads6.bed"],
+    ["coverage", "-i", "refs12.bed", "reads12_bad.bed"],                       # a region whose blocks overlap: the reference's error
+    ["coverage", "-S", "-i", "refs12.bed", "reads12_bad.bed"],
+]
+
+
+@pytest.mark.parametrize("args", BED12_NOGAPS_RUNS, ids=[" ".join(a) for a in BED12_NOGAPS_RUNS])
+def test_bed12_coverage_without_gaps_equals_oracle_cli(bed12, args):
+    want = oracle(args, cwd=bed12)
+    got = product("overlaps", args, cwd=bed12)
+    assert got[0] == want[0], (got[2], want[2])
+    assert got[1] == want[1]
+    if want[0] != 0:
+        assert got[2].strip() == want[2].strip()
+    elif args[-1] == "reads12.bed" and args[-2] == "refs12.bed":
+        assert want[1] != oracle(args[:1] + ["-gaps"] + args[1:], cwd=bed12)[1]        # (the fixture tells the two rules apart)
+
+
+def test_bed12_count_without_gaps_is_refused_loudly(bed12):
+    """Without -gaps a COUNT over multi-interval regions needs "some interval pair overlaps" (genomic_intervals.cpp:1167-1172): no
+    sum of independent pieces gives that -- the tool says so instead of printing envelope counts."""
     for args in (["count", "-i", "refs12.bed", "reads12.bed"], ["count", "-S", "-i", "refs12.bed", "reads12.bed"]):
         rc, out, err = product("overlaps", args, cwd=bed12)
         assert rc == 1 and out == "" and "multi-interval" in err

@@ -86,6 +86,23 @@ def test_permutation_range_shards_add_up(pe):
     assert pe.count_ge("sum", Y, 5, 0, 0).sum() == 0
 
 
+def test_config5_table_10k_shuffles(pe):
+    """BASELINE config 5's permutation stage at its full size -- 20 k rows x 5 k categories (~1 M memberships), 10 k shuffles:
+    the shuffle ranges a multi-GPU run deals to its ranks add up to the whole (8 uneven shards), a 24-shuffle range and the observed
+    statistic against the CPU oracle bit for bit (the scalar restatement takes ~0.5 s per shuffle of this table), and every count
+    within the number of shuffles."""
+    t = perm.PermTable.synthetic(20000, 5000, 200, seed=1, values="gamma")
+    pe.set_table(t)
+    Y = pe.statistic("sum")
+    assert same_bits(Y, porc.statistic(t, "sum"))
+    whole = pe.count_ge("sum", Y, 2024, 0, 10000)
+    cuts = [0, 1250, 2500, 2563, 5000, 6250, 7500, 9999, 10000]
+    parts = sum(pe.count_ge("sum", Y, 2024, a, b - a).astype(np.int64) for a, b in zip(cuts[:-1], cuts[1:]))
+    np.testing.assert_array_equal(whole.astype(np.int64), parts)
+    assert whole.max() <= 10000 and whole.sum() > 0
+    np.testing.assert_array_equal(pe.count_ge("sum", Y, 2024, 5000, 24), porc.count_ge(t, "sum", Y, 2024, 5000, 24))
+
+
 def test_small_slab_budget_batches_give_the_same_counts(pe):
     t = perm.PermTable.synthetic(40000, 100, 60, seed=9, values="gamma", totals=True)
     pe.set_table(t)
