@@ -44,6 +44,14 @@ void GtxFinish(int code)
 {
   if (getenv("GTX_TIMING")) fprintf(stderr, "[gtx leaving at epoch ms %lld]\n", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count());
   fflush(stdout); fflush(stderr);
+  if (const char *x = getenv("GTX_EXIT_EXPERIMENT")) {             // (diagnostic: what makes the process go away in 2 ms instead of 150)
+    const int mode = atoi(x);
+    static std::vector<std::thread> th;
+    static volatile bool stop = false;
+    if (mode == 1 || mode == 2) { for (int i = 0; i < 8; i++) th.emplace_back([] { while (!stop) usleep(1000); }); usleep(3000); }
+    if (mode == 1) { stop = true; for (auto &t : th) t.join(); }
+    if (mode == 3) usleep(20000);
+  }
   const char *pre = getenv("LD_PRELOAD");
   if (getenv("GTX_FULL_EXIT") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("HSA_TOOLS_LIB") ||
       (pre && strstr(pre, "rocprof")))
@@ -514,6 +522,8 @@ const gtxhost::GtxView *GenomicRegionSet::DetachPacked(long int *current_record)
   return packed;
 }
 
+long int GenomicRegionSet::StreamBytesLeft() { return (load_in_memory || !src) ? -1 : src->regular_file_bytes(); }
+
 LineSource *GenomicRegionSet::DetachStream(std::string *current_line, long int *current_line_no)
 {
   if (load_in_memory) PrintError("[DetachStream] the set is loaded in memory!");
@@ -608,7 +618,11 @@ void StdoutIsOurs()
 
 void GtxWarmUp()
 {
-  if (!g_group_future.valid()) { atexit(JoinStartUp); g_group_future = std::async(std::launch::async, CreateGroup); }
+  if (!g_group_future.valid()) {
+    atexit(JoinStartUp);
+    // (GTX_SYNC_STARTUP=1, diagnostic: bring the device up on the calling thread instead of next to the parsing of the index set)
+    g_group_future = std::async(getenv("GTX_SYNC_STARTUP") ? std::launch::deferred : std::launch::async, CreateGroup);
+  }
 }
 
 static gtx_group *Devices()
@@ -635,14 +649,81 @@ static void CheckGrp(gtx_group *g, int rc)
 // page-locked memory to release at exit, and 100 M reads from text came out 10 % slower (0.95 -> 1.06 s on one box).
 static std::atomic<bool> g_drain_stop(false);                 // set by a sink that has seen enough (an error it will raise after DrainSet): no more batches
 
+// What DrainSet needs to have a streamed BED file tokenised on the device (gtx_count_add_text, include/gtx.h) instead of parsing it
+// here: add(text, bytes, lines, rules) -> ticket, and needs_host(ticket).  The device takes the plain case only; a block with
+// anything else in it comes back and is packed here, with the reference's reading of it and the reference's errors.
+struct TextSink {
+  std::function<bool()> usable;                                   // (asked behind prep(): one GPU)
+  std::function<int(const char *, size_t, int64_t, const gtx_text_rules &)> add;
+  std::function<bool(int)> needs_host;
+};
+
+static bool TextOnDevice(GenomicRegionSet *set, const PackOptions &opt, const TextSink *ts)
+{
+  static const char *e = getenv("GTX_TEXT_ON_DEVICE");        // 0: never; 1: whenever the input qualifies (tests); default: files of 32 MB or more
+  if (!ts || (e && atoi(e) == 0)) return false;
+  if (set->load_in_memory || set->format != "BED") return false;
+  if (opt.guard || opt.explode_blocks || opt.collect_zero_length) return false;
+  if (opt.mode != gtxhost::PACK_OVERLAPS_SORTED && opt.mode != gtxhost::PACK_OVERLAPS_UNSORTED) return false;
+  if (opt.strand_aware && !opt.sorted_by_strand) return false;   // (reads of both strands interleaved: the packer groups them by strand for the streaming kernel)
+  if (!g_pool.buf[0] || !g_pool.buf[1] || !ts->usable()) return false;
+  const long left = set->StreamBytesLeft();                      // -1: not a regular uncompressed file
+  return left >= ((e && atoi(e) == 1) ? 1 : (32l << 20));
+}
+
 template <class Prep, class Sink>
-static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sink)
+static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sink, const TextSink *text_sink = NULL)
 {
   g_drain_stop = false;
   const size_t batch_reads = kBatchReads;
   PackedBatch two[2]; PackError err;
-  auto pump = [&](BedPacker &packer) {
-    prep();
+  auto pump_text = [&](BedPacker &packer) {
+    // blocks of complete lines straight into the two page-locked buffers, tokenised and counted on the device; what is not plain is
+    // packed here.  Two blocks in flight: block i's verdict is collected before block i+2 is read over it.
+    std::vector<const char *> names((size_t)opt.chroms->size());
+    for (int i = 0; i < opt.chroms->size(); i++) names[i] = opt.chroms->name(i).c_str();
+    gtx_text_rules rules;
+    rules.chrom_names = names.empty() ? NULL : names.data(); rules.n_chrom = opt.chroms->size();
+    rules.strand_aware = opt.strand_aware; rules.sorted_rules = opt.mode == gtxhost::PACK_OVERLAPS_SORTED; rules.sorted_by_strand = opt.sorted_by_strand;
+    rules.max_label_value = opt.max_label_value;
+    g_pool.used[0] = g_pool.used[1] = true;                      // (the buffers hold text now: a batch packed here takes heap memory)
+    packer.UseTextBuffers((char *)g_pool.buf[0], (char *)g_pool.buf[1], kPoolBytes);
+    PackedBatch batch;
+    if (!packer.PackPrimedText(&batch, &err)) DiePack(err);
+    if (!batch.tri.empty()) sink(batch);
+    BedPacker::TextBlock blk[2]; int ticket[2] = {-1, -1}; bool host_only = false;
+    auto settle = [&](int k) {                                   // the verdict on the block in blk[k]
+      if (ticket[k] < 0) return;
+      const bool redo = text_sink->needs_host(ticket[k]);
+      ticket[k] = -1;
+      if (!redo) return;
+      batch.tri.clear(); batch.w.clear(); batch.zero_len.clear(); batch.n_lines = 0; batch.label_sum = 0;
+      const bool ok = packer.PackTextBlock(blk[k], &batch, &err);
+      if (err.set) DiePack(err);
+      (void)ok;
+      if (!batch.tri.empty()) sink(batch);
+    };
+    for (int cur = 0;; cur ^= 1) {
+      settle(cur);                                               // (its buffer is about to be read over)
+      if (g_drain_stop) break;
+      if (!packer.NextTextBlock(&blk[cur])) break;
+      BedPacker::TextBlock &b = blk[cur];
+      if (!b.seam_ok) host_only = true;                          // a last line that could not be read: no seam key for the device
+      if (host_only) {
+        batch.tri.clear(); batch.w.clear(); batch.zero_len.clear(); batch.n_lines = 0; batch.label_sum = 0;
+        packer.PackTextBlock(b, &batch, &err);
+        if (err.set) { settle(cur ^ 1); DiePack(err); }
+        if (!batch.tri.empty()) sink(batch);
+        continue;
+      }
+      rules.have_prev = b.have_prev; rules.prev_chrom = b.prev_chrom.c_str(); rules.prev_strand = b.prev_strand; rules.prev_start = b.prev_start;
+      ticket[cur] = text_sink->add(b.text, b.bytes, b.n_lines, rules);
+    }
+    settle(0); settle(1);
+    g_pool.used[0] = g_pool.used[1] = false;
+  };
+  auto pump = [&](BedPacker &packer, bool prepared = false) {
+    if (!prepared) prep();
     if (g_pool_future.valid()) g_pool_future.get();             // the page-locked batch buffers are there
     for (int cur = 0;;) {
       PackedBatch &batch = two[cur];
@@ -667,10 +748,17 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
   }
   if (!set->load_in_memory) {
     std::string first; long int first_no = 0;
-    LineSource *src = set->DetachStream(&first, &first_no);
+    LineSource *src = NULL;
+    bool on_device = false;
+    if (text_sink) {                                             // the decision needs the page-locked buffers and the device: made behind prep()
+      prep();
+      if (g_pool_future.valid()) g_pool_future.get();
+      on_device = TextOnDevice(set, opt, text_sink);
+    }
+    src = set->DetachStream(&first, &first_no);
     BedPacker packer(src, opt);
     if (first_no > 0) packer.Prime(first, first_no);
-    pump(packer);
+    if (on_device) pump_text(packer); else pump(packer, text_sink != NULL);
     return;
   }
   // in-memory set: re-emit its regions as lines through the same packer rules
@@ -712,6 +800,38 @@ static bool LooksSorted(const gtxhost::RawVec &tri)
   }
   return true;
 }
+
+// the same hint from the text of a block: pairs of adjacent lines at ~4096 places, (chromosome token, column 2) compared
+static bool TextLooksSorted(const char *text, size_t bytes)
+{
+  if (bytes < 64) return true;
+  const size_t stride = bytes > (4096u * 64u) ? bytes / 4096 : 64;
+  int descents = 0;
+  auto key = [&](const char *l, const char *e, const char **tok, size_t *len, long *start) {
+    const char *t = (const char *)memchr(l, '\t', (size_t)(e - l));
+    if (!t) return false;
+    *tok = l; *len = (size_t)(t - l); *start = atol(t + 1);
+    return true;
+  };
+  for (size_t at = 0; at + 2 < bytes; at += stride) {
+    const char *a = (const char *)memchr(text + at, '\n', bytes - at);
+    if (!a || a + 1 >= text + bytes) break;
+    a++;
+    const char *ae = (const char *)memchr(a, '\n', (size_t)(text + bytes - a));
+    if (!ae || ae + 1 >= text + bytes) break;
+    const char *b = ae + 1, *be = (const char *)memchr(b, '\n', (size_t)(text + bytes - b));
+    if (!be) break;
+    const char *ta, *tb; size_t la, lb; long sa, sb;
+    if (!key(a, ae, &ta, &la, &sa) || !key(b, be, &tb, &lb, &sb)) continue;
+    const int d = memcmp(ta, tb, std::min(la, lb));
+    const bool before = d ? d > 0 : (la != lb ? la > lb : sb < sa);
+    if (before && ++descents > 2) return false;
+  }
+  return true;
+}
+
+// an error of a member context, reported through the group's channel (CheckGrp prints gtx_group_last_error)
+static void gtxi_note(gtx_group *, gtx_ctx *c) { fflush(stdout); fprintf(stderr, "\nError: [gtx] %s\n", gtx_last_error(c)); exit(1); }
 
 static bool LooksSortedVec(const std::vector<int32_t> &tri)
 {
@@ -861,12 +981,21 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   std::vector<int32_t> zero_len;
   unsigned long int *hits = new unsigned long int[M > 0 ? M : 1];
   gtx_count_info info;
+  // the query file's text tokenised on the device where that applies (one GPU, a plain BED file: TextOnDevice)
+  TextSink text_sink;
+  text_sink.usable = [&] { return gtx_group_size(grp) == 1; };
+  text_sink.needs_host = [&](int ticket) { int redo = 0; gtx_ctx *c = gtx_group_ctx(grp, 0); if (gtx_text_result(c, ticket, &redo) != GTX_OK) { gtxi_note(grp, c); CheckGrp(grp, GTX_E_HIP); } return redo != 0; };
   if (coverage) {
     // zero-length reads (sorted rules let them through) and zero-length regions contribute 0: the device leaves them out
+    const uint32_t cflags = sorted ? (GTX_ZERO_LENGTH_OK | (match_gaps ? GTX_GAPS_FORMULA : 0u)) : 0u;
+    text_sink.add = [&](const char *text, size_t bytes, int64_t lines, const gtx_text_rules &rules) {
+      int ticket = -1; gtx_ctx *c = gtx_group_ctx(grp, 0);
+      if (gtx_coverage_add_text(c, text, bytes, lines, &rules, cflags | (sorted ? GTX_READS_SORTED : 0u), &ticket) != GTX_OK) { gtxi_note(grp, c); CheckGrp(grp, GTX_E_HIP); }
+      return ticket;
+    };
     DrainSet(QuerySet, opt, [&] { device_side(true); }, [&](const PackedBatch &b) {
-      CheckGrp(grp, gtx_group_coverage_add(grp, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3),
-                                           sorted ? (GTX_ZERO_LENGTH_OK | (match_gaps ? GTX_GAPS_FORMULA : 0u)) : 0u));
-    });
+      CheckGrp(grp, gtx_group_coverage_add(grp, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), cflags));
+    }, &text_sink);
     Mark("queries packed and enqueued");
     if (explode) {
       std::vector<uint64_t> part((size_t)std::max<long int>(MD, 1));
@@ -879,11 +1008,18 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
     return hits;
   }
   const uint32_t mode_flags = sorted ? GTX_ZERO_LENGTH_OK : 0;
+  text_sink.add = [&](const char *text, size_t bytes, int64_t lines, const gtx_text_rules &rules) {
+    int ticket = -1; gtx_ctx *c = gtx_group_ctx(grp, 0);
+    // (the sorted merge's input is in order, or the block comes back; the bin index takes any order: a look at the text decides the kernel)
+    const uint32_t flags = mode_flags | ((sorted || TextLooksSorted(text, bytes)) ? GTX_READS_SORTED : 0);
+    if (gtx_count_add_text(c, text, bytes, lines, &rules, flags, &ticket) != GTX_OK) { gtxi_note(grp, c); CheckGrp(grp, GTX_E_HIP); }
+    return ticket;
+  };
   DrainSet(QuerySet, opt, [&] { device_side(false); }, [&](const PackedBatch &b) {
     uint32_t flags = mode_flags | (LooksSorted(b.tri) ? GTX_READS_SORTED : 0);
     CheckGrp(grp, gtx_group_count_add(grp, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), flags));
     zero_len.insert(zero_len.end(), b.zero_len.begin(), b.zero_len.end());
-  });
+  }, &text_sink);
   Mark("queries packed and enqueued");
   CheckGrp(grp, gtx_group_count_end(grp, (uint64_t *)hits, &info));
   if (getenv("GTX_TIMING") && gtx_group_size(grp) > 1) {

@@ -128,6 +128,7 @@ class GenomicRegionSet
   FILE *file_ptr;                                                  // the FILE* constructor's stream (NULL otherwise)
   unsigned long int buffer_size;
   bool verbose, load_in_memory, from_stdin, hide_header;
+  long int StreamBytesLeft();                     // size of a streamed regular text file, -1 otherwise (MI355X build: the device-side tokenizer's test)
   long int n_regions;
   std::string format;                                              // "BED", "EMPTY" or "GTX" (a packed region file, gtx_bed.h)
   GenomicRegion **R;

@@ -165,6 +165,36 @@ char *LineSource::Next()
   }
 }
 
+// a regular text file only (fd_ >= 0): up to `cap` bytes of complete lines straight into dst (page-locked memory of the caller's).
+// Returns 0 at the end of the input and (size_t)-1 when not even one line fits (or the source is not a regular file).
+size_t LineSource::ReadTextInto(char *dst, size_t cap, long *first_line)
+{
+  if (fd_ < 0) return (size_t)-1;
+  *first_line = line_no_ + 1;
+  if (!bulk_started_) {
+    bulk_started_ = true;
+    long at = ftell(fp_);
+    file_pos_ = at < 0 ? file_len_ : (size_t)at - (end_ - pos_);
+    pos_ = end_ = 0;
+  }
+  const size_t left = file_len_ - file_pos_;
+  if (left == 0) return 0;
+  const size_t want = std::min(left, cap);
+  static const int maxReaders = getenv("GTX_READ_THREADS") && atoi(getenv("GTX_READ_THREADS")) > 0 ? atoi(getenv("GTX_READ_THREADS")) : std::max(2, std::min(8, EffectiveCpus() / 2));
+  const int K = (int)std::min<size_t>((size_t)maxReaders, want / (4u << 20) + 1);
+  std::vector<std::thread> th;
+  auto rd = [&](int k) {
+    size_t b0 = want * (size_t)k / K, b1 = want * (size_t)(k + 1) / K;
+    while (b0 < b1) { ssize_t g = pread(fd_, dst + b0, b1 - b0, (off_t)(file_pos_ + b0)); if (g <= 0) break; b0 += (size_t)g; }
+  };
+  for (int k = 1; k < K; k++) th.emplace_back(rd, k);
+  rd(0);
+  for (auto &x : th) x.join();
+  char *nl = (char *)memrchr(dst, '\n', want);
+  if (nl) { const size_t n = (size_t)(nl - dst) + 1; file_pos_ += n; return n; }
+  return want == left ? 0 : (size_t)-1;                  // only an unterminated tail is left | a line longer than the buffer
+}
+
 size_t LineSource::NextBlockView(std::vector<char> &block, char **view, size_t target, long *first_line)
 {
   if (fd_ < 0) { size_t n = NextBlock(block, target, first_line); *view = block.data(); return n; }
@@ -921,6 +951,62 @@ bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
     if (!ok) { ahead_.wait(); return false; }
   }
   return true;
+}
+
+bool BedPacker::PackPrimedText(PackedBatch *out, PackError *err)
+{
+  out->tri.clear(); out->w.clear(); out->zero_len.clear(); out->n_lines = 0; out->label_sum = 0;
+  if (!primed_set_) return true;
+  primed_set_ = false;
+  const bool ok = PackBlock(primed_.data(), primed_.size(), primed_first_line_, out, err);
+  seam_have_ = have_prev_; seam_chrom_ = prev_chrom_; seam_strand_ = prev_strand_; seam_start_ = prev_start_;
+  return ok;
+}
+
+bool BedPacker::NextTextBlock(TextBlock *b)
+{
+  if (!src_ || exhausted_) return false;
+  const size_t block_bytes = (getenv("GTX_PACK_BLOCK_MB") && atoi(getenv("GTX_PACK_BLOCK_MB")) > 0 ? (size_t)atoi(getenv("GTX_PACK_BLOCK_MB")) : 64u) << 20;
+  auto read_block = [this, block_bytes](int buf) { Ahead a; long fl = 0; a.buf = buf; a.got = src_->NextBlockView(blocks_[buf], &a.view, block_bytes, &fl); return a; };
+  // (no read-ahead into the other buffer here: the caller may still need the block before this one -- it reads while the device works)
+  Ahead cur;
+  if (text_buf_[0]) {                                               // the caller's page-locked buffers: read where the DMA engine reads
+    long fl = 0;
+    cur.buf = next_buf_; cur.view = text_buf_[next_buf_];
+    cur.got = src_->ReadTextInto(cur.view, std::min(text_cap_, block_bytes), &fl);
+    if (cur.got == (size_t)-1) { text_buf_[0] = text_buf_[1] = nullptr; cur = read_block(next_buf_); }   // (a line longer than the buffer, stdin, .gz)
+  } else cur = read_block(next_buf_);
+  next_buf_ ^= 1;
+  if (cur.got == 0) { exhausted_ = true; return false; }
+  b->text = cur.view; b->bytes = cur.got; b->first_line = src_->line_no() + 1;
+  {
+    const int T = (int)std::min<size_t>((size_t)opt_.threads, cur.got / (1u << 20) + 1);
+    std::vector<long> part(T, 0);
+    char *v = cur.view; const size_t got = cur.got;
+    Pool::Run(T, [&](int t) { part[t] = CountLines(v + got * (size_t)t / T, v + got * (size_t)(t + 1) / T); });
+    long n = 0; for (long x : part) n += x;
+    b->n_lines = n;
+  }
+  src_->AdvanceLines((long)b->n_lines);
+  b->have_prev = seam_have_; b->prev_chrom = seam_chrom_; b->prev_strand = seam_strand_; b->prev_start = seam_start_; b->seam_ok = seam_ok_;
+  // the order key of the block's last line (a copy of it is parsed: the block itself stays as it is)
+  if (b->bytes >= 2) {
+    const char *e = b->text + b->bytes - 1;                        // the final newline
+    const char *s = e;
+    while (s > b->text && s[-1] != '\n') s--;
+    std::string line(s, e);
+    BedFields f; char *bad = nullptr;
+    if (!line.empty() && line.find('\0') == std::string::npos && ParseBedLine(&line[0], &f, &bad) == BED_OK && f.n_tokens != 12) {
+      seam_have_ = true; seam_chrom_ = f.chrom; seam_strand_ = f.strand; seam_start_ = f.start;
+    } else seam_ok_ = false;
+  }
+  return true;
+}
+
+bool BedPacker::PackTextBlock(const TextBlock &b, PackedBatch *out, PackError *err)
+{
+  have_prev_ = b.have_prev; prev_chrom_ = b.prev_chrom; prev_strand_ = b.prev_strand; prev_start_ = b.prev_start;
+  return PackBlock(b.text, b.bytes, b.first_line, out, err);
 }
 
 }  // namespace gtxhost

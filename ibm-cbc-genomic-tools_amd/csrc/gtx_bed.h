@@ -42,7 +42,9 @@ class LineSource {
   // Same, but a regular text file is read with several pread() calls in parallel straight into
   // `block` (no intermediate buffer); *view = block.data().  .gz and stdin go through NextBlock.
   size_t NextBlockView(std::vector<char> &block, char **view, size_t target_bytes, long *first_line);
+  size_t ReadTextInto(char *dst, size_t cap, long *first_line);     // regular text files: complete lines straight into the caller's memory
   void AdvanceLines(long n) { line_no_ += n; }
+  long regular_file_bytes() const { return fd_ >= 0 ? (long)file_len_ : -1; }   // -1: stdin, .gz, a FILE* of the caller's
 
  private:
   LineSource() {}
@@ -205,7 +207,20 @@ class BedPacker {
   void Prime(const std::string &line, long line_no);
   void PrimeBlock(const std::string &lines, long first_line);
   bool NextBatch(PackedBatch *out, size_t target_reads, PackError *err);
+  // For a caller that has the text tokenised on the device (gtx_count_add_text) and keeps this packer for what is not plain:
+  // the next block of complete lines as it is (false at the end of the input; its lines are counted and the source's line number
+  // moves on).  have_prev / prev_*: the order key of the line before the block, for the sorted merge's order check at the seam;
+  // seam_ok = false: the block's own last line could not be read as a plain BED line (the blocks after it are the host's).
+  // The text stays valid until the call after next.  PackPrimedText: what Prime() / PrimeBlock() left, packed here.
+  struct TextBlock { char *text = nullptr; size_t bytes = 0; long first_line = 0; int64_t n_lines = 0;
+                     bool have_prev = false; std::string prev_chrom; char prev_strand = '+'; long prev_start = 0; bool seam_ok = true; };
+  bool PackPrimedText(PackedBatch *out, PackError *err);
+  void UseTextBuffers(char *b0, char *b1, size_t cap) { text_buf_[0] = b0; text_buf_[1] = b1; text_cap_ = cap; }   // NextTextBlock reads into these in turn
+  bool NextTextBlock(TextBlock *b);
+  bool PackTextBlock(const TextBlock &b, PackedBatch *out, PackError *err);   // the host's reading of that block (appended to *out)
  private:
+  char *text_buf_[2] = {nullptr, nullptr}; size_t text_cap_ = 0;
+  bool seam_have_ = false, seam_ok_ = true; std::string seam_chrom_; char seam_strand_ = '+'; long seam_start_ = 0;   // NextTextBlock's view of the line before
   bool PackBlock(char *block, size_t got, long first_line, PackedBatch *out, PackError *err);
   bool PackPieces(void *pieces, long first_line, PackedBatch *out, PackError *err);
   const GtxView *gtx_ = nullptr; uint64_t gtx_pos_ = 0;

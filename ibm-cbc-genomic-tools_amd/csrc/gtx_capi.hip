@@ -15,6 +15,7 @@
 #include <vector>
 #include "gtx.h"
 #include "gtx_kernels.h"
+#include "gtx_text.h"
 
 typedef unsigned long long u64;
 
@@ -81,6 +82,16 @@ struct gtx_ctx {
   int copyThreads = 8;                  // host threads that move a pageable batch into the pinned slot (GTX_COPY_THREADS)
   u64 *d_out = nullptr; size_t capOut = 0;
   char *d_scratch = nullptr; size_t capScratch = 0;   // gtxi_scratch
+  // region text tokenised on the device (gtx_count_add_text): two blocks in flight
+  struct TextSlot {
+    char *d_text = nullptr; size_t capText = 0; unsigned *d_seg = nullptr; size_t capSeg = 0;
+    unsigned *d_nl = nullptr; int *d_tri = nullptr, *d_w = nullptr; size_t capLines = 0;
+    int *d_flag = nullptr, *h_flag = nullptr; char *h_pin = nullptr; size_t capPin = 0; char *h_seam = nullptr;
+    hipEvent_t evParsed = nullptr, evConsumed = nullptr, evCopied = nullptr; bool busy = false;
+  } text[2];
+  long long textSeq = 0;
+  int *d_textTable = nullptr; char *d_textNames = nullptr; size_t capTextNames = 0; unsigned textMask = 0, textBlobLen = 0;
+  std::string textBlob;                               // the chromosome names the device tables were built from
 
   // scan state
   u64 *d_micro = nullptr; size_t capMicro = 0;
@@ -216,6 +227,14 @@ void gtx_destroy(gtx_ctx *c)
     if (c->evRes[k]) (void)hipEventDestroy(c->evRes[k]);
   }
   if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
+  for (auto &t : c->text) {
+    dfree(t.d_text); dfree(t.d_seg); dfree(t.d_nl); dfree(t.d_tri); dfree(t.d_w); dfree(t.d_flag);
+    if (t.h_flag) (void)hipHostFree(t.h_flag);
+    if (t.h_pin) (void)hipHostFree(t.h_pin);
+    if (t.h_seam) (void)hipHostFree(t.h_seam);
+    for (hipEvent_t e : {t.evParsed, t.evConsumed, t.evCopied}) if (e) (void)hipEventDestroy(e);
+  }
+  dfree(c->d_textTable); dfree(c->d_textNames);
   dfree(c->d_out); dfree(c->d_scratch); dfree(c->d_micro); dfree(c->d_scanTab); dfree(c->d_scanBounds); dfree(c->d_scanFlag); dfree(c->d_resReads); dfree(c->d_resWeights);
   for (auto &p : c->d_cov) dfree(p);
   dfree(c->d_sortedT); dfree(c->d_segT); dfree(c->d_topT); dfree(c->d_posTE); dfree(c->d_posTS); dfree(c->d_classBaseT);
@@ -1448,6 +1467,119 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
   HIPCHK(c, hipStreamSynchronize(c->copyStream));
   return GTX_OK;
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// region text tokenised on the device (gtx_text.hip)
+// ---------------------------------------------------------------------------------------------
+static int add_text(gtx_ctx *c, bool coverage, const char *text, size_t bytes, int64_t nLines, const gtx_text_rules *r, uint32_t flags, int *ticket)
+{
+  const char *who = coverage ? "gtx_coverage_add_text" : "gtx_count_add_text";
+  if (coverage ? !c->covOpen : !c->streamOpen) return fail(c, GTX_E_STATE, "gtx_*_add_text: no open count / coverage call");
+  if (!text || !r || !ticket || nLines < 0 || bytes >= (1ull << 32) - 4096 || nLines >= (1ll << 31) || r->n_chrom < 0 || (r->n_chrom > 0 && !r->chrom_names))
+    { c->err = std::string(who) + ": bad argument"; return GTX_E_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int slot = (int)(c->textSeq & 1);
+  gtx_ctx::TextSlot &t = c->text[slot];
+  *ticket = slot;
+  if (!t.evParsed) {
+    HIPCHK(c, hipEventCreateWithFlags(&t.evParsed, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&t.evConsumed, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&t.evCopied, hipEventDisableTiming));
+    HIPCHK(c, hipMalloc(&t.d_flag, sizeof(int))); HIPCHK(c, hipHostMalloc((void **)&t.h_flag, sizeof(int))); HIPCHK(c, hipHostMalloc((void **)&t.h_seam, 4096));
+  }
+  if (t.busy) { HIPCHK(c, hipEventSynchronize(t.evConsumed)); t.busy = false; }          // the block before last has been counted: its buffers are free
+  c->textSeq++;
+  if (nLines == 0 || bytes == 0) { *t.h_flag = 0; HIPCHK(c, hipEventRecord(t.evParsed, c->stream)); return GTX_OK; }
+  const size_t nSeg = (bytes + 1023) / 1024;
+  if (bytes + 64 > t.capText) { dfree(t.d_text); t.capText = 0; HIPCHK(c, hipMalloc(&t.d_text, bytes + (bytes >> 3) + 4096)); t.capText = bytes + (bytes >> 3) + 4096 - 64; }
+  if (nSeg + 2 > t.capSeg) { dfree(t.d_seg); t.capSeg = 0; HIPCHK(c, hipMalloc(&t.d_seg, sizeof(unsigned) * (nSeg + (nSeg >> 3) + 16))); t.capSeg = nSeg + (nSeg >> 3) + 14; }
+  if ((size_t)nLines > t.capLines) {
+    dfree(t.d_nl); dfree(t.d_tri); dfree(t.d_w); t.capLines = 0;
+    const size_t cap = (size_t)nLines + ((size_t)nLines >> 3) + 1024;
+    HIPCHK(c, hipMalloc(&t.d_nl, sizeof(unsigned) * cap)); HIPCHK(c, hipMalloc(&t.d_tri, sizeof(int) * 3 * cap)); HIPCHK(c, hipMalloc(&t.d_w, sizeof(int) * cap));
+    t.capLines = cap;
+  }
+  // the names' tables: per set of names (rebuilt when they change)
+  {
+    std::string blob; std::vector<int32_t> table; unsigned mask = 0;
+    size_t total = 0; for (int i = 0; i < r->n_chrom; i++) total += strlen(r->chrom_names[i]) + 1;
+    std::string key; key.reserve(total);
+    for (int i = 0; i < r->n_chrom; i++) { key += r->chrom_names[i]; key += '\n'; }
+    if (key != c->textBlob || !c->d_textTable) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      gtxtext::build_tables(*r, &table, &mask, &blob);
+      dfree(c->d_textTable); dfree(c->d_textNames);
+      HIPCHK(c, hipMalloc(&c->d_textTable, sizeof(int32_t) * table.size()));
+      HIPCHK(c, hipMalloc(&c->d_textNames, blob.size() + 4096 * 2 + 16));
+      HIPCHK(c, hipMemcpy(c->d_textTable, table.data(), sizeof(int32_t) * table.size(), hipMemcpyHostToDevice));
+      if (!blob.empty()) HIPCHK(c, hipMemcpy(c->d_textNames, blob.data(), blob.size(), hipMemcpyHostToDevice));
+      c->textMask = mask; c->textBlobLen = (unsigned)blob.size(); c->textBlob = key;
+    }
+  }
+  gtxtext::TextTables tabs; tabs.table = c->d_textTable; tabs.tableMask = c->textMask; tabs.names = c->d_textNames; tabs.prevOff = 0; tabs.prevLen = 0;
+  if (r->have_prev && r->prev_chrom) {
+    const size_t len = strlen(r->prev_chrom);
+    if (len > 0 && len < 4096) {                                       // the seam's name behind the names, one place per slot
+      memcpy(t.h_seam, r->prev_chrom, len);
+      tabs.prevOff = c->textBlobLen + (unsigned)slot * 4096; tabs.prevLen = (unsigned)len;
+      HIPCHK(c, hipMemcpyAsync(c->d_textNames + tabs.prevOff, t.h_seam, len, hipMemcpyHostToDevice, c->stream));
+    }
+  }
+  // the text: page-locked memory is read where it is, anything else goes through a page-locked slot of the context
+  const char *src = text;
+  if (!is_pinned(text)) {
+    if (bytes > t.capPin) { if (t.h_pin) (void)hipHostFree(t.h_pin); t.h_pin = nullptr; t.capPin = 0; HIPCHK(c, hipHostMalloc((void **)&t.h_pin, bytes + (bytes >> 3))); t.capPin = bytes + (bytes >> 3); }
+    parallel_copy(t.h_pin, text, bytes, c->copyThreads);
+    src = t.h_pin;
+  }
+  HIPCHK(c, hipMemcpyAsync(t.d_text, src, bytes, hipMemcpyHostToDevice, c->copyStream));
+  HIPCHK(c, hipEventRecord(t.evCopied, c->copyStream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, t.evCopied, 0));
+  HIPCHK(c, hipMemsetAsync(t.d_flag, 0, sizeof(int), c->stream));
+  gtxtext::TextDevice d; d.text = t.d_text; d.segCount = t.d_seg; d.nl = t.d_nl; d.tri = t.d_tri; d.w = t.d_w; d.flag = t.d_flag;
+  HIPCHK(c, gtxtext::launch_tokenize(d, tabs, *r, bytes, (unsigned)nLines, c->stream));
+  HIPCHK(c, hipMemcpyAsync(t.h_flag, t.d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(t.evParsed, c->stream));
+  // ... and counted where the triples are
+  const int *dW = r->max_label_value > 1 ? t.d_w : nullptr;
+  const int64_t seen = c->streamSeen;
+  int rc = GTX_OK;
+  if (coverage) {
+    if (flags & GTX_GAPS_FORMULA) { rc = merge_prepare(c, flags, 2); if (rc) return rc; }
+    rc = cover_launch(c, t.d_tri, dW, nLines, seen, flags, (flags & GTX_READS_UNSORTED) != 0 || !(flags & GTX_READS_SORTED)); if (rc) return rc;
+  } else {
+    rc = merge_prepare(c, flags, 0); if (rc) return rc;
+    const bool streaming = (flags & (GTX_READS_SORTED | GTX_CHECK_SORTED)) != 0;
+    if (!streaming) c->tileSumsValid = false;
+    if (streaming) HIPCHK(c, gtx::launch_count(t.d_tri, dW, nLines, count_args(c, flags & ~GTX_CHECK_SORTED, nLines, seen), true, c->stream));
+    else { rc = launch_unsorted(c, t.d_tri, dW, nLines, count_args(c, flags, nLines, seen)); if (rc) return rc; }
+  }
+  rc = merge_batch(c, t.d_tri, dW, nLines); if (rc) return rc;
+  HIPCHK(c, hipEventRecord(t.evConsumed, c->stream));
+  t.busy = true;
+  c->streamSeen += nLines;
+  return GTX_OK;
+}
+
+extern "C" {
+int gtx_count_add_text(gtx_ctx *c, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket)
+{ return c ? add_text(c, false, text, bytes, n_lines, rules, flags, ticket) : GTX_E_ARG; }
+int gtx_coverage_add_text(gtx_ctx *c, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket)
+{ return c ? add_text(c, true, text, bytes, n_lines, rules, flags, ticket) : GTX_E_ARG; }
+int gtx_text_result(gtx_ctx *c, int ticket, int *needs_host)
+{
+  if (!c || !needs_host || (ticket & ~1)) return c ? fail(c, GTX_E_ARG, "gtx_text_result: bad argument") : GTX_E_ARG;
+  gtx_ctx::TextSlot &t = c->text[ticket];
+  if (!t.evParsed) return fail(c, GTX_E_STATE, "gtx_text_result: no such block");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(t.evParsed));
+  *needs_host = *t.h_flag;
+  return GTX_OK;
+}
+}
+
+extern "C" {
 
 // A group member's share: the classes `owned` (flags per class).  tiles = the 1024-slot histogram tiles that hold a slot of an
 // owned class or the slot just below its first (class c has slots seg[c]+c-1 .. seg[c+1]+c: the gather reads the prefix at the

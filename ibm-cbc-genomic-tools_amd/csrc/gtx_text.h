@@ -1,0 +1,24 @@
+// gtx_text.h -- launch interface of the device-side BED tokenizer (gtx_text.hip), used by gtx_capi.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "gtx.h"
+
+namespace gtxtext {
+
+struct TextDevice {               // device buffers of one block in flight
+  const char *text;               // the block's bytes
+  unsigned *segCount;             // [segments + 1] newlines per 1 KB segment, then their exclusive prefix
+  unsigned *nl;                   // [n_lines] byte offset of every newline
+  int *tri; int *w;               // [n_lines] packed triples / weights
+  int *flag;                      // != 0: the block is not plain (nothing of it is counted)
+};
+struct TextTables {               // per reference set: hash table of the chromosome names, the names, the seam's name behind them
+  const void *table; unsigned tableMask; const char *names; unsigned prevOff, prevLen;
+};
+hipError_t launch_tokenize(const TextDevice &d, const TextTables &t, const gtx_text_rules &r, size_t bytes, unsigned nLines, hipStream_t st);
+void build_tables(const gtx_text_rules &r, std::vector<int32_t> *table, unsigned *mask, std::string *blob);
+
+}  // namespace gtxtext

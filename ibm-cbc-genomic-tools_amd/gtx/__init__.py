@@ -99,6 +99,9 @@ ABI = {
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32,
                                       ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_group_member_reads": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_count_add_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "gtx_coverage_add_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "gtx_text_result": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "gtx_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gtx_profile_last": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_profile_count": (ctypes.c_int, [ctypes.c_void_p]),

@@ -300,6 +300,33 @@ int gtx_group_scan(gtx_group *g, const int32_t *read_triples, const int32_t *wei
 /* reads each member received in the last (or open) group call: the load balance actually achieved */
 int gtx_group_member_reads(const gtx_group *g, int64_t *reads_out /* gtx_group_size */);
 
+/* ---- region text tokenised on the device ---------------------------------------------------
+ * Ingest (GenomicRegionBED::Read genomic_intervals.cpp:2157-2182, tokenizer core.cpp:577-625, FileBufferText::Next
+ * core.cpp:241-259) for the query stream of the two reductions: a block of COMPLETE lines of a BED file ('\n' after every line,
+ * n_lines of them) is copied to the device as text and cut into packed triples there, then counted like a gtx_count_add /
+ * gtx_coverage_add batch of an open call.  The device recognises only the plain case -- tab-separated, decimal columns 2 and 3,
+ * strand column one of + - . 1 -1, not 12 columns, in the order the sorted merge requires, reads the mode accepts; the reference's
+ * reading of everything else (blanks as separators, signs, '\r', BED12, its error messages with their line numbers) stays with
+ * the host-side packer: a block with ANY other line is not counted at all and gtx_text_result says so -- the caller packs that
+ * block itself and adds it with gtx_count_add.  chrom_names: the chromosome of class c (classes beyond n_chrom are the '-' strand
+ * when strand_aware); a line of another chromosome is dropped, as the reference's index lookup does (:5719-5720).
+ * sorted_rules: the sorted merge's rules (order check against the line before -- prev_* describe the line before the block --, no
+ * validation of the interval), else the bin index's (stop <= 0 or start > stop is the reference's error: not plain).
+ * max_label_value > 1: weights = min(max, atol(column 4)) (genomic_intervals.cpp:1081-1085). */
+typedef struct gtx_text_rules {
+  const char *const *chrom_names; int32_t n_chrom;
+  int32_t strand_aware, sorted_rules, sorted_by_strand;
+  int64_t max_label_value;
+  int32_t have_prev; const char *prev_chrom; int32_t prev_strand /* '+' | '-' */; int64_t prev_start;
+} gtx_text_rules;
+/* text: host memory (page-locked memory is read by the DMA engine directly and must stay untouched until gtx_text_result of the
+ * ticket has returned).  flags as gtx_count_add / gtx_coverage_add.  Up to two blocks are in flight: the call waits for the block
+ * before last. */
+int gtx_count_add_text(gtx_ctx *ctx, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket);
+int gtx_coverage_add_text(gtx_ctx *ctx, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket);
+/* waits for the tokenizer of that block; *needs_host != 0: nothing of the block was counted, the caller packs and adds it */
+int gtx_text_result(gtx_ctx *ctx, int ticket, int *needs_host);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 
 /* on = 1: every *_device call brackets its dominant kernel and the whole call with HIP events on the
