@@ -663,9 +663,8 @@ static bool TextOnDevice(GenomicRegionSet *set, const PackOptions &opt, const Te
   static const char *e = getenv("GTX_TEXT_ON_DEVICE");        // 0: never; 1: whenever the input qualifies (tests); default: files of 32 MB or more
   if (!ts || (e && atoi(e) == 0)) return false;
   if (set->load_in_memory || set->format != "BED") return false;
-  if (opt.guard || opt.explode_blocks || opt.collect_zero_length) return false;
+  if (opt.guard || opt.collect_zero_length) return false;                 // (explode_blocks: a 12-column line sends its block back to the packer, which does it)
   if (opt.mode != gtxhost::PACK_OVERLAPS_SORTED && opt.mode != gtxhost::PACK_OVERLAPS_UNSORTED) return false;
-  if (opt.strand_aware && !opt.sorted_by_strand) return false;   // (reads of both strands interleaved: the packer groups them by strand for the streaming kernel)
   if (!g_pool.buf[0] || !g_pool.buf[1] || !ts->usable()) return false;
   const long left = set->StreamBytesLeft();                      // -1: not a regular uncompressed file
   return left >= ((e && atoi(e) == 1) ? 1 : (32l << 20));
@@ -692,11 +691,13 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
     if (!packer.PackPrimedText(&batch, &err)) DiePack(err);
     if (!batch.tri.empty()) sink(batch);
     BedPacker::TextBlock blk[2]; int ticket[2] = {-1, -1}; bool host_only = false;
+    long on_device = 0, redone = 0, host_blocks = 0;
     auto settle = [&](int k) {                                   // the verdict on the block in blk[k]
       if (ticket[k] < 0) return;
       const bool redo = text_sink->needs_host(ticket[k]);
       ticket[k] = -1;
-      if (!redo) return;
+      if (!redo) { on_device++; return; }
+      redone++;
       batch.tri.clear(); batch.w.clear(); batch.zero_len.clear(); batch.n_lines = 0; batch.label_sum = 0;
       const bool ok = packer.PackTextBlock(blk[k], &batch, &err);
       if (err.set) DiePack(err);
@@ -710,6 +711,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       BedPacker::TextBlock &b = blk[cur];
       if (!b.seam_ok) host_only = true;                          // a last line that could not be read: no seam key for the device
       if (host_only) {
+        host_blocks++;
         batch.tri.clear(); batch.w.clear(); batch.zero_len.clear(); batch.n_lines = 0; batch.label_sum = 0;
         packer.PackTextBlock(b, &batch, &err);
         if (err.set) { settle(cur ^ 1); DiePack(err); }
@@ -720,6 +722,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       ticket[cur] = text_sink->add(b.text, b.bytes, b.n_lines, rules);
     }
     settle(0); settle(1);
+    if (getenv("GTX_TEXT_TRACE")) fprintf(stderr, "[gtx text] blocks tokenised on the device: %ld, sent back to the host packer: %ld, packed on the host from the start: %ld\n", on_device, redone, host_blocks);
     g_pool.used[0] = g_pool.used[1] = false;
   };
   auto pump = [&](BedPacker &packer, bool prepared = false) {

@@ -85,7 +85,7 @@ struct gtx_ctx {
   // region text tokenised on the device (gtx_count_add_text): two blocks in flight
   struct TextSlot {
     char *d_text = nullptr; size_t capText = 0; unsigned *d_seg = nullptr; size_t capSeg = 0;
-    unsigned *d_nl = nullptr; int *d_tri = nullptr, *d_w = nullptr; size_t capLines = 0;
+    unsigned *d_nl = nullptr; int *d_tri = nullptr, *d_w = nullptr, *d_tri2 = nullptr, *d_w2 = nullptr; unsigned *d_blk = nullptr; size_t capLines = 0, capLines2 = 0;
     int *d_flag = nullptr, *h_flag = nullptr; char *h_pin = nullptr; size_t capPin = 0; char *h_seam = nullptr;
     hipEvent_t evParsed = nullptr, evConsumed = nullptr, evCopied = nullptr; bool busy = false;
   } text[2];
@@ -228,7 +228,7 @@ void gtx_destroy(gtx_ctx *c)
   }
   if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
   for (auto &t : c->text) {
-    dfree(t.d_text); dfree(t.d_seg); dfree(t.d_nl); dfree(t.d_tri); dfree(t.d_w); dfree(t.d_flag);
+    dfree(t.d_text); dfree(t.d_seg); dfree(t.d_nl); dfree(t.d_tri); dfree(t.d_w); dfree(t.d_tri2); dfree(t.d_w2); dfree(t.d_blk); dfree(t.d_flag);
     if (t.h_flag) (void)hipHostFree(t.h_flag);
     if (t.h_pin) (void)hipHostFree(t.h_pin);
     if (t.h_seam) (void)hipHostFree(t.h_seam);
@@ -1537,25 +1537,32 @@ static int add_text(gtx_ctx *c, bool coverage, const char *text, size_t bytes, i
   HIPCHK(c, hipEventRecord(t.evCopied, c->copyStream));
   HIPCHK(c, hipStreamWaitEvent(c->stream, t.evCopied, 0));
   HIPCHK(c, hipMemsetAsync(t.d_flag, 0, sizeof(int), c->stream));
+  if (r->strand_aware && (size_t)nLines > t.capLines2) {
+    dfree(t.d_tri2); dfree(t.d_w2); dfree(t.d_blk); t.capLines2 = 0;
+    HIPCHK(c, hipMalloc(&t.d_tri2, sizeof(int) * 3 * t.capLines)); HIPCHK(c, hipMalloc(&t.d_w2, sizeof(int) * t.capLines)); HIPCHK(c, hipMalloc(&t.d_blk, sizeof(unsigned) * (t.capLines / 128 + 4)));
+    t.capLines2 = t.capLines;
+  }
   gtxtext::TextDevice d; d.text = t.d_text; d.segCount = t.d_seg; d.nl = t.d_nl; d.tri = t.d_tri; d.w = t.d_w; d.flag = t.d_flag;
+  d.tri2 = r->strand_aware ? t.d_tri2 : nullptr; d.w2 = r->strand_aware ? t.d_w2 : nullptr; d.blkMinus = r->strand_aware ? t.d_blk : nullptr;
+  const int *triOut = r->strand_aware ? t.d_tri2 : t.d_tri;
   HIPCHK(c, gtxtext::launch_tokenize(d, tabs, *r, bytes, (unsigned)nLines, c->stream));
   HIPCHK(c, hipMemcpyAsync(t.h_flag, t.d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipEventRecord(t.evParsed, c->stream));
   // ... and counted where the triples are
-  const int *dW = r->max_label_value > 1 ? t.d_w : nullptr;
+  const int *dW = r->max_label_value > 1 ? (r->strand_aware ? t.d_w2 : t.d_w) : nullptr;
   const int64_t seen = c->streamSeen;
   int rc = GTX_OK;
   if (coverage) {
     if (flags & GTX_GAPS_FORMULA) { rc = merge_prepare(c, flags, 2); if (rc) return rc; }
-    rc = cover_launch(c, t.d_tri, dW, nLines, seen, flags, (flags & GTX_READS_UNSORTED) != 0 || !(flags & GTX_READS_SORTED)); if (rc) return rc;
+    rc = cover_launch(c, triOut, dW, nLines, seen, flags, (flags & GTX_READS_UNSORTED) != 0 || !(flags & GTX_READS_SORTED)); if (rc) return rc;
   } else {
     rc = merge_prepare(c, flags, 0); if (rc) return rc;
     const bool streaming = (flags & (GTX_READS_SORTED | GTX_CHECK_SORTED)) != 0;
     if (!streaming) c->tileSumsValid = false;
-    if (streaming) HIPCHK(c, gtx::launch_count(t.d_tri, dW, nLines, count_args(c, flags & ~GTX_CHECK_SORTED, nLines, seen), true, c->stream));
-    else { rc = launch_unsorted(c, t.d_tri, dW, nLines, count_args(c, flags, nLines, seen)); if (rc) return rc; }
+    if (streaming) HIPCHK(c, gtx::launch_count(triOut, dW, nLines, count_args(c, flags & ~GTX_CHECK_SORTED, nLines, seen), true, c->stream));
+    else { rc = launch_unsorted(c, triOut, dW, nLines, count_args(c, flags, nLines, seen)); if (rc) return rc; }
   }
-  rc = merge_batch(c, t.d_tri, dW, nLines); if (rc) return rc;
+  rc = merge_batch(c, triOut, dW, nLines); if (rc) return rc;
   HIPCHK(c, hipEventRecord(t.evConsumed, c->stream));
   t.busy = true;
   c->streamSeen += nLines;

@@ -13,6 +13,7 @@ struct TextDevice {               // device buffers of one block in flight
   unsigned *segCount;             // [segments + 1] newlines per 1 KB segment, then their exclusive prefix
   unsigned *nl;                   // [n_lines] byte offset of every newline
   int *tri; int *w;               // [n_lines] packed triples / weights
+  int *tri2; int *w2; unsigned *blkMinus;   // strand-aware runs: the same grouped by strand ('+' first), and the '-' lines per 128-line block [n_lines / 128 + 2]; null otherwise
   int *flag;                      // != 0: the block is not plain (nothing of it is counted)
 };
 struct TextTables {               // per reference set: hash table of the chromosome names, the names, the seam's name behind them

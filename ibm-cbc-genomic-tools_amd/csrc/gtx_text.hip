@@ -105,6 +105,7 @@ struct ParseArgs {
   long long maxLabel;
   int havePrev; unsigned prevNameOff, prevNameLen; int prevStrand; long long prevStart;   // the line before the block (its chromosome name in `names`' blob)
   int *tri; int *w; int *flag;
+  unsigned *blkMinus;             // strand-aware runs: '-' lines per parse block (for the grouping pass), else null
 };
 
 __device__ __forceinline__ unsigned fnv1a(const unsigned char *p, unsigned n)
@@ -247,6 +248,34 @@ __global__ __launch_bounds__(kLines) void text_parse_kernel(ParseArgs a)
   if (!plain) atomicOr(a.flag, 1);
   a.tri[3 * (size_t)j] = cls; a.tri[3 * (size_t)j + 1] = start; a.tri[3 * (size_t)j + 2] = stop;
   if (a.weighted) a.w[j] = wv;
+  if (a.blkMinus && cls >= a.nChrom) atomicAdd(&a.blkMinus[blockIdx.x], 1u);
+}
+
+// strand-aware runs: the '+' lines first, then the '-' lines, each group in file order -- a position-sorted stream of both strands
+// becomes two class-sorted runs for the streaming kernel (what the host packer does per batch).  blkOff = exclusive prefix of the
+// '-' counts per parse block, the total behind the last.
+__global__ __launch_bounds__(kLines) void strand_group_kernel(const int *__restrict__ tri, const int *__restrict__ w, unsigned nLines, int nChrom,
+                                                              const unsigned *__restrict__ blkOff, unsigned nBlocks, int *__restrict__ tri2, int *__restrict__ w2,
+                                                              const int *__restrict__ flag)
+{
+  __shared__ unsigned waveMinus[kLines / 64];
+  const unsigned j = blockIdx.x * kLines + threadIdx.x;
+  const bool in = j < nLines;
+  if (*flag) { if (in) { tri2[3 * (size_t)j] = -1; tri2[3 * (size_t)j + 1] = 0; tri2[3 * (size_t)j + 2] = 0; if (w2) w2[j] = 1; } return; }   // a block that goes back to the host: nothing to count
+  int c = -1, s0 = 0, e0 = 0, wv = 1;
+  if (in) { c = tri[3 * (size_t)j]; s0 = tri[3 * (size_t)j + 1]; e0 = tri[3 * (size_t)j + 2]; if (w) wv = w[j]; }
+  const bool minus = in && c >= nChrom;
+  const unsigned long long m = __ballot(minus);
+  const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+  if (lane == 0) waveMinus[wv_id] = (unsigned)__popcll(m);
+  __syncthreads();
+  unsigned before = (unsigned)__popcll(m & ((1ull << lane) - 1));
+  for (int k = 0; k < wv_id; k++) before += waveMinus[k];
+  if (!in) return;
+  const unsigned minusBefore = blkOff[blockIdx.x] + before, totalMinus = blkOff[nBlocks], nPlus = nLines - totalMinus;
+  const size_t at = minus ? (size_t)nPlus + minusBefore : (size_t)j - minusBefore;
+  tri2[3 * at] = c; tri2[3 * at + 1] = s0; tri2[3 * at + 2] = e0;
+  if (w2) w2[at] = wv;
 }
 
 // a block that is not plain is not counted at all: the host packer redoes it
@@ -269,8 +298,19 @@ hipError_t launch_tokenize(const TextDevice &d, const TextTables &t, const gtx_t
   a.weighted = r.max_label_value > 1; a.maxLabel = r.max_label_value;
   a.havePrev = r.have_prev && t.prevLen > 0; a.prevNameOff = t.prevOff; a.prevNameLen = t.prevLen; a.prevStrand = r.prev_strand; a.prevStart = r.prev_start;
   a.tri = d.tri; a.w = d.w; a.flag = d.flag;
-  text_parse_kernel<<<(nLines + kLines - 1) / kLines, kLines, 0, st>>>(a);
+  const unsigned nBlocks = (nLines + kLines - 1) / kLines;
+  a.blkMinus = nullptr;
+  if (r.strand_aware && d.tri2) {
+    a.blkMinus = d.blkMinus;
+    hipError_t e = hipMemsetAsync(d.blkMinus, 0, sizeof(unsigned) * ((size_t)nBlocks + 1), st);
+    if (e != hipSuccess) return e;
+  }
+  text_parse_kernel<<<nBlocks, kLines, 0, st>>>(a);
   text_void_kernel<<<256, 256, 0, st>>>(d.tri, nLines, d.flag);
+  if (a.blkMinus) {
+    nl_scan_kernel<<<1, 1024, 0, st>>>(d.blkMinus, nBlocks);
+    strand_group_kernel<<<nBlocks, kLines, 0, st>>>(d.tri, a.weighted ? d.w : nullptr, nLines, r.n_chrom, d.blkMinus, nBlocks, d.tri2, a.weighted ? d.w2 : nullptr, d.flag);
+  }
   return hipGetLastError();
 }
 

@@ -622,3 +622,99 @@ def test_bed12_count_without_gaps_is_refused_loudly(bed12):
     for args in (["count", "-i", "refs12.bed", "reads12.bed"], ["count", "-S", "-i", "refs12.bed", "reads12.bed"]):
         rc, out, err = product("overlaps", args, cwd=bed12)
         assert rc == 1 and out == "" and "multi-interval" in err
+
+
+# ---- BED text tokenised on the device (gtx_count_add_text, csrc/gtx_text.hip): the plain case there, everything else back to the host packer
+def _product_text(args, cwd, block_mb=None):
+    env = dict(os.environ, GTX_TEXT_ON_DEVICE="1", GTX_TEXT_TRACE="1")
+    if block_mb:
+        env["GTX_PACK_BLOCK_MB"] = str(block_mb)
+    r = subprocess.run([TOOLS["overlaps"]] + list(args), capture_output=True, cwd=cwd, env=env)
+    lines = r.stderr.decode().split("\n")                                          # (not splitlines: a '\r' may be part of a message)
+    trace = [l for l in lines if l.startswith("[gtx text]")]
+    err = "\n".join(l for l in lines if not l.startswith("[gtx text]"))
+    nums = [int(x) for x in __import__("re").findall(r": (\d+)", trace[0])] if trace else None
+    return r.returncode, r.stdout.decode(), err, nums
+
+
+@pytest.fixture(scope="module")
+def text_beds(tmp_path_factory):
+    d = tmp_path_factory.mktemp("textdev")
+    rng = np.random.default_rng(77)
+    names = ["chr1", "chr10", "chr2", "chrX"]
+    def lines(n, lo, hi, width, sort=True, extra_chrom=None):
+        c = rng.integers(0, len(names), n); s = rng.integers(lo, hi, n); ln = rng.integers(20, width, n)
+        if sort:
+            o = np.lexsort((s, c)); c, s, ln = c[o], s[o], ln[o]
+        out = []
+        for i in range(n):
+            nm = names[c[i]] if extra_chrom is None or i % 97 else extra_chrom
+            out.append("%s\t%d\t%d\tr%d\t%d\t%s" % (nm, s[i], s[i] + ln[i], rng.integers(0, 9), 0, "+-"[int(rng.integers(0, 2))]))
+        return out
+    (d / "refs.bed").write_text("\n".join(lines(3000, 1000, 2_000_000, 3000)) + "\n")
+    plain = lines(200_000, 1000, 2_000_000, 300)
+    (d / "plain.bed").write_text("\n".join(plain) + "\n")
+    (d / "unknown_chrom.bed").write_text("\n".join(lines(100_000, 1000, 2_000_000, 300, extra_chrom="chr1_random")) + "\n")   # dropped lines; also breaks the order for -S
+    (d / "shuffled.bed").write_text("\n".join(lines(120_000, 1000, 2_000_000, 300, sort=False)) + "\n")
+    def variant(name, edit, at=150_000):
+        v = list(plain); v[at] = edit(v[at]); (d / name).write_text("\n".join(v) + "\n")
+    variant("crlf.bed", lambda l: l + "\r")
+    variant("spaces.bed", lambda l: l.replace("\t", " "))
+    variant("plus_sign.bed", lambda l: l.split("\t")[0] + "\t+" + "\t".join(l.split("\t")[1:]))
+    variant("bad_strand.bed", lambda l: "\t".join(l.split("\t")[:5] + ["x"]))
+    variant("three_cols.bed", lambda l: "\t".join(l.split("\t")[:3]))
+    variant("two_cols.bed", lambda l: "\t".join(l.split("\t")[:2]))
+    variant("empty_token.bed", lambda l: l.replace("\t0\t", "\t\t"))
+    variant("bed12.bed", lambda l: l + "\t0\t0\t0\t1\t%d,\t0," % (int(l.split("\t")[2]) - int(l.split("\t")[1])))
+    variant("zero_stop.bed", lambda l: "chr1\t0\t0\tz\t0\t+", at=0)
+    variant("inverted.bed", lambda l: "\t".join([l.split("\t")[0], l.split("\t")[2], l.split("\t")[1]] + l.split("\t")[3:]))
+    variant("label_text.bed", lambda l: "\t".join(l.split("\t")[:3] + ["7up"] + l.split("\t")[4:]))
+    v = list(plain)
+    v[150_000] = "chr1\t1999999\t2000100\tlate\t0\t+"                                      # out of order inside a block
+    (d / "disorder.bed").write_text("\n".join(v) + "\n")
+    (d / "no_final_newline.bed").write_text("\n".join(plain))
+    return d
+
+
+TEXT_RUNS = [["count", "-S", "-i"], ["count", "-i"], ["count", "-S"], ["count"], ["count", "-S", "-s"], ["count", "-S", "-i", "--max-label-value", "5"],
+             ["coverage", "-S", "-i"], ["coverage", "-i", "--max-label-value", "3"], ["density", "-S"], ["rpkm", "-S", "-i"]]
+
+
+@pytest.mark.parametrize("mode", TEXT_RUNS, ids=[" ".join(m) for m in TEXT_RUNS])
+def test_text_on_device_plain_file(text_beds, mode):
+    """a plain tab-separated BED file: every block is tokenised on the device, none comes back, output = the oracle CLI's"""
+    reads = "plain.bed"
+    if mode[-1] == "-s":                                                             # sorted by strand: regroup the file
+        rows = sorted((l.split("\t") for l in (text_beds / "plain.bed").read_text().splitlines()), key=lambda r: (r[0], r[5], int(r[1])))
+        (text_beds / "plain_by_strand.bed").write_text("\n".join("\t".join(r) for r in rows) + "\n")
+        reads = "plain_by_strand.bed"
+        rows = sorted((l.split("\t") for l in (text_beds / "refs.bed").read_text().splitlines()), key=lambda r: (r[0], r[5], int(r[1])))
+        (text_beds / "refs_by_strand.bed").write_text("\n".join("\t".join(r) for r in rows) + "\n")
+    args = mode + ["refs_by_strand.bed" if mode[-1] == "-s" else "refs.bed", reads]
+    want = oracle(args, cwd=text_beds)
+    rc, out, err, nums = _product_text(args, text_beds, block_mb=1)
+    assert (rc, out) == (want[0], want[1]), err
+    assert nums is not None and nums[0] >= 5 and nums[1] == 0 and nums[2] == 0, nums
+
+
+ODD_FILES = ["crlf.bed", "spaces.bed", "plus_sign.bed", "bad_strand.bed", "three_cols.bed", "two_cols.bed", "empty_token.bed", "bed12.bed", "zero_stop.bed",
+             "inverted.bed", "label_text.bed", "disorder.bed", "no_final_newline.bed", "unknown_chrom.bed", "shuffled.bed"]
+
+
+@pytest.mark.parametrize("name", ODD_FILES)
+def test_text_on_device_odd_lines_go_back_to_the_host(text_beds, name):
+    """one line outside the plain case (or an error of the reference's) in a file of 200 k lines: that block is redone by the host
+    packer -- output, exit code and message are the oracle CLI's in both algorithms; the other blocks stay on the device"""
+    gaps = ["-gaps"] if name == "bed12.bed" else []          # (a COUNT over multi-interval regions is inside the path under -gaps only)
+    for mode in (["count", "-S", "-i"] + gaps, ["count", "-i", "--max-label-value", "9"] + gaps, ["coverage", "-i"]):
+        args = mode + ["refs.bed", name]
+        want = oracle(args, cwd=text_beds)
+        rc, out, err, nums = _product_text(args, text_beds, block_mb=1)
+        assert rc == want[0], (args, err, want[2])
+        assert out == want[1], args
+        if want[0] != 0:
+            assert err.strip() == want[2].strip(), args
+        elif name in ("crlf.bed", "spaces.bed", "plus_sign.bed", "empty_token.bed", "bed12.bed"):
+            assert nums is not None and nums[1] >= 1, (args, nums)                    # the odd line's block did come back (odd under either algorithm's rules)
+        if name in ("three_cols.bed", "label_text.bed", "no_final_newline.bed") and want[0] == 0:
+            assert nums is not None and nums[1] == 0, (args, nums)                    # plain after all: a 3-column line, a label atol reads, a dropped tail
