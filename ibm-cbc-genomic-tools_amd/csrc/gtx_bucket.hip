@@ -306,6 +306,7 @@ __global__ __launch_bounds__(1024) void chunk_place_kernel(BucketTable t, Bucket
 
 static constexpr int kBktE = 2048, kBktS = 4096;                 // boundaries per bucket (ends array) / starts-array slice in LDS
 static constexpr int kCellsE = 2048, kCellsS = 4096;             // cells of the direct-address tables
+static constexpr int kBktT = 2560, kCellsT = 2560;               // coverage: slice of the threshold array in LDS (the bucket's 2048 + what a read's end can lie beyond them) / its cells
 
 // ranks of U keys among the sorted boundaries v[0..n): #{v < key} (LE = false) or #{v <= key} (true), through the table
 // tab[c] = i0 | i1 << 16: the boundaries whose value lies in cell c are v[i0..i1) (cell(x) = (x - lo) >> sh, clamped to [0, cells)):
@@ -427,9 +428,12 @@ __global__ __launch_bounds__(1024) void bucket_count_kernel(CountArgs a, BucketT
 template <bool WEIGHTED>
 __global__ __launch_bounds__(1024) void bucket_cover_kernel(CoverArgs cv, BucketTable t, BucketWork w, int splits)
 {
-  __shared__ int sT[kBktS];
-  __shared__ unsigned tT[kCellsS + 1];
-  __shared__ u64 hWs[kBktE + 1], hFs[kBktE + 1], hWe[kBktS + 1], hFe[kBktS + 1];
+  // unweighted reads count in 32 bits (a block sees < 2^31 reads; the key sums need 64): 74 KB, two blocks per CU (weighted: 92 KB, one)
+  typedef typename std::conditional<WEIGHTED, u64, unsigned>::type cnt_t;
+  __shared__ int sT[kBktT];
+  __shared__ unsigned tT[kCellsT + 1];
+  __shared__ cnt_t hWs[kBktE + 1], hWe[kBktT + 1];
+  __shared__ u64 hFs[kBktE + 1], hFe[kBktT + 1];
   const int b = blockIdx.x / splits, k = blockIdx.x % splits;
   const unsigned c0 = w.rowOff[b], nCh = w.rowOff[b + 1] - c0;   // the bucket's stretch of the chunk list
   const unsigned r0 = c0 + (unsigned)((u64)nCh * k / splits), r1 = c0 + (unsigned)((u64)nCh * (k + 1) / splits);
@@ -440,8 +444,8 @@ __global__ __launch_bounds__(1024) void bucket_cover_kernel(CoverArgs cv, Bucket
   for (int i = threadIdx.x; i <= nE; i += blockDim.x) { hWs[i] = 0; hFs[i] = 0; }
   for (int i = threadIdx.x; i <= nS; i += blockDim.x) { hWe[i] = 0; hFe[i] = 0; }
   __syncthreads();
-  const int loT = nS ? sT[0] : 0, shT = nS ? shift_for(loT, sT[nS - 1], kCellsS) : 0;
-  build_table(sT, nS, tT, kCellsS, loT, shT);
+  const int loT = nS ? sT[0] : 0, shT = nS ? shift_for(loT, sT[nS - 1], kCellsT) : 0;
+  build_table(sT, nS, tT, kCellsT, loT, shT);
   __syncthreads();
   const int2 *__restrict__ reads = (const int2 *)w.tmpReads;
   constexpr int U = 4;
@@ -465,14 +469,14 @@ __global__ __launch_bounds__(1024) void bucket_cover_kernel(CoverArgs cv, Bucket
     int ks[U], ke[U], slotS[U], slotE[U];
 #pragma unroll
     for (int u = 0; u < U; u++) { ks[u] = se[u].x; ke[u] = se[u].y; }
-    table_ranks<false, U>(sT, tT, kCellsS, loT, shT, ks, slotS);      // #{T < s} inside the slice
-    table_ranks<false, U>(sT, tT, kCellsS, loT, shT, ke, slotE);      // #{T < e}
+    table_ranks<false, U>(sT, tT, kCellsT, loT, shT, ks, slotS);      // #{T < s} inside the slice
+    table_ranks<false, U>(sT, tT, kCellsT, loT, shT, ke, slotE);      // #{T < e}
 #pragma unroll
     for (int u = 0; u < U; u++) {
       if (!on[u]) continue;
       const u64 wt = WEIGHTED ? (u64)(i64)wt4[u] : 1;
-      atomicAdd(&hWs[slotS[u]], wt); atomicAdd(&hFs[slotS[u]], wt * (u64)(i64)ks[u]);
-      if (slotE[u] < nS || sHi == segEnd) { atomicAdd(&hWe[slotE[u]], wt); atomicAdd(&hFe[slotE[u]], wt * (u64)(i64)ke[u]); }
+      atomicAdd(&hWs[slotS[u]], (cnt_t)wt); atomicAdd(&hFs[slotS[u]], wt * (u64)(i64)ks[u]);
+      if (slotE[u] < nS || sHi == segEnd) { atomicAdd(&hWe[slotE[u]], (cnt_t)wt); atomicAdd(&hFe[slotE[u]], wt * (u64)(i64)ke[u]); }
       else {                                                          // the read ends beyond the slice: global search above it
         int glo = sHi, ghi = segEnd;
         while (glo < ghi) { const int mid = (int)(((i64)glo + ghi) >> 1); if (cv.sortedT[mid] < ke[u]) glo = mid + 1; else ghi = mid; }
@@ -482,12 +486,12 @@ __global__ __launch_bounds__(1024) void bucket_cover_kernel(CoverArgs cv, Bucket
   }
   __syncthreads();
   for (int i = threadIdx.x; i <= nE; i += blockDim.x) {
-    const u64 a0 = hWs[i], a1 = hFs[i];
+    const u64 a0 = (u64)(WEIGHTED ? (i64)hWs[i] : (i64)(u64)hWs[i]), a1 = hFs[i];
     if (a0) atomicAdd(&cv.hist[0][(i64)sLo + i + cls], a0);
     if (a1) atomicAdd(&cv.hist[1][(i64)sLo + i + cls], a1);
   }
   for (int i = threadIdx.x; i <= nS; i += blockDim.x) {
-    const u64 a0 = hWe[i], a1 = hFe[i];
+    const u64 a0 = (u64)(WEIGHTED ? (i64)hWe[i] : (i64)(u64)hWe[i]), a1 = hFe[i];
     if (a0) atomicAdd(&cv.hist[2][(i64)sLo + i + cls], a0);
     if (a1) atomicAdd(&cv.hist[3][(i64)sLo + i + cls], a1);
   }
@@ -553,12 +557,15 @@ int scan_part_bins(bool weighted) { return weighted ? kScanBins64 : kScanBins32;
 
 int bucket_e_size() { return kBktE; }
 int bucket_s_size() { return kBktS; }
+int bucket_t_size() { return kBktT; }
 
 static int device_cus()
 {
-  static int cus = 0;
-  if (!cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
-  return cus > 0 ? cus : 256;
+  static int cus[64] = {0};                                       // per device (a race writes the same value twice)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cus[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus[dev] = n; }
+  return cus[dev] > 0 ? cus[dev] : 256;
 }
 
 static size_t scatter_lds(int nClasses, int nB, int nCells, int per, bool weighted) { return 16 * ((size_t)nClasses + 2) + 32 * (size_t)nB + 8 + (weighted ? 16 : 12) * 1024 * (size_t)per + 2 * ((size_t)nCells + 2) + 16; }
@@ -593,14 +600,16 @@ BucketPlan bucket_plan(i64 n, int nClasses, int nB, int nCells, bool weighted)
 static hipError_t launch_partition(const void *reads, const void *weights, i64 n, const CountArgs &a, const BucketTable &t, const BucketWork &w,
                                    const BucketPlan &p, hipStream_t st)
 {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipSuccess;
-    const void *fn[] = {(const void *)bucket_scatter_kernel<false, 1>, (const void *)bucket_scatter_kernel<true, 1>, (const void *)bucket_scatter_kernel<false, 4>,
-                        (const void *)bucket_scatter_kernel<true, 4>, (const void *)bucket_scatter_kernel<false, 2>, (const void *)bucket_scatter_kernel<true, 2>};
-    for (const void *f : fn) if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  static PerDevice attr;
+  {
+    hipError_t e = attr.once([] {
+      hipError_t e = hipSuccess;
+      const void *fn[] = {(const void *)bucket_scatter_kernel<false, 1>, (const void *)bucket_scatter_kernel<true, 1>, (const void *)bucket_scatter_kernel<false, 4>,
+                          (const void *)bucket_scatter_kernel<true, 4>, (const void *)bucket_scatter_kernel<false, 2>, (const void *)bucket_scatter_kernel<true, 2>};
+      for (const void *f : fn) if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+      return e;
+    });
     if (e != hipSuccess) return e;
-    attr = true;
   }
   const size_t lds = scatter_lds(a.nClasses, t.nB, t.nCells, p.per, weights != nullptr);
 #define GTX_SCATTER(W, P) bucket_scatter_kernel<W, P><<<p.blocks, 1024, lds, st>>>((const Tri3 *)reads, (const int *)weights, n, a, t, w)
@@ -642,13 +651,13 @@ hipError_t launch_scan_bucketed(const void *reads, const void *weights, i64 n, c
   if (n <= 0 || nParts <= 0) return hipSuccess;
   hipError_t e = launch_partition(reads, weights, n, a, t, w, p, st);
   if (e != hipSuccess) return e;
-  static bool attr = false;
-  if (!attr) {
-    e = hipFuncSetAttribute((const void *)bucket_scanhist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)bucket_scanhist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static PerDevice attr;
+  e = attr.once([] {
+    hipError_t e2 = hipFuncSetAttribute((const void *)bucket_scanhist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)bucket_scanhist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return e2;
+  });
+  if (e != hipSuccess) return e;
   const size_t lds = (size_t)scan_part_bins(weights != nullptr) * (weights ? 8 : 4);
   if (weights) bucket_scanhist_kernel<true><<<(unsigned)nParts, 1024, lds, st>>>(sc, t, w, parts);
   else bucket_scanhist_kernel<false><<<(unsigned)nParts, 1024, lds, st>>>(sc, t, w, parts);

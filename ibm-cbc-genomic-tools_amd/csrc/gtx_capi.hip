@@ -893,7 +893,7 @@ int gtx_count(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t 
 static int cover_bucket_tables(gtx_ctx *c, const std::vector<int32_t> &sortedT, const std::vector<int32_t> &seg)
 {
   const int nClasses = c->nClasses;
-  const int kE = gtx::bucket_e_size(), kS = gtx::bucket_s_size();
+  const int kE = gtx::bucket_e_size(), kS = gtx::bucket_t_size();
   std::vector<int32_t> posHi, eLo, eHi, sLo, sHi, cls, clsStart(nClasses + 1, 0);
   for (int cl = 0; cl < nClasses; cl++) {
     clsStart[cl] = (int32_t)posHi.size();

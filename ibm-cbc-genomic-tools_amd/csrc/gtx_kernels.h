@@ -2,8 +2,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 namespace gtx {
+
+// Function attributes (dynamic LDS limits) and device properties are per DEVICE: a gtx_group drives several devices from one
+// process.  once(fn) runs fn the first time it is reached with a given current device, under a lock.
+struct PerDevice {
+  std::mutex m; unsigned long long done = 0;
+  template <class F> hipError_t once(F fn)
+  {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(m);
+    if (dev >= 0 && dev < 64 && ((done >> dev) & 1)) return hipSuccess;
+    e = fn();
+    if (e == hipSuccess && dev >= 0 && dev < 64) done |= 1ull << dev;
+    return e;
+  }
+};
 
 // device-side mirror of gtx_count_info (include/gtx.h)
 struct DevInfo {
@@ -137,6 +155,7 @@ BucketPlan bucket_plan(long long n, int nClasses, int nB, int nCells, bool weigh
 bool bucket_tables_fit(int nClasses, int nB, int nCells);
 int bucket_e_size();
 int bucket_s_size();
+int bucket_t_size();                 // coverage: entries of the threshold array a bucket keeps in LDS
 hipError_t launch_count_bucketed(const void *reads, const void *weights, long long n, const CountArgs &a, const BucketTable &t,
                                  const BucketWork &w, const BucketPlan &p, hipStream_t st);
 // coverage of reads in no particular order: the same partition over a bucket table of the THRESHOLD array (cuts and slices both

@@ -1866,12 +1866,14 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
     else count_walk_kernel<false, 4><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   } else {
     // one 1024-thread block per CU (the LDS top level fills most of the CU's 160 KB)
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute((const void *)count_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSearchLdsBytes);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)count_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSearchLdsBytes);
+    static PerDevice attr;
+    {
+      hipError_t e = attr.once([] {
+        hipError_t e2 = hipFuncSetAttribute((const void *)count_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSearchLdsBytes);
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)count_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSearchLdsBytes);
+        return e2;
+      });
       if (e != hipSuccess) return e;
-      attr = true;
     }
     i64 blocks = (n + 1023) / 1024; if (blocks > 512) blocks = 512;
     const size_t lds = sizeof(int) * 2 * (size_t)a.nSamp;

@@ -167,12 +167,14 @@ hipError_t launch_scan_own(const void *reads, const void *weights, i64 n, const 
   if (o.totalBlocks <= 0) return hipSuccess;
   scan_bounds_kernel<<<(unsigned)((o.totalBlocks + 1 + 255) / 256), 256, 0, st>>>((const Tri5 *)reads, n, a, o);
   const size_t lds = (size_t)(o.tile + a.comb + 1) * (weights ? 8 : 4);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void *)scan_own_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)scan_own_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  static PerDevice attr;
+  {
+    hipError_t e = attr.once([] {
+      hipError_t e2 = hipFuncSetAttribute((const void *)scan_own_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)scan_own_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      return e2;
+    });
     if (e != hipSuccess) return e;
-    attr = true;
   }
   if (weights) scan_own_kernel<true><<<(unsigned)o.totalBlocks, kOwnThreads, lds, st>>>((const Tri5 *)reads, (const int *)weights, n, a, o, out);
   else scan_own_kernel<false><<<(unsigned)o.totalBlocks, kOwnThreads, lds, st>>>((const Tri5 *)reads, (const int *)weights, n, a, o, out);
