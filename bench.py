@@ -257,7 +257,7 @@ def bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads,
         emit(({
             "metric": "window-counted reads/sec, genomic_scans counts 1 kb windows (BASELINE config 4)",
             "value": total_reads * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": "BASELINE config 4: genomic_scans counts -i -w 1000 -d 1000 over %d 50bp reads in total, hg38 chromosome "
                                    "shards (LPT, gtx_group), the owners' per-chromosome pieces of the %d-window vector to member 0 (ncclSend/ncclRecv)" % (total_reads, tot), "total_reads": total_reads,
@@ -361,6 +361,14 @@ def bench_perm(args, rank, world, local, device, rehearse):
         dist.destroy_process_group()
 
 
+def shape_name(total_reads, n_refs):
+    if total_reads == 100_000_000 and n_refs == 1_000_000:
+        return "BASELINE config 3"
+    if total_reads == 1_000_000_000 and n_refs == 2_000_000:
+        return "BASELINE config 5 shape (count part)"
+    return "BASELINE config 3 workload at another size"
+
+
 def make_group(rank, world, local, device, rehearse, force_dist):
     """this process's view of the gtx_group of a multi-GPU run: (group or None, the members it drives)"""
     if rehearse:                                                      # one GPU, gloo: rank 0 drives all members on device 0
@@ -458,8 +466,8 @@ def bench_count_group(args, rank, world, local, device, rehearse, force_dist):
             "value": total_reads * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: %d 50bp reads in total, sorted by (chrom,start), x %d ref intervals over 24 hg38 "
-                                   "chromosomes, strand ignored (genomic_overlaps count -S -i); reads resident in HBM" % (total_reads, len(refs)),
+            "config": {"workload": "%s: %d 50bp reads in total, sorted by (chrom,start), x %d ref intervals over 24 hg38 "
+                                   "chromosomes, strand ignored (genomic_overlaps count -S -i); reads resident in HBM" % (shape_name(total_reads, len(refs)), total_reads, len(refs)),
                        "total_reads": total_reads, "refs": len(refs), "reads_per_rank": reads_per_rank,
                        "imbalance": max(reads_per_rank) / (sum(reads_per_rank) / n_members),
                        "parallelism": "%s scaling through the product's gtx_group (libgtx.so): one process per GPU = one member each "
@@ -486,7 +494,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads in total (strong scaling, the default of the count workload) or per GPU (--scaling weak)")
     ap.add_argument("--refs", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="reads given to the CPU baseline (0 = skip)")
     ap.add_argument("--workload", choices=["count", "scans", "permutation_test"], default="count",
@@ -729,10 +737,10 @@ def main():
         line = {
             "metric": "overlap-counted reads/sec, 100M reads x 1M ref intervals",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: %d 50bp reads in total, sorted by (chrom,start), x %d ref intervals over 24 hg38 "
-                                   "chromosomes, strand ignored (genomic_overlaps count -S -i); reads resident in HBM" % (total_reads, len(refs)),
+            "config": {"workload": "%s: %d 50bp reads in total, sorted by (chrom,start), x %d ref intervals over 24 hg38 "
+                                   "chromosomes, strand ignored (genomic_overlaps count -S -i); reads resident in HBM" % (shape_name(total_reads, len(refs)), total_reads, len(refs)),
                        "total_reads": total_reads, "refs": len(refs), "reads_per_rank": reads_per_rank,
                        "imbalance": max(reads_per_rank) / (sum(reads_per_rank) / world),
                        "parallelism": "%s scaling: one global read set, chromosomes dealt to %d rank(s) by LPT packing of their read counts "
