@@ -689,7 +689,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
     packer.UseTextBuffers((char *)g_pool.buf[0], (char *)g_pool.buf[1], kPoolBytes);
     PackedBatch batch;
     if (!packer.PackPrimedText(&batch, &err)) DiePack(err);
-    if (!batch.tri.empty()) sink(batch);
+    if (!batch.empty()) sink(batch);
     BedPacker::TextBlock blk[2]; int ticket[2] = {-1, -1}; bool host_only = false;
     long on_device = 0, redone = 0, host_blocks = 0;
     auto settle = [&](int k) {                                   // the verdict on the block in blk[k]
@@ -698,11 +698,11 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       ticket[k] = -1;
       if (!redo) { on_device++; return; }
       redone++;
-      batch.tri.clear(); batch.w.clear(); batch.zero_len.clear(); batch.n_lines = 0; batch.label_sum = 0;
+      batch.clear();
       const bool ok = packer.PackTextBlock(blk[k], &batch, &err);
       if (err.set) DiePack(err);
       (void)ok;
-      if (!batch.tri.empty()) sink(batch);
+      if (!batch.empty()) sink(batch);
     };
     for (int cur = 0;; cur ^= 1) {
       settle(cur);                                               // (its buffer is about to be read over)
@@ -712,10 +712,10 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       if (!b.seam_ok) host_only = true;                          // a last line that could not be read: no seam key for the device
       if (host_only) {
         host_blocks++;
-        batch.tri.clear(); batch.w.clear(); batch.zero_len.clear(); batch.n_lines = 0; batch.label_sum = 0;
+        batch.clear();
         packer.PackTextBlock(b, &batch, &err);
         if (err.set) { settle(cur ^ 1); DiePack(err); }
-        if (!batch.tri.empty()) sink(batch);
+        if (!batch.empty()) sink(batch);
         continue;
       }
       rules.have_prev = b.have_prev; rules.prev_chrom = b.prev_chrom.c_str(); rules.prev_strand = b.prev_strand; rules.prev_start = b.prev_start;
@@ -733,7 +733,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       bool more = packer.NextBatch(&batch, batch_reads, &err);
       if (g_drain_stop) break;
       if (err.set) DiePack(err);
-      if (!batch.tri.empty()) {
+      if (!batch.empty()) {
         const auto t0 = std::chrono::steady_clock::now();
         sink(batch); cur ^= 1;
         if (getenv("GTX_PACK_TRACE")) fprintf(stderr, "[sink] %zu reads handed over in %.1f ms\n", batch.tri.size() / 3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -769,10 +769,21 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
   for (GenomicRegion *r = set->Get(); r != NULL; r = set->Next()) {
     GenomicInterval *i = r->I.front();
     if (r->I.size() > 1) {                                  // a multi-interval region: its envelope under -gaps, its intervals one by one for coverage
-      if (!opt.match_gaps && !opt.explode_blocks) r->PrintError("multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps, and coverage / density)!");
+      if (!opt.match_gaps && !opt.explode_blocks && !opt.collect_blocks) r->PrintError("multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps count, coverage and density)!");
       if (!r->IsCompatibleSortedAndNonoverlapping()) r->PrintError("query regions should be compatible, sorted and non-overlapping!");
     }
     char buf[64];
+    if (opt.collect_blocks && r->I.size() > 1) {               // as a 12-column line: the packer lists its intervals
+      text += i->CHROMOSOME; text += '\t';
+      snprintf(buf, sizeof buf, "%ld\t%ld\t", i->START - 1, r->I.back()->STOP); text += buf;
+      text += r->LABEL; text += "\t0\t"; text += i->STRAND; text += "\t0\t0\t0\t";
+      snprintf(buf, sizeof buf, "%zu\t", r->I.size()); text += buf;
+      for (GenomicIntervalSet::iterator b = r->I.begin(); b != r->I.end(); b++) { snprintf(buf, sizeof buf, "%ld,", (*b)->STOP - (*b)->START + 1); text += buf; }
+      text += '\t';
+      for (GenomicIntervalSet::iterator b = r->I.begin(); b != r->I.end(); b++) { snprintf(buf, sizeof buf, "%ld,", (*b)->START - i->START); text += buf; }
+      text += '\n';
+      continue;
+    }
     if (opt.explode_blocks && r->I.size() > 1) {
       for (GenomicIntervalSet::iterator b = r->I.begin(); b != r->I.end(); b++) {
         text += i->CHROMOSOME; text += '\t';
@@ -905,6 +916,7 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   }
   ChromTable chroms;
   bool explode = false;                                                             // coverage without -gaps over multi-interval index regions
+  bool blocks_mode = false;                                                         // count without -gaps over multi-interval index regions
   const char *last_name = NULL;                                                     // region files repeat a chromosome many times in a row
   for (long int k = 0; k < v; k++) {
     GenomicRegion *r = IndexSet->R[k];
@@ -913,10 +925,11 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
       // a multi-interval (BED12) region: with -gaps it is matched on its envelope (:5226, :5752, :5278) -- what the device computes.
       // Without: coverage is a sum over ALL interval pairs of the two regions (CalcOverlap :1196-1202, pairs that do not overlap
       // add 0), so the intervals go to the device one by one (`explode`) and a region's value is the sum of its intervals';
-      // count needs "some interval pair overlaps" (:1167-1172), which no sum of independent pieces gives: outside the path
-      if (!match_gaps && !coverage) r->PrintError("multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps, and coverage / density)!");
+      // count needs "some interval pair overlaps" (:1167-1172), which no sum of independent pieces gives: the device counts on the
+      // envelopes and settles the pairs with a multi-interval side one by one (`blocks_mode`, gtx_set_ref_blocks);
       if (!r->IsCompatibleSortedAndNonoverlapping()) r->PrintError("index regions should be compatible, sorted and non-overlapping!");   // :5607, :5853
-      if (!match_gaps) explode = true;
+      if (!match_gaps && coverage) explode = true;
+      if (!match_gaps && !coverage) blocks_mode = true;
     }
     if (!sorted && (i->START > r->I.back()->STOP || r->I.back()->STOP <= 0)) continue;   // :5609, :5659
     if (last_name && strcmp(last_name, i->CHROMOSOME) == 0) continue;
@@ -962,6 +975,25 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
     MD = first_piece[M];
     refs.swap(pieces);
   }
+  // `blocks_mode`: the intervals of every region, as gtx_set_ref_blocks takes them
+  std::vector<int64_t> blk_first; std::vector<int32_t> blk_iv;
+  if (blocks_mode) {
+    blk_first.assign((size_t)M + 1, 0);
+    for (long int k = 0; k < M; k++) {
+      blk_first[k] = (int64_t)(blk_iv.size() / 2);
+      GenomicRegion *r = IndexSet->R[k];
+      if (refs[3 * k] < 0 || r->I.size() == 1) { blk_iv.push_back(refs[3 * k + 1]); blk_iv.push_back(refs[3 * k + 2]); continue; }
+      long int prev_stop = LONG_MIN;
+      for (GenomicIntervalSet::iterator b = r->I.begin(); b != r->I.end(); b++) {
+        if ((*b)->START >= INT_MAX - 1 || (*b)->STOP >= INT_MAX - 1 || (*b)->START <= INT_MIN + 1 || (*b)->STOP <= INT_MIN + 1)
+          r->PrintError("coordinate does not fit the packed 32-bit representation of the MI355X path!");
+        if ((*b)->STOP < prev_stop) r->PrintError("multi-interval (BED12) region with an interval of negative size is outside the MI355X counting path!");
+        prev_stop = (*b)->STOP;
+        blk_iv.push_back((int32_t)(*b)->START); blk_iv.push_back((int32_t)(*b)->STOP);
+      }
+    }
+    blk_first[M] = (int64_t)(blk_iv.size() / 2);
+  }
   Mark("index packed");
   gtx_group *grp = NULL;
   const int n_classes = std::max(1, n_chrom * (strand_aware ? 2 : 1));
@@ -969,6 +1001,7 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
     grp = Devices();
     Mark("device ready");
     CheckGrp(grp, gtx_group_set_refs(grp, refs.data(), MD, n_classes, sorted ? GTX_REFS_KEEP_ZERO_LENGTH : 0));
+    if (blocks_mode) CheckGrp(grp, gtx_group_set_ref_blocks(grp, blk_first.data(), blk_iv.data()));
     Mark("gtx_set_refs done");
     CheckGrp(grp, cover ? gtx_group_coverage_begin(grp) : gtx_group_count_begin(grp));
   };
@@ -980,6 +1013,7 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   opt.max_label_value = max_label_value; opt.collect_zero_length = !coverage && sorted && zero_length_refs;
   opt.match_gaps = match_gaps;
   opt.explode_blocks = coverage && !match_gaps;                  // multi-interval queries: their intervals one by one (see the index side)
+  opt.collect_blocks = !coverage && !match_gaps;                 // ... or on a list of their own, for the pair kernel
   if (v < M) opt.guard = &guard;
   std::vector<int32_t> zero_len;
   unsigned long int *hits = new unsigned long int[M > 0 ? M : 1];
@@ -1021,6 +1055,11 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   DrainSet(QuerySet, opt, [&] { device_side(false); }, [&](const PackedBatch &b) {
     uint32_t flags = mode_flags | (LooksSorted(b.tri) ? GTX_READS_SORTED : 0);
     CheckGrp(grp, gtx_group_count_add(grp, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), flags));
+    if (!b.m_cnt.empty()) {                                       // the multi-interval queries of the batch
+      std::vector<int64_t> first(b.m_cnt.size() + 1, 0);
+      for (size_t i = 0; i < b.m_cnt.size(); i++) first[i + 1] = first[i] + b.m_cnt[i];
+      CheckGrp(grp, gtx_group_count_add_regions(grp, b.m_tri.data(), b.m_w.data(), first.data(), b.m_blocks.data(), (int64_t)b.m_cnt.size()));
+    }
     zero_len.insert(zero_len.end(), b.zero_len.begin(), b.zero_len.end());
   }, &text_sink);
   Mark("queries packed and enqueued");

@@ -566,6 +566,7 @@ struct alignas(128) Piece {          // one thread's share of a block
   const GtxView *gtx = nullptr; uint64_t rec0 = 0, rec1 = 0;   // ... or of a packed file: records [rec0, rec1)
   long first_line = 0; long n_lines = 0;
   std::vector<int32_t> tri, w, zero_len;
+  std::vector<int32_t> m_tri, m_w, m_cnt, m_blocks;   // collect_blocks (PackedBatch::m_*)
   std::vector<int32_t> tri_minus, w_minus;   // strand-aware runs: '-' reads are grouped behind the '+' reads of the batch
   // strand-blind runs write straight into the batch (room for one read per line was made there): no per-piece
   // buffer, no copy -- fresh memory is what packing costs (first-touch page faults do not run in parallel)
@@ -662,7 +663,11 @@ static inline bool HandleRecord(Piece *p, const PackOptions &o, const BedFields 
     if (p->err.set) return false;
     const bool minus = o.strand_aware && f.strand == '-';
     const int32_t cls = (int32_t)(id + (minus ? n_chrom : 0));
-    if (!p->cur_blocks.empty()) {                                        // (never in direct mode: PackPieces)
+    if (!p->cur_blocks.empty() && o.collect_blocks) {
+      p->m_tri.push_back(cls); p->m_tri.push_back((int32_t)f.start); p->m_tri.push_back((int32_t)f.stop);
+      p->m_w.push_back((int32_t)wv); p->m_cnt.push_back((int32_t)(p->cur_blocks.size() / 2));
+      for (long x : p->cur_blocks) p->m_blocks.push_back((int32_t)x);
+    } else if (!p->cur_blocks.empty()) {                                 // (never in direct mode: PackPieces)
       std::vector<int32_t> &dst = minus ? p->tri_minus : p->tri;
       for (size_t b = 0; b + 1 < p->cur_blocks.size(); b += 2) {
         dst.push_back(cls); dst.push_back((int32_t)p->cur_blocks[b]); dst.push_back((int32_t)p->cur_blocks[b + 1]);
@@ -729,13 +734,15 @@ void ParsePiece(Piece *p, const PackOptions &o)
       // a multi-interval region: under -gaps it is matched on its envelope [first interval's start, last interval's stop]
       // (genomic_intervals.cpp:5226, :5752, :5278); its intervals must be sorted and disjoint (:1153-1161, checked at :5709, :5880)
       const bool overlaps = o.mode == PACK_OVERLAPS_SORTED || o.mode == PACK_OVERLAPS_UNSORTED;
-      if (!overlaps || !(o.match_gaps || o.explode_blocks) || f.n_blocks < 1) { SetErr(&p->err, line_no, "multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps with -gaps, and coverage / density)!"); break; }
+      if (!overlaps || !(o.match_gaps || o.explode_blocks || o.collect_blocks) || f.n_blocks < 1) { SetErr(&p->err, line_no, "multi-interval (BED12) regions are outside the MI355X counting path (except genomic_overlaps count, coverage and density)!"); break; }
       std::vector<long> iv; BedBlocks(f, &iv);
       bool ok = true;
       for (size_t k = 2; k < iv.size(); k += 2) if (iv[k] < iv[k - 2] || iv[k] <= iv[k - 1]) ok = false;
       if (!ok) { SetErr(&p->err, line_no, "query regions should be compatible, sorted and non-overlapping!"); break; }
+      if (o.collect_blocks) for (size_t k = 3; k < iv.size(); k += 2) if (iv[k] < iv[k - 2]) ok = false;     // (a block of negative size)
+      if (!ok) { SetErr(&p->err, line_no, "multi-interval (BED12) region with an interval of negative size is outside the MI355X counting path!"); break; }
       f.start = iv.front(); f.stop = iv.back();
-      if (o.explode_blocks && iv.size() > 2) {
+      if ((o.explode_blocks || o.collect_blocks) && iv.size() > 2) {
         for (long x : iv) if (x >= INT_MAX - 1 || x <= INT_MIN + 1) { SetErr(&p->err, line_no, "coordinate does not fit the packed 32-bit representation of the MI355X path!"); break; }
         if (p->err.set) break;
         p->cur_blocks.swap(iv);
@@ -876,6 +883,8 @@ bool BedPacker::PackPieces(void *pieces_ptr, long first_line, PackedBatch *out, 
     if (weighted) out->w.resize(base_w + wpos);
     for (int t = 0; t < T; t++) {
       out->zero_len.insert(out->zero_len.end(), pieces[t].zero_len.begin(), pieces[t].zero_len.end());
+      out->m_tri.insert(out->m_tri.end(), pieces[t].m_tri.begin(), pieces[t].m_tri.end()); out->m_w.insert(out->m_w.end(), pieces[t].m_w.begin(), pieces[t].m_w.end());
+      out->m_cnt.insert(out->m_cnt.end(), pieces[t].m_cnt.begin(), pieces[t].m_cnt.end()); out->m_blocks.insert(out->m_blocks.end(), pieces[t].m_blocks.begin(), pieces[t].m_blocks.end());
       out->n_lines += pieces[t].n_lines;
       out->label_sum += pieces[t].label_sum;
     }
@@ -900,6 +909,8 @@ bool BedPacker::PackPieces(void *pieces_ptr, long first_line, PackedBatch *out, 
   }
   for (int t = 0; t < T; t++) {
     out->zero_len.insert(out->zero_len.end(), pieces[t].zero_len.begin(), pieces[t].zero_len.end());
+    out->m_tri.insert(out->m_tri.end(), pieces[t].m_tri.begin(), pieces[t].m_tri.end()); out->m_w.insert(out->m_w.end(), pieces[t].m_w.begin(), pieces[t].m_w.end());
+    out->m_cnt.insert(out->m_cnt.end(), pieces[t].m_cnt.begin(), pieces[t].m_cnt.end()); out->m_blocks.insert(out->m_blocks.end(), pieces[t].m_blocks.begin(), pieces[t].m_blocks.end());
     out->n_lines += pieces[t].n_lines;
     out->label_sum += pieces[t].label_sum;
   }
@@ -908,7 +919,7 @@ bool BedPacker::PackPieces(void *pieces_ptr, long first_line, PackedBatch *out, 
 
 bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
 {
-  out->tri.clear(); out->w.clear(); out->zero_len.clear(); out->n_lines = 0; out->label_sum = 0;    // (the batch object is the caller's and is reused)
+  out->clear();    // (the batch object is the caller's and is reused)
   out->tri.reserve(target_reads * 3 + (24u << 20));       // one allocation; its pages are first touched by the copy threads
   if (opt_.max_label_value > 1) out->w.reserve(target_reads + (8u << 20));
   if (primed_set_) {
@@ -955,7 +966,7 @@ bool BedPacker::NextBatch(PackedBatch *out, size_t target_reads, PackError *err)
 
 bool BedPacker::PackPrimedText(PackedBatch *out, PackError *err)
 {
-  out->tri.clear(); out->w.clear(); out->zero_len.clear(); out->n_lines = 0; out->label_sum = 0;
+  out->clear();
   if (!primed_set_) return true;
   primed_set_ = false;
   const bool ok = PackBlock(primed_.data(), primed_.size(), primed_first_line_, out, err);

@@ -144,6 +144,8 @@ struct PackOptions {
                                      // (genomic_intervals.cpp:5226, :5752); without it they are outside the path, unless ...
   bool explode_blocks = false;       // ... coverage without -gaps: CalcOverlap is a sum over ALL interval pairs (:1196-1202, :5278), so
                                      // every interval of a region goes out as a read of its own with the region's label value
+  bool collect_blocks = false;       // ... count without -gaps: "some interval overlaps some interval" (:1167-1172) -- a region with several
+                                     // intervals goes out on its own list (PackedBatch::m_*), after the same checks as any other region
   int threads = 0;                   // 0 = hardware concurrency
   IndexGuard *guard = nullptr;       // PACK_OVERLAPS_SORTED with an out-of-order index set (forces one thread)
 };
@@ -187,6 +189,11 @@ struct PackedBatch {
   RawVec tri;                        // 3 per read
   RawVec w;                          // empty unless max_label_value > 1
   std::vector<int32_t> zero_len;     // (class, start, weight) triples, see collect_zero_length
+  // collect_blocks: the multi-interval regions of the batch -- (class, envelope start, envelope stop) triples, label values,
+  // interval counts, and the (start, stop) pairs of their intervals one region after the other
+  std::vector<int32_t> m_tri, m_w, m_cnt, m_blocks;
+  bool empty() const { return tri.empty() && m_cnt.empty(); }
+  void clear() { tri.clear(); w.clear(); zero_len.clear(); m_tri.clear(); m_w.clear(); m_cnt.clear(); m_blocks.clear(); n_lines = 0; label_sum = 0; }
   int64_t n_lines = 0;               // lines consumed (regions seen), including dropped ones
   int64_t label_sum = 0;             // sum of GetLabelValue(max_label_value) over ALL regions seen (CountGenomicRegions, genomic_intervals.cpp:6206-6214)
 };

@@ -15,6 +15,7 @@
 #include <vector>
 #include "gtx.h"
 #include "gtx_kernels.h"
+#include "gtx_pairs.h"
 #include "gtx_text.h"
 
 typedef unsigned long long u64;
@@ -67,6 +68,14 @@ struct gtx_ctx {
   int specialMode = 0;                  // value of a pair in the open call: 0 count, 2 the -gaps coverage formula
   bool tileSumsValid = true;           // every kernel since the last finalize maintained the tile sums
   int64_t histLen = 0;
+  // count without -gaps over multi-interval regions (gtx_pairs.hip): envelope indexes over the multi-interval index regions
+  // (reads with one interval are checked against them batch by batch) and over all regions (made on the first multi-interval
+  // read), the regions' interval lists, and the two correction vectors add[nRefs] | sub[nRefs] (zero between calls)
+  struct PairIdx { int *d_mem = nullptr; int n = 0; bool built = false; gtx::PairIndex ix = {}; };
+  PairIdx pairMulti, pairAll;
+  int2 *d_blkOf = nullptr, *d_blkIv = nullptr; bool refBlocks = false;
+  u64 *d_pairAcc = nullptr; bool pairUsed = false;
+  int4 *d_pairQ = nullptr; size_t capPairQ = 0, capPairIv = 0; int2 *d_pairQBlk = nullptr, *d_pairQIv = nullptr;
 
   gtx::DevInfo *d_info = nullptr;       // 2 blocks: the finalize of one call resets the block of the next
   int infoCur = 0;
@@ -239,6 +248,7 @@ void gtx_destroy(gtx_ctx *c)
   for (auto &p : c->d_cov) dfree(p);
   dfree(c->d_sortedT); dfree(c->d_segT); dfree(c->d_topT); dfree(c->d_posTE); dfree(c->d_posTS); dfree(c->d_classBaseT);
   dfree(c->d_refS); dfree(c->d_refE); dfree(c->d_refC); dfree(c->d_specialRefs); dfree(c->d_specialIdx); dfree(c->d_specialOut); dfree(c->d_side); dfree(c->d_sideCount);
+  dfree(c->pairMulti.d_mem); dfree(c->pairAll.d_mem); dfree(c->d_blkOf); dfree(c->d_blkIv); dfree(c->d_pairAcc); dfree(c->d_pairQ); dfree(c->d_pairQBlk); dfree(c->d_pairQIv);
   if (c->h_info) (void)hipHostFree(c->h_info);
   for (auto &slot : c->evRing) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
   delete c;
@@ -462,6 +472,8 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
       HIPCHK(c, hipMemset(c->d_specialOut, 0, sizeof(u64) * sp.size()));
     }
   }
+  dfree(c->pairMulti.d_mem); dfree(c->pairAll.d_mem); dfree(c->d_blkOf); dfree(c->d_blkIv); dfree(c->d_pairAcc);
+  c->pairMulti = gtx_ctx::PairIdx(); c->pairAll = gtx_ctx::PairIdx(); c->refBlocks = false; c->pairUsed = false;
   c->nRefs = m; c->nValid = nv; c->nClasses = nClasses; c->histLen = histLen;
   c->h_seg = seg;
   c->shareOn = false; dfree(c->d_shareTiles); dfree(c->d_shareRegions); c->nShareTiles = 0; c->nShareRegions = 0; c->shareOffset = 0;
@@ -607,6 +619,17 @@ static int merge_prepare(gtx_ctx *c, uint32_t flags, int mode)
   return GTX_OK;
 }
 
+// after the count kernels of one batch, multi-interval index regions (gtx_set_ref_blocks): a read with one interval that lies in
+// a gap of such a region was counted on the region's envelope -- off again
+static int pairs_batch(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n)
+{
+  if (c->pairMulti.n > 0) {
+    HIPCHK(c, gtx::launch_pair_miss(d_reads, d_weights, n, c->pairMulti.ix, gtx::RegionBlocks{c->d_blkOf, c->d_blkIv}, c->d_pairAcc + c->nRefs, c->stream));
+    c->pairUsed = true;
+  }
+  return GTX_OK;
+}
+
 // after the kernels of one batch: the batch against the inverted reference regions
 static int merge_batch(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n)
 {
@@ -617,6 +640,10 @@ static int merge_batch(gtx_ctx *c, const void *d_reads, const void *d_weights, i
 // after the gather: the inverted reads against the other regions, then the inverted regions' sums into their places
 static int merge_end(gtx_ctx *c, void *d_out)
 {
+  if (c->pairUsed) {
+    c->pairUsed = false;
+    HIPCHK(c, gtx::launch_pair_apply((u64 *)d_out, c->d_pairAcc, c->d_pairAcc + c->nRefs, c->nRefs, c->stream));
+  }
   if (!c->sideUsed) return GTX_OK;
   c->sideUsed = false;
   HIPCHK(c, gtx::launch_side_reads(c->d_refC, c->d_refS, c->d_refE, c->nRefs, c->d_side, c->d_sideCount, c->sideCap, c->specialMode, (u64 *)d_out,
@@ -641,7 +668,8 @@ static int count_begin(gtx_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_sideCount, 0, sizeof(unsigned), c->stream));
     if (c->nSpecial) HIPCHK(c, hipMemsetAsync(c->d_specialOut, 0, sizeof(u64) * c->nSpecial, c->stream));
   }
-  c->sideUsed = false;
+  if (c->histDirty && c->d_pairAcc) HIPCHK(c, hipMemsetAsync(c->d_pairAcc, 0, sizeof(u64) * 2 * (size_t)std::max<int64_t>(c->nRefs, 1), c->stream));
+  c->sideUsed = false; c->pairUsed = false;
   c->histDirty = true; c->tileSumsValid = true;
   return GTX_OK;
 }
@@ -675,6 +703,7 @@ int gtx_count_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int
   if (streaming) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), true, c->stream));
   else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n)); if (rc) return rc; }
   rc = merge_batch(c, d_reads, d_weights, n); if (rc) return rc;
+  rc = pairs_batch(c, d_reads, d_weights, n); if (rc) return rc;
   if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   rc = count_end(c, d_hits); if (rc) return rc;
   if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
@@ -831,6 +860,7 @@ int gtx_count_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int6
     if (!streaming) c->tileSumsValid = false;
     if (streaming) HIPCHK(c, gtx::launch_count(dR, dW, cnt, count_args(c, flags, cnt, seen + off), true, c->stream));
     else { int rcu = launch_unsorted(c, dR, dW, cnt, count_args(c, flags, cnt, seen + off)); if (rcu) return rcu; }
+    { int rcp = pairs_batch(c, dR, dW, cnt); if (rcp) return rcp; }
     return merge_batch(c, dR, dW, cnt);
   });
   if (rc) return rc;
@@ -844,6 +874,7 @@ int gtxi_count_finish(gtx_ctx *c, void **d_out, int share)
 {
   if (!c->streamOpen) return fail(c, GTX_E_STATE, "gtx_count_end: gtx_count_begin has not been called");
   if (share && !c->shareOn) return fail(c, GTX_E_STATE, "gtxi_count_finish: no share set");
+  if (share && (c->refBlocks || c->pairUsed)) return fail(c, GTX_E_STATE, "gtxi_count_finish: multi-interval regions are finalized over the whole vector");
   HIPCHK(c, hipSetDevice(c->device));
   c->streamOpen = false;
   int rc = ensure_out(c, (size_t)c->nRefs); if (rc) return rc;
@@ -883,6 +914,139 @@ int gtx_count(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t 
   rc = gtx_count_add(c, reads, weights, n, flags); if (rc) { c->streamOpen = false; return rc; }
   return gtx_count_end(c, hits, info);
 }
+
+// ---------------------------------------------------------------------------------------------
+// count without -gaps over multi-interval regions (gtx_pairs.hip)
+// ---------------------------------------------------------------------------------------------
+} // extern "C"
+
+// the envelopes of the regions `pick` selects, per class in the order of their starts, with the running and the per-64 maxima
+// of their ends.  Which regions take part at all follows gtx_set_refs (placeholders and, under the bin index's rules, regions
+// with start > stop or stop <= 0 never match); under the sorted merge's rules every region with a class does, inverted or not:
+// the envelope test below is the merge's own (CalcDirection == 0, genomic_intervals.cpp:1225-1236).
+template <class Pick>
+static int build_pair_index(gtx_ctx *c, gtx_ctx::PairIdx *out, Pick pick)
+{
+  dfree(out->d_mem); *out = gtx_ctx::PairIdx();
+  struct Item { int32_t cls, s, e, k; };
+  std::vector<Item> it;
+  for (int64_t k = 0; k < c->nRefs; k++) {
+    const int32_t cl = c->h_refC[k], s = c->h_refS[k], e = c->h_refE[k];
+    if (cl < 0 || !(c->mergeRefs || !(s > e || e <= 0)) || !pick(k)) continue;
+    it.push_back({cl, s, e, (int32_t)k});
+  }
+  std::sort(it.begin(), it.end(), [](const Item &a, const Item &b) { return a.cls != b.cls ? a.cls < b.cls : (a.s != b.s ? a.s < b.s : a.k < b.k); });
+  const size_t n = it.size(), nb = (n + 63) / 64, nc = (size_t)c->nClasses;
+  std::vector<int32_t> mem(nc + 1 + 4 * n + nb + 1, 0);
+  int32_t *seg = mem.data(), *st = seg + nc + 1, *en = st + n, *pm = en + n, *bm = pm + n, *id = bm + nb;
+  for (size_t i = 0; i < n; i++) seg[it[i].cls + 1]++;
+  for (size_t cl = 0; cl < nc; cl++) seg[cl + 1] += seg[cl];
+  for (size_t i = 0; i < nb; i++) bm[i] = INT32_MIN;
+  for (size_t i = 0; i < n; i++) {
+    st[i] = it[i].s; en[i] = it[i].e; id[i] = it[i].k;
+    pm[i] = (i > 0 && it[i - 1].cls == it[i].cls) ? std::max(pm[i - 1], it[i].e) : it[i].e;
+    bm[i >> 6] = std::max(bm[i >> 6], it[i].e);
+  }
+  HIPCHK(c, hipMalloc(&out->d_mem, sizeof(int32_t) * mem.size()));
+  HIPCHK(c, hipMemcpy(out->d_mem, mem.data(), sizeof(int32_t) * mem.size(), hipMemcpyHostToDevice));
+  int *d = out->d_mem;
+  out->ix = gtx::PairIndex{d, d + nc + 1, d + nc + 1 + n, d + nc + 1 + 2 * n, d + nc + 1 + 3 * n, d + nc + 1 + 3 * n + nb, c->nClasses};
+  out->n = (int)n; out->built = true;
+  return GTX_OK;
+}
+
+static int pair_acc(gtx_ctx *c)
+{
+  if (c->d_pairAcc) return GTX_OK;
+  const size_t bytes = sizeof(u64) * 2 * (size_t)std::max<int64_t>(c->nRefs, 1);
+  HIPCHK(c, hipMalloc(&c->d_pairAcc, bytes));
+  HIPCHK(c, hipMemset(c->d_pairAcc, 0, bytes));
+  return GTX_OK;
+}
+
+// {start, stop} lists as the kernels need them: starts and stops both non-decreasing (sorted, disjoint intervals are)
+static bool blocks_monotone(const int32_t *b, int64_t cnt)
+{
+  for (int64_t j = 1; j < cnt; j++) if (b[2 * j] < b[2 * j - 2] || b[2 * j + 1] < b[2 * j - 1]) return false;
+  return true;
+}
+
+extern "C" {
+
+int gtx_set_ref_blocks(gtx_ctx *c, const int64_t *first, const int32_t *blocks)
+{
+  if (!c) return GTX_E_ARG;
+  if (c->nRefs < 0) return fail(c, GTX_E_STATE, "gtx_set_ref_blocks: gtx_set_refs has not been called");
+  if (c->streamOpen || c->covOpen) return fail(c, GTX_E_STATE, "gtx_set_ref_blocks: a call is open");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  dfree(c->pairMulti.d_mem); dfree(c->pairAll.d_mem); dfree(c->d_blkOf); dfree(c->d_blkIv);
+  c->pairMulti = gtx_ctx::PairIdx(); c->pairAll = gtx_ctx::PairIdx(); c->refBlocks = false;
+  if (!first) return GTX_OK;                                   // back to single-interval regions
+  const int64_t m = c->nRefs;
+  if (first[0] != 0) return fail(c, GTX_E_ARG, "gtx_set_ref_blocks: first[0] must be 0");
+  if (first[m] >= INT32_MAX || (first[m] > 0 && !blocks)) return fail(c, GTX_E_ARG, "gtx_set_ref_blocks: bad argument");
+  std::vector<int2> blkOf((size_t)std::max<int64_t>(m, 1), make_int2(0, 0)), iv;
+  for (int64_t k = 0; k < m; k++) {
+    const int64_t cnt = first[k + 1] - first[k];
+    if (cnt < 1) return fail(c, GTX_E_ARG, "gtx_set_ref_blocks: every region has at least one interval");
+    const int32_t *b = blocks + 2 * first[k];
+    if (c->h_refC[k] >= 0 && (b[0] != c->h_refS[k] || b[2 * cnt - 1] != c->h_refE[k]))
+      return fail(c, GTX_E_ARG, "gtx_set_ref_blocks: a region's triple must be its envelope (first interval's start, last interval's stop)");
+    if (cnt == 1 || c->h_refC[k] < 0) continue;
+    if (!blocks_monotone(b, cnt)) return fail(c, GTX_E_RANGE, "gtx_set_ref_blocks: the intervals of a region must be sorted (starts and stops non-decreasing)");
+    blkOf[k] = make_int2((int)iv.size(), (int)cnt);
+    for (int64_t j = 0; j < cnt; j++) iv.push_back(make_int2(b[2 * j], b[2 * j + 1]));
+  }
+  if (iv.empty()) return GTX_OK;                               // no multi-interval region: nothing to correct
+  HIPCHK(c, hipMalloc(&c->d_blkOf, sizeof(int2) * blkOf.size()));
+  HIPCHK(c, hipMalloc(&c->d_blkIv, sizeof(int2) * iv.size()));
+  HIPCHK(c, hipMemcpy(c->d_blkOf, blkOf.data(), sizeof(int2) * blkOf.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_blkIv, iv.data(), sizeof(int2) * iv.size(), hipMemcpyHostToDevice));
+  int rc = build_pair_index(c, &c->pairMulti, [&](int64_t k) { return blkOf[k].y > 0; }); if (rc) return rc;
+  rc = pair_acc(c); if (rc) return rc;
+  c->refBlocks = true;
+  return GTX_OK;
+}
+
+int gtx_count_add_regions(gtx_ctx *c, const int32_t *env, const int32_t *weights, const int64_t *first, const int32_t *blocks, int64_t n)
+{
+  if (!c) return GTX_E_ARG;
+  if (!c->streamOpen) return fail(c, GTX_E_STATE, "gtx_count_add_regions: gtx_count_begin has not been called");
+  if (n < 0 || (n > 0 && (!env || !first || !blocks))) return fail(c, GTX_E_ARG, "gtx_count_add_regions: bad argument");
+  if (n == 0) return GTX_OK;
+  if (first[0] != 0 || first[n] >= INT32_MAX) return fail(c, GTX_E_ARG, "gtx_count_add_regions: bad interval lists");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<int4> q((size_t)n); std::vector<int2> qb((size_t)n), iv((size_t)first[n]);
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t cnt = first[i + 1] - first[i];
+    if (cnt < 1) return fail(c, GTX_E_ARG, "gtx_count_add_regions: every region has at least one interval");
+    const int32_t *b = blocks + 2 * first[i];
+    if (b[0] != env[3 * i + 1] || b[2 * cnt - 1] != env[3 * i + 2]) return fail(c, GTX_E_ARG, "gtx_count_add_regions: a region's triple must be its envelope");
+    if (!blocks_monotone(b, cnt)) return fail(c, GTX_E_RANGE, "gtx_count_add_regions: the intervals of a region must be sorted (starts and stops non-decreasing)");
+    q[i] = make_int4(env[3 * i], env[3 * i + 1], env[3 * i + 2], weights ? weights[i] : 1);
+    qb[i] = make_int2((int)first[i], (int)cnt);
+    for (int64_t j = 0; j < cnt; j++) iv[first[i] + j] = make_int2(b[2 * j], b[2 * j + 1]);
+  }
+  if (!c->pairAll.built) { int rc = build_pair_index(c, &c->pairAll, [](int64_t) { return true; }); if (rc) return rc; }
+  { int rc = pair_acc(c); if (rc) return rc; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));                  // (the kernel of the previous call may still read the query buffers)
+  if ((size_t)n > c->capPairQ) {
+    dfree(c->d_pairQ); dfree(c->d_pairQBlk); c->capPairQ = 0;
+    HIPCHK(c, hipMalloc(&c->d_pairQ, sizeof(int4) * (size_t)n)); HIPCHK(c, hipMalloc(&c->d_pairQBlk, sizeof(int2) * (size_t)n));
+    c->capPairQ = (size_t)n;
+  }
+  if (iv.size() > c->capPairIv) { dfree(c->d_pairQIv); c->capPairIv = 0; HIPCHK(c, hipMalloc(&c->d_pairQIv, sizeof(int2) * iv.size())); c->capPairIv = iv.size(); }
+  HIPCHK(c, hipMemcpy(c->d_pairQ, q.data(), sizeof(int4) * (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_pairQBlk, qb.data(), sizeof(int2) * (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_pairQIv, iv.data(), sizeof(int2) * iv.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, gtx::launch_pair_hit(c->d_pairQ, c->d_pairQBlk, c->d_pairQIv, n, c->pairAll.ix, gtx::RegionBlocks{c->refBlocks ? c->d_blkOf : nullptr, c->d_blkIv},
+                                 c->d_pairAcc, c->stream));
+  c->pairUsed = true;
+  return GTX_OK;
+}
+
+int gtxi_pairs_on(gtx_ctx *c) { return c && (c->refBlocks || c->pairUsed) ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------
 // coverage
@@ -1561,6 +1725,7 @@ static int add_text(gtx_ctx *c, bool coverage, const char *text, size_t bytes, i
     if (!streaming) c->tileSumsValid = false;
     if (streaming) HIPCHK(c, gtx::launch_count(triOut, dW, nLines, count_args(c, flags & ~GTX_CHECK_SORTED, nLines, seen), true, c->stream));
     else { rc = launch_unsorted(c, triOut, dW, nLines, count_args(c, flags, nLines, seen)); if (rc) return rc; }
+    rc = pairs_batch(c, triOut, dW, nLines); if (rc) return rc;
   }
   rc = merge_batch(c, triOut, dW, nLines); if (rc) return rc;
   HIPCHK(c, hipEventRecord(t.evConsumed, c->stream));
@@ -1621,6 +1786,7 @@ int gtxi_set_share(gtx_ctx *c, const uint8_t *owned, int32_t nClasses, const int
 int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, void **d_piece, int64_t *pieceLen)
 {
   if (!c->shareOn) return fail(c, GTX_E_STATE, "gtxi_count_device_share: no share set");
+  if (c->refBlocks) return fail(c, GTX_E_STATE, "gtx_group_count_device: multi-interval regions (gtx_set_ref_blocks) are outside the members' shares");
   if (n < 0 || (n > 0 && !d_reads)) return fail(c, GTX_E_ARG, "gtx_group_count_device: bad argument");
   if (flags & GTX_ZERO_LENGTH_OK) return fail(c, GTX_E_ARG, "gtx_group_count_device: GTX_ZERO_LENGTH_OK (sorted-merge semantics with their host-side corrections) is served by the host-buffer group calls only");
   HIPCHK(c, hipSetDevice(c->device));

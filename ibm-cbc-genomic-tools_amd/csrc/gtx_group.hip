@@ -109,6 +109,7 @@ struct gtx_group {
   std::vector<int32_t> owner;              // class -> member
   std::vector<int64_t> memberReads;        // reads routed to each member in the open call
   bool countOpen = false, coverOpen = false;
+  unsigned long long regionsTurn = 0;                 // gtx_group_count_add_regions: next member
   bool rehearse = false;                   // GTX_GROUP_REHEARSE=1
   bool selfExchange = false;               // GTX_GROUP_SELF_EXCHANGE=1 (test hook): member 0's own piece travels through RCCL to itself
   int64_t nRefs = 0; uint32_t refFlags = 0; int32_t nClasses = 0;
@@ -596,7 +597,9 @@ static int finish(gtx_group *g, bool coverage, uint64_t *out, gtx_count_info *in
   { int rc = wait_exchanges(g); if (rc) return rc; }
   std::vector<void *> d(n, nullptr);
   // count on a plain reference set: every member finalizes its own classes into its piece of the compact vector
-  const bool pieces = !coverage && !(g->refFlags & GTX_REFS_KEEP_ZERO_LENGTH);
+  bool pairs = false;                                            // multi-interval regions: corrections go into a member's whole vector
+  for (int i = 0; i < n; i++) pairs = pairs || gtxi_pairs_on(g->ctx[i]);
+  const bool pieces = !coverage && !(g->refFlags & GTX_REFS_KEEP_ZERO_LENGTH) && !pairs;
   if (pieces) { int rc = ensure_plan(g); if (rc) return rc; }
   for (int i = 0; i < n; i++) GCHK_CTX(g, i, coverage ? gtxi_coverage_finish(g->ctx[i], &d[i]) : gtxi_count_finish(g->ctx[i], &d[i], pieces ? 1 : 0));
   GCHK_HIP(g, hipSetDevice(g->dev[0]));
@@ -650,6 +653,25 @@ int gtx_group_count_add(gtx_group *g, const int32_t *reads, const int32_t *weigh
     GCHK_CTX(g, m, gtx_count_add(g->ctx[m], r, w, cnt, flags));
     return GTX_OK;
   });
+}
+
+int gtx_group_set_ref_blocks(gtx_group *g, const int64_t *first, const int32_t *blocks)
+{
+  if (!g) return GTX_E_ARG;
+  for (size_t i = 0; i < g->ctx.size(); i++) GCHK_CTX(g, i, gtx_set_ref_blocks(g->ctx[i], first, blocks));
+  return GTX_OK;
+}
+
+// multi-interval queries are a side channel (one lane per query against the whole reference set, which every member holds):
+// they go to the members in turn, whatever their class
+int gtx_group_count_add_regions(gtx_group *g, const int32_t *env, const int32_t *weights, const int64_t *first, const int32_t *blocks, int64_t n)
+{
+  if (!g) return GTX_E_ARG;
+  if (!g->countOpen) return gfail(g, GTX_E_STATE, "gtx_group_count_add_regions: gtx_group_count_begin has not been called");
+  if (n <= 0) return n < 0 ? gfail(g, GTX_E_ARG, "gtx_group_count_add_regions: bad argument") : GTX_OK;
+  const int m = (int)(g->regionsTurn++ % g->ctx.size());
+  GCHK_CTX(g, m, gtx_count_add_regions(g->ctx[m], env, weights, first, blocks, n));
+  return GTX_OK;
 }
 
 int gtx_group_count_end(gtx_group *g, uint64_t *hits, gtx_count_info *info)

@@ -18,5 +18,6 @@ int gtxi_scratch(gtx_ctx *c, size_t bytes, void **p);   // a second device buffe
 int gtxi_wait_direct(gtx_ctx *c);                       // the previous host-buffer call's DMA out of page-locked caller memory is done
 hipStream_t gtxi_stream(gtx_ctx *c);
 int gtxi_device(gtx_ctx *c);
+int gtxi_pairs_on(gtx_ctx *c);                           // multi-interval regions declared, or multi-interval queries added to the open call
 void gtxi_set_error(gtx_ctx *c, const char *msg);
 }

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kLines) void text_parse_kernel(ParseArgs a)
     if (plain && a.sortedRules) {
       bool before = false, havePrev = true;
       const unsigned char *pn; unsigned pl; int ps; long long pstart;
-      long long q2, q3, ql; int qn, qs = '+'; unsigned qlen = 0;
+      long long q2 = 0, q3 = 0, ql = 0; int qn = 0, qs = '+'; unsigned qlen = 0;
       if (j > j0) {
         const unsigned pb = (unsigned)((j - 1 ? (size_t)a.nl[j - 2] + 1 : 0) - a0), pe = (unsigned)((size_t)a.nl[j - 1] - a0);
         if (!parse_line((const unsigned char *)lds, pb, pe, false, q2, q3, qn, qlen, qs, ql)) havePrev = false;   // (that line voids the block anyway)

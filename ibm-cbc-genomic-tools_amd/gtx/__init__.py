@@ -99,6 +99,10 @@ ABI = {
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32,
                                       ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_group_member_reads": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_set_ref_blocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_count_add_regions": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    "gtx_group_set_ref_blocks": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_group_count_add_regions": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     "gtx_count_add_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "gtx_coverage_add_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "gtx_text_result": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -209,13 +213,32 @@ class Engine:
         self._chk(self.lib.gtx_set_refs_ex(self.ctx, _ptr(refs), refs.shape[0], int(n_classes), int(flags)))
         self.n_refs = refs.shape[0]
 
-    def count_stream(self, batches, flags=READS_SORTED):
-        """gtx_count_begin / _add per (reads, weights) batch / _end."""
+    def set_ref_blocks(self, first=None, blocks=None):
+        """gtx_set_ref_blocks: region k's intervals are blocks[first[k]:first[k+1]] ((start, stop) rows); None: envelopes only."""
+        if first is None:
+            self._chk(self.lib.gtx_set_ref_blocks(self.ctx, None, None))
+            return
+        first = np.ascontiguousarray(first, dtype=np.int64)
+        blocks = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 2)
+        if len(first) != self.n_refs + 1 or first[-1] != len(blocks):
+            raise GtxError("set_ref_blocks: first must have n_refs + 1 entries and end at len(blocks)")
+        self._chk(self.lib.gtx_set_ref_blocks(self.ctx, _ptr(first), _ptr(blocks)))
+
+    def count_stream(self, batches, flags=READS_SORTED, regions=()):
+        """gtx_count_begin / _add per (reads, weights) batch / _add_regions per (env_triples, weights, first, blocks) / _end."""
         self._chk(self.lib.gtx_count_begin(self.ctx))
         for reads, w in batches:
             reads = _triples(reads)
             w = None if w is None else np.ascontiguousarray(w, dtype=np.int32)
             self._chk(self.lib.gtx_count_add(self.ctx, _ptr(reads), _ptr(w), reads.shape[0], int(flags)))
+        for env, w, first, blocks in regions:
+            env = _triples(env)
+            w = None if w is None else np.ascontiguousarray(w, dtype=np.int32)
+            first = np.ascontiguousarray(first, dtype=np.int64)
+            blocks = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 2)
+            if len(first) != env.shape[0] + 1 or first[-1] != len(blocks):
+                raise GtxError("count_stream: first must have n + 1 entries and end at len(blocks)")
+            self._chk(self.lib.gtx_count_add_regions(self.ctx, _ptr(env), _ptr(w), _ptr(first), _ptr(blocks), env.shape[0]))
         hits = np.zeros(max(self.n_refs, 1), dtype=np.uint64)
         info = CountInfo()
         self._chk(self.lib.gtx_count_end(self.ctx, _ptr(hits), ctypes.byref(info)))
@@ -403,20 +426,34 @@ class Group:
         self._chk(self.lib.gtx_group_set_refs(self.g, _ptr(refs), refs.shape[0], int(n_classes), int(flags)))
         self.n_refs = refs.shape[0]
 
-    def _reduce(self, kind, batches, flags):
+    def set_ref_blocks(self, first=None, blocks=None):
+        if first is None:
+            self._chk(self.lib.gtx_group_set_ref_blocks(self.g, None, None))
+            return
+        first = np.ascontiguousarray(first, dtype=np.int64)
+        blocks = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 2)
+        self._chk(self.lib.gtx_group_set_ref_blocks(self.g, _ptr(first), _ptr(blocks)))
+
+    def _reduce(self, kind, batches, flags, regions=()):
         begin, add, end = [getattr(self.lib, "gtx_group_%s_%s" % (kind, x)) for x in ("begin", "add", "end")]
         self._chk(begin(self.g))
         for reads, w in batches:
             reads = _triples(reads)
             w = None if w is None else np.ascontiguousarray(w, dtype=np.int32)
             self._chk(add(self.g, _ptr(reads), _ptr(w), reads.shape[0], int(flags)))
+        for env, w, first, blocks in regions:
+            env = _triples(env)
+            w = None if w is None else np.ascontiguousarray(w, dtype=np.int32)
+            first = np.ascontiguousarray(first, dtype=np.int64)
+            blocks = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 2)
+            self._chk(self.lib.gtx_group_count_add_regions(self.g, _ptr(env), _ptr(w), _ptr(first), _ptr(blocks), env.shape[0]))
         out = np.zeros(max(self.n_refs, 1), dtype=np.uint64)
         info = CountInfo()
         self._chk(end(self.g, _ptr(out), ctypes.byref(info)))
         return out[:self.n_refs], info.as_dict()
 
-    def count(self, batches, flags=READS_SORTED):
-        return self._reduce("count", batches, flags)
+    def count(self, batches, flags=READS_SORTED, regions=()):
+        return self._reduce("count", batches, flags, regions)
 
     def coverage(self, batches, flags=0):
         return self._reduce("coverage", batches, flags)

@@ -171,6 +171,27 @@ int gtx_count_device(gtx_ctx *ctx, const void *d_read_triples, const void *d_wei
 /* Result of the most recent *_device call (synchronises the stream). */
 int gtx_last_info(gtx_ctx *ctx, gtx_count_info *info);
 
+/* ---- count over multi-interval (BED12) regions, match_gaps = false ------------------------ */
+
+/* CountIndexOverlaps counts a query once for an index region when GetMatch / NextMatch deliver the pair -- their envelopes
+ * (first interval's start .. last interval's stop) overlap, genomic_intervals.cpp:5752 -- and GenomicRegion::OverlapsWith holds:
+ * SOME interval of the one overlaps SOME interval of the other (:1167-1172, :5226-5232).  With match_gaps = true the envelope
+ * alone decides, and a caller simply hands over envelopes as triples.  Without it:
+ *
+ * gtx_set_ref_blocks declares the intervals of the index regions given to gtx_set_refs[_ex] (whose triples must be the
+ * envelopes): region k's intervals are blocks[2 * first[k]] .. blocks[2 * first[k+1] - 1] as (start, stop) pairs, sorted and
+ * disjoint as IsCompatibleSortedAndNonoverlapping demands (:1153-1161; GTX_E_RANGE when starts or stops decrease).  From then
+ * on every count call of the context (gtx_count*, gtx_count_device, gtx_count_add_text) takes the reads that lie in a gap of a
+ * multi-interval region off that region's count again.  first == NULL: back to envelopes only.  gtx_set_refs clears it.
+ *
+ * gtx_count_add_regions adds multi-interval QUERIES to an open count stream (gtx_count_begin): env_triples are their
+ * (class, envelope start, envelope stop), first / blocks their intervals as above; each is counted once for every index region
+ * one of its intervals overlaps.  They never enter the streaming kernel (a side channel: one lane per query, candidates from
+ * the index regions' envelopes in the order of their starts). */
+int gtx_set_ref_blocks(gtx_ctx *ctx, const int64_t *first /* n_refs + 1, or NULL */, const int32_t *blocks);
+int gtx_count_add_regions(gtx_ctx *ctx, const int32_t *env_triples, const int32_t *weights /* may be NULL */,
+                          const int64_t *first /* n + 1 */, const int32_t *blocks, int64_t n);
+
 /* ---- genomic_overlaps coverage / density ------------------------------------------------- */
 
 /* Replaces GenomicRegionSetOverlaps::CalcIndexCoverage (genomic_intervals.cpp:5269-5285, decl
@@ -289,6 +310,10 @@ int gtx_group_last_info(gtx_group *g, gtx_count_info *info);
 int gtx_group_count_begin(gtx_group *g);
 int gtx_group_count_add(gtx_group *g, const int32_t *read_triples, const int32_t *weights, int64_t n_reads, uint32_t flags);
 int gtx_group_count_end(gtx_group *g, uint64_t *hits_out /* n_refs */, gtx_count_info *info /* may be NULL */);
+/* gtx_set_ref_blocks on every member / gtx_count_add_regions on the members in turn (every member holds the whole reference set) */
+int gtx_group_set_ref_blocks(gtx_group *g, const int64_t *first /* n_refs + 1, or NULL */, const int32_t *blocks);
+int gtx_group_count_add_regions(gtx_group *g, const int32_t *env_triples, const int32_t *weights /* may be NULL */,
+                                const int64_t *first /* n + 1 */, const int32_t *blocks, int64_t n);
 int gtx_group_coverage_begin(gtx_group *g);
 int gtx_group_coverage_add(gtx_group *g, const int32_t *read_triples, const int32_t *weights, int64_t n_reads, uint32_t flags);
 int gtx_group_coverage_end(gtx_group *g, uint64_t *cov_out /* n_refs */, gtx_count_info *info /* may be NULL */);

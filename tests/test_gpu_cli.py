@@ -616,12 +616,106 @@ def test_bed12_coverage_without_gaps_equals_oracle_cli(bed12, args):
         assert want[1] != oracle(args[:1] + ["-gaps"] + args[1:], cwd=bed12)[1]        # (the fixture tells the two rules apart)
 
 
-def test_bed12_count_without_gaps_is_refused_loudly(bed12):
-    """Without -gaps a COUNT over multi-interval regions needs "some interval pair overlaps" (genomic_intervals.cpp:1167-1172): no
-    sum of independent pieces gives that -- the tool says so instead of printing envelope counts."""
-    for args in (["count", "-i", "refs12.bed", "reads12.bed"], ["count", "-S", "-i", "refs12.bed", "reads12.bed"]):
-        rc, out, err = product("overlaps", args, cwd=bed12)
-        assert rc == 1 and out == "" and "multi-interval" in err
+# count without -gaps: a query counts once for an index region when their envelopes overlap and SOME interval of the one overlaps
+# SOME interval of the other (genomic_intervals.cpp:1167-1172, :5226-5232) -- the streaming kernel counts on the envelopes, the pair
+# kernels (csrc/gtx_pairs.hip) settle the pairs with a multi-interval side
+@pytest.fixture(scope="module")
+def genes12(tmp_path_factory):
+    """Transcript-shaped regions (2-12 exons, introns up to 20 kb, a few regions that span most of a chromosome) and spliced reads."""
+    from test_class_api import bed6, NAMES
+    d = tmp_path_factory.mktemp("genes12")
+    rng = np.random.default_rng(47)
+    def regions(n, span, multi_frac, exon, intron, max_blocks, single_len, wide=0, sort=True):
+        c = rng.integers(0, len(NAMES), size=n); s = rng.integers(0, span, size=n)
+        if sort:
+            o = np.lexsort((s, np.array([NAMES[i] for i in c]))); c, s = c[o], s[o]
+        rows = []
+        for i in range(n):
+            strand = "+-"[int(rng.integers(0, 2))]; lab = int(rng.integers(0, 7))
+            if i < wide or rng.random() >= multi_frac:
+                ln = int(rng.integers(span // 2, span)) if i < wide else int(rng.integers(1, single_len))
+                rows.append([NAMES[c[i]], int(s[i]), int(s[i]) + ln, lab, 0, strand])
+                continue
+            nb = int(rng.integers(2, max_blocks + 1)); sizes, starts, at = [], [], 0
+            for _ in range(nb):
+                starts.append(at); sz = int(rng.integers(exon[0], exon[1])); sizes.append(sz); at += sz + int(rng.integers(intron[0], intron[1]))
+            end = int(s[i]) + starts[-1] + sizes[-1]
+            rows.append([NAMES[c[i]], int(s[i]), end, lab, 0, strand, int(s[i]), end, 0, nb, ",".join(map(str, sizes)) + ",", ",".join(map(str, starts)) + ","])
+        if sort:
+            rows.sort(key=lambda r: (r[0], r[1]))
+        return rows
+    genes = regions(3000, 3_000_000, 0.7, (50, 300), (100, 20000), 12, 5000, wide=3)
+    bed6(d / "genes12.bed", [r[:3] + ["t%d" % i] + r[4:] for i, r in enumerate(genes)])
+    bed6(d / "spliced.bed", regions(80000, 3_000_000, 0.3, (10, 80), (50, 5000), 3, 120))
+    bed6(d / "spliced_shuffled.bed", regions(40000, 3_000_000, 0.3, (10, 80), (50, 5000), 3, 120, sort=False))
+    bed6(d / "unspliced.bed", regions(80000, 3_000_000, 0.0, None, None, 0, 120))
+    bed6(d / "peaks6.bed", [r[:3] + ["p%d" % i] + r[4:] for i, r in enumerate(regions(4000, 3_000_000, 0.0, None, None, 0, 2000, wide=2))])
+    by_strand = lambda rows: sorted(rows, key=lambda r: (r[0], r[5], r[1]))
+    bed6(d / "genes12_strand.bed", by_strand([r[:3] + ["t%d" % i] + r[4:] for i, r in enumerate(genes)]))
+    bed6(d / "spliced_strand.bed", by_strand(regions(50000, 3_000_000, 0.3, (10, 80), (50, 5000), 3, 120)))
+    return d
+
+
+BED12_COUNT_RUNS = [
+    ("bed12", ["count", "-i", "refs12.bed", "reads12.bed"]),
+    ("bed12", ["count", "refs12.bed", "reads12.bed"]),
+    ("bed12", ["count", "-i", "refs12.bed", "reads12_shuffled.bed"]),
+    ("bed12", ["count", "-S", "-i", "refs12.bed", "reads12.bed"]),
+    ("bed12", ["count", "-S", "--max-label-value", "4", "refs12.bed", "reads12.bed"]),
+    ("bed12", ["count", "-i", "exons6.bed", "reads12.bed"]),                          # spliced reads x single-interval regions
+    ("bed12", ["count", "-i", "refs12.bed", "reads6.bed"]),                           # plain reads x multi-interval regions
+    ("bed12", ["rpkm", "-S", "-i", "refs12.bed", "reads12.bed"]),
+    ("bed12", ["count", "-i", "refs12.bed", "reads12_bad.bed"]),                      # a region whose blocks overlap: the reference's error
+    ("bed12", ["count", "-S", "-i", "refs12.bed", "reads12_bad.bed"]),
+    ("genes12", ["count", "-i", "genes12.bed", "spliced.bed"]),
+    ("genes12", ["count", "genes12.bed", "spliced.bed"]),
+    ("genes12", ["count", "-S", "-i", "genes12.bed", "spliced.bed"]),
+    ("genes12", ["count", "-S", "-s", "genes12_strand.bed", "spliced_strand.bed"]),
+    ("genes12", ["count", "-S", "-i", "--max-label-value", "5", "genes12.bed", "spliced.bed"]),
+    ("genes12", ["count", "-i", "genes12.bed", "spliced_shuffled.bed"]),
+    ("genes12", ["count", "-i", "genes12.bed", "unspliced.bed"]),
+    ("genes12", ["count", "-S", "-i", "genes12.bed", "unspliced.bed"]),
+    ("genes12", ["count", "-i", "peaks6.bed", "spliced.bed"]),
+    ("genes12", ["count", "-S", "peaks6.bed", "spliced.bed"]),
+    ("genes12", ["rpkm", "-i", "genes12.bed", "spliced.bed"]),
+]
+
+
+@pytest.mark.parametrize("where,args", BED12_COUNT_RUNS, ids=[" ".join(a) for _, a in BED12_COUNT_RUNS])
+def test_bed12_count_without_gaps_equals_oracle_cli(request, where, args):
+    cwd = request.getfixturevalue(where)
+    want = oracle(args, cwd=cwd)
+    got = product("overlaps", args, cwd=cwd)
+    assert got[0] == want[0], (got[2], want[2])
+    assert got[1] == want[1]
+    if want[0] != 0:
+        assert got[2].strip() == want[2].strip()
+    elif "bad" not in args[-1]:
+        assert want[1] != oracle(args[:1] + ["-gaps"] + args[1:], cwd=cwd)[1]          # (the fixture tells the two rules apart)
+
+
+@pytest.mark.parametrize("args", [["count", "-i", "genes12.bed", "unspliced.bed"], ["count", "-S", "-i", "genes12.bed", "spliced.bed"],
+                                  ["count", "-S", "genes12.bed", "spliced.bed"]], ids=lambda a: " ".join(a))
+def test_bed12_count_with_text_on_device(genes12, args):
+    """The query text tokenised on the device: plain lines are checked against the multi-interval regions where their triples are, a
+    block with 12-column lines goes back to the host packer, which lists their intervals."""
+    want = oracle(args, cwd=genes12)
+    rc, out, err, nums = _product_text(args, genes12, block_mb=1)
+    assert rc == want[0] == 0, err
+    assert out == want[1]
+    assert nums is not None and sum(nums) > 0
+    if args[-1] == "unspliced.bed":
+        assert nums[0] > 0 and nums[1] == 0                                             # every block stayed on the device
+
+
+def test_bed12_count_in_memory_query_set(genes12):
+    """A caller that holds the query set in memory (load_in_memory = true): its multi-interval regions reach the packer as 12-column lines."""
+    caller = os.path.join(BIN, "api_caller")
+    for opts in (["-i"], ["-S", "-i"]):
+        want = oracle(["count"] + opts + ["genes12.bed", "spliced.bed"], cwd=genes12)
+        r = subprocess.run([caller, "icount"] + opts + ["genes12.bed", "spliced.bed"], capture_output=True, cwd=genes12)
+        assert r.returncode == 0 == want[0], r.stderr.decode()
+        assert r.stdout.decode() == want[1]
 
 
 # ---- BED text tokenised on the device (gtx_count_add_text, csrc/gtx_text.hip): the plain case there, everything else back to the host packer

@@ -2,8 +2,9 @@
 // loops of genomic_overlaps.cpp: e.g. `overlap` :630-660, `subset` :797-811), compiled against this package's
 // csrc/genomic_intervals.h.  It exercises the members SURVEY 8(b) lists beyond the two reductions: the FILE* constructor,
 // GetQuery/NextQuery, GetOverlap/NextOverlap, CountQueryOverlaps, CalcQueryCoverage, Done.
-//   api_caller pairs|qcount|qcover [-S] [-s] [-i] [-gaps] [-B bits] [--max-label-value N] REF QUERY
+//   api_caller pairs|qcount|qcover|icount [-S] [-s] [-i] [-gaps] [-B bits] [--max-label-value N] REF QUERY
 // pairs:  "<query line>\t<index label>" per overlap, in iteration order;  qcount / qcover: "<query line>\t<value>" per query
+// icount: CountIndexOverlaps with both sets in memory, "<index label>\t<count>" per index region
 // (one walk per query: a second GetOverlap walk of the same query finds the merge's buffer already consumed, in the reference too)
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,6 +23,16 @@ int main(int argc, char **argv)
     else { fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
   }
   GenomicRegionSet RefRegSet(argv[a], 10000, false, true, true);
+  if (!strcmp(argv[1], "icount")) {                                     // CountIndexOverlaps with the QUERY set held in memory as well
+    GenomicRegionSet Queries(argv[a + 1], 10000, false, true, true);
+    GenomicRegionSetOverlaps *ov;
+    if (sorted) ov = new SortedGenomicRegionSetOverlaps(&Queries, &RefRegSet, by_strand);
+    else ov = new UnsortedGenomicRegionSetOverlaps(&Queries, &RefRegSet, bits);
+    unsigned long int *hits = ov->CountIndexOverlaps(gaps, ignore_strand, mlv);
+    for (long int k = 0; k < RefRegSet.n_regions; k++) printf("%s\t%lu\n", RefRegSet.R[k]->LABEL, hits[k]);
+    delete[] hits; delete ov;
+    return 0;
+  }
   FILE *qf = fopen(argv[a + 1], "r");                                   // the FILE* constructor (genomic_intervals.h:1836)
   if (!qf) { fprintf(stderr, "cannot open %s\n", argv[a + 1]); return 2; }
   GenomicRegionSet TestRegSet(qf, 10000, false, false, true);
