@@ -110,19 +110,28 @@ __device__ __forceinline__ unsigned wave_prefix(unsigned x)
 // pairs (one 64-byte request per ~8 pairs; storing the pairs straight from the registers of the threads that loaded them is a
 // request per pair: no faster when a tile's pairs of a bucket still leave together, 1.8x slower when they leave one by one).
 // (launch bounds: weighted tiles of 4096 reads are one block per CU by LDS anyway)
-template <bool WEIGHTED, int PER>
-__global__ __launch_bounds__(1024, (WEIGHTED && PER == 4) ? 4 : 8) void bucket_scatter_kernel(const Tri3 *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a, BucketTable t, BucketWork w)
+// LINE > 0: pairs leave for the scratch array only as whole, aligned groups of LINE pairs (64 or 32 bytes).  A (tile, bucket) group
+// is ~8 pairs at an arbitrary offset of its chunk: written as it comes, most groups are two partial lines, and a line completed
+// only tiles later has long left the L2 -- HBM then takes two masked writes for it (1.63x the bytes by WRITE_SIZE, and far more
+// than that in time: with the pairs written to an L2-resident window instead the pass takes 0.34 ms, with the reads from one
+// 0.45, with both from HBM 0.66).  So every bucket keeps its last < LINE pairs in LDS (`carry`): per tile it sends
+// floor((carried + new) / LINE) * LINE pairs -- the carried ones first, picked up into registers before the tile is regrouped --
+// and keeps the rest; what is left at the end goes out with the chunk's fill count.
+template <bool WEIGHTED, int PER, int LINE>
+__global__ __launch_bounds__(1024, ((WEIGHTED && PER == 4) || LINE) ? 4 : 8) void bucket_scatter_kernel(const Tri3 *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a, BucketTable t, BucketWork w)
 {
   constexpr int TB = PER * 1024;
   extern __shared__ int4 lds4[];
   const int nB = t.nB;
   int4 *clsCell = lds4; uint4 *gb = (uint4 *)(clsCell + a.nClasses + 1); int2 *stage = (int2 *)(gb + nB + 1); unsigned *sat = (unsigned *)(stage + TB);
   int *sw = (int *)(sat + TB); int *posHi = sw + (WEIGHTED ? TB : 0); unsigned *cnt = (unsigned *)(posHi + nB + 1), *next = cnt + nB + 1, *nch = next + nB;
-  unsigned short *tab = (unsigned short *)(nch + nB);
+  unsigned *rcar = nch + nB;                                       // LINE: pairs a bucket carries (< LINE), the pairs, their weights
+  int2 *carry = (int2 *)(rcar + (LINE ? nB + (nB & 1) : 0)); int *carryW = (int *)(carry + (LINE ? (size_t)nB * LINE : 0));
+  unsigned short *tab = (unsigned short *)(carryW + ((LINE && WEIGHTED) ? (size_t)nB * LINE : 0));
   __shared__ unsigned arenaCur, tileCur[2];
   const unsigned arena0 = blockIdx.x * w.arenaPairs;               // this block's part of the scratch array
   const int4 nullEntry = make_int4(t.nCells, INT_MAX, 0, nB);       // (bucket_lookup)
-  for (int i = threadIdx.x; i < nB; i += 1024) { posHi[i] = t.posHi[i]; cnt[i] = 0; next[i] = 0; nch[i] = 0; }   // next = 0: no chunk yet, no room
+  for (int i = threadIdx.x; i < nB; i += 1024) { posHi[i] = t.posHi[i]; cnt[i] = 0; next[i] = 0; nch[i] = 0; if (LINE) rcar[i] = 0; }   // next = 0: no chunk yet, no room
   for (int i = threadIdx.x; i < a.nClasses; i += 1024) { const int4 e = t.clsCell[i]; const bool none = e.z <= 0; clsCell[i] = make_int4(none ? nullEntry.x : e.x, none ? nullEntry.y : e.y, none ? 0 : e.z - 1, none ? nullEntry.w : e.w); }
   for (int i = threadIdx.x; i < t.nCells; i += 1024) tab[i] = t.cellTab[i];
   if (threadIdx.x == 0) { arenaCur = arena0; tileCur[0] = tileCur[1] = 0; clsCell[a.nClasses] = nullEntry; tab[t.nCells] = 0; posHi[nB] = INT_MAX; cnt[nB] = 0; }
@@ -184,9 +193,11 @@ __global__ __launch_bounds__(1024, (WEIGHTED && PER == 4) ? 4 : 8) void bucket_s
       const int b = b0 + threadIdx.x;
       const unsigned c = b < nB ? cnt[b] : 0u;
       const unsigned A = b < nB ? next[b] : 0u, room = (0u - A) & (kChunk - 1);
+      // LINE: r pairs carried, F = what leaves now (whole lines: the carried pairs, then the first F - r new ones)
+      const unsigned r = (LINE && b < nB) ? rcar[b] : 0u, F = LINE ? (c ? (r + c) & ~(unsigned)(LINE ? LINE - 1 : 0) : 0u) : c;
       // the chunk fills up: as many new ones as the rest needs, side by side.  Both running sums (places in the staged tile, pairs
       // of the arena) by wave prefix and one LDS atomic per wave
-      const unsigned need = c > room ? c - room : 0u, fresh = (need + kChunk - 1) & ~(unsigned)(kChunk - 1);
+      const unsigned need = F > room ? F - room : 0u, fresh = (need + kChunk - 1) & ~(unsigned)(kChunk - 1);
       const unsigned incL = wave_prefix(c), incF = wave_prefix(fresh);
       const unsigned totL = (unsigned)__builtin_amdgcn_readlane((int)incL, 63), totF = (unsigned)__builtin_amdgcn_readlane((int)incF, 63);
       unsigned baseL = 0, baseF = 0;
@@ -194,10 +205,12 @@ __global__ __launch_bounds__(1024, (WEIGHTED && PER == 4) ? 4 : 8) void bucket_s
         if (lane == 0) { baseL = atomicAdd(&tileCur[parity], totL); if (totF) baseF = atomicAdd(&arenaCur, totF); }
         baseL = (unsigned)__builtin_amdgcn_readfirstlane((int)baseL); baseF = (unsigned)__builtin_amdgcn_readfirstlane((int)baseF);
       }
+      if (LINE && b < nB && !c) gb[b].w = 0u;                        // (nothing leaves: the carried pairs stay where they are)
       if (c) {
         const unsigned at = baseF + incF - fresh;
-        cnt[b] = 0; next[b] = need ? at + need : A + c;
-        gb[b] = make_uint4(A, at - room, baseL + incL - c, 0u);
+        cnt[b] = 0; next[b] = need ? at + need : A + F;
+        if (LINE) rcar[b] = r + c - F;
+        gb[b] = make_uint4(A, at - room, baseL + incL - c, LINE ? (r | (F << 4)) : 0u);
         if (need) {
           nch[b] += fresh >> kChunkShift;
           for (unsigned j = 0; j < fresh >> kChunkShift; j++) w.dir[(at >> kChunkShift) + j] = (unsigned)b | ((unsigned)kChunk << 16);   // full, unless it stays the bucket's last (below)
@@ -205,16 +218,39 @@ __global__ __launch_bounds__(1024, (WEIGHTED && PER == 4) ? 4 : 8) void bucket_s
       }
     }
     __syncthreads();
+    constexpr int CARRY_ROUNDS = LINE ? 9 : 1;                      // (nB * LINE <= 9 * 1024: launch_partition)
+    int2 cv[CARRY_ROUNDS]; unsigned cat[CARRY_ROUNDS]; int cw[CARRY_ROUNDS];
     {
       uint4 g[PER];
 #pragma unroll
       for (int k = 0; k < PER; k++) g[k] = gb[id[k]];               // (entry nB: whatever; not used)
 #pragma unroll
       for (int k = 0; k < PER; k++) {
-        const unsigned room = (0u - g[k].x) & (kChunk - 1), at = (rank[k] < room ? g[k].x : g[k].y) + rank[k], p = g[k].z + rank[k];
+        const unsigned room = (0u - g[k].x) & (kChunk - 1), p = g[k].z + rank[k];
+        unsigned at;
+        if (LINE) {
+          const unsigned q = (g[k].w & 15u) + rank[k], F = g[k].w >> 4;        // its place among the bucket's pairs of this round
+          at = q < F ? (q < room ? g[k].x : g[k].y) + q : 0x80000000u | ((unsigned)id[k] * LINE + (q - F));
+        } else at = (rank[k] < room ? g[k].x : g[k].y) + rank[k];
         if (id[k] != nB) {
           stage[p] = make_int2(rs[k], re[k]); sat[p] = at;
           if (WEIGHTED) sw[p] = rw[k];
+        }
+      }
+      if (LINE) {
+        // the carried pairs of the buckets that send lines now: into registers (their places in `carry` are taken over below)
+#pragma unroll
+        for (int i = 0; i < CARRY_ROUNDS; i++) {
+          const unsigned idx = threadIdx.x + 1024u * i, b = idx / (LINE ? LINE : 1), slot = idx % (LINE ? LINE : 1);
+          cat[i] = 0xffffffffu;
+          if (b < (unsigned)nB) {
+            const uint4 gg = gb[b];
+            const unsigned room = (0u - gg.x) & (kChunk - 1);
+            if ((gg.w >> 4) && slot < (gg.w & 15u)) {
+              cat[i] = (slot < room ? gg.x : gg.y) + slot; cv[i] = carry[idx];
+              if (WEIGHTED) cw[i] = carryW[idx];
+            }
+          }
         }
       }
     }
@@ -222,18 +258,37 @@ __global__ __launch_bounds__(1024, (WEIGHTED && PER == 4) ? 4 : 8) void bucket_s
     const unsigned total = tileCur[parity];
     for (unsigned j = threadIdx.x; j < total; j += 1024) {
       const unsigned at = sat[j];
+      if (LINE && (at & 0x80000000u)) {
+        carry[at & 0x7fffffffu] = stage[j];
+        if (WEIGHTED) carryW[at & 0x7fffffffu] = sw[j];
+        continue;
+      }
       out[at] = stage[j];
       if (WEIGHTED) w.tmpWeights[at] = sw[j];
+    }
+    if (LINE) {
+#pragma unroll
+      for (int i = 0; i < CARRY_ROUNDS; i++)
+        if (cat[i] != 0xffffffffu) { out[cat[i]] = cv[i]; if (WEIGHTED) w.tmpWeights[cat[i]] = cw[i]; }
     }
     // (the next round's writes to cnt and tileCur come behind barriers every wave reaches after this copy; those to stage and gb too)
   }
 
   __syncthreads();
   for (int b = threadIdx.x; b < nB; b += 1024) {
-    const unsigned e = next[b];
+    unsigned e = next[b];
+    if (LINE) {
+      const unsigned r = rcar[b];                                   // what the bucket still carries: behind its last line
+      if (r) {
+        if (!(e & (kChunk - 1))) { e = atomicAdd(&arenaCur, (unsigned)kChunk); nch[b]++; }      // (the arena has a chunk per bucket beyond its reads)
+        for (unsigned k = 0; k < r; k++) { out[e + k] = carry[(unsigned)b * LINE + k]; if (WEIGHTED) w.tmpWeights[e + k] = carryW[(unsigned)b * LINE + k]; }
+        e += r;
+      }
+    }
     if (e & (kChunk - 1)) w.dir[e >> kChunkShift] = (unsigned)b | ((e & (kChunk - 1)) << 16);   // the bucket's last chunk is part full
     w.chunkCount[(size_t)b * gridDim.x + blockIdx.x] = nch[b];
   }
+  if (LINE) __syncthreads();
   if (threadIdx.x == 0) w.arenaUsed[blockIdx.x] = (arenaCur - arena0) >> kChunkShift;
   if (nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)nNoClass);
   if (nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)nDegen); atomicMin((i64 *)&a.info->first_degenerate, (i64)firstDegen + a.indexBase); }
@@ -568,7 +623,11 @@ static int device_cus()
   return cus[dev] > 0 ? cus[dev] : 256;
 }
 
-static size_t scatter_lds(int nClasses, int nB, int nCells, int per, bool weighted) { return 16 * ((size_t)nClasses + 2) + 32 * (size_t)nB + 8 + (weighted ? 16 : 12) * 1024 * (size_t)per + 2 * ((size_t)nCells + 2) + 16; }
+static size_t scatter_lds(int nClasses, int nB, int nCells, int per, bool weighted, int line = 0)
+{
+  return 16 * ((size_t)nClasses + 2) + 32 * (size_t)nB + 8 + (weighted ? 16 : 12) * 1024 * (size_t)per + 2 * ((size_t)nCells + 2) + 16 +
+         (line ? (size_t)nB * (4 + (weighted ? 12 : 8) * (size_t)line) + 8 : 0);
+}
 
 // whether a reference set's tables fit the scatter kernel's LDS at its smallest tile (if not, the search kernel serves)
 bool bucket_tables_fit(int nClasses, int nB, int nCells) { return nB <= 65535 && scatter_lds(nClasses, nB, nCells, 1, true) <= 150 * 1024; }
@@ -583,14 +642,23 @@ BucketPlan bucket_plan(i64 n, int nClasses, int nB, int nCells, bool weighted)
   static const int tbMax = getenv("GTX_SPLIT_TILE") ? atoi(getenv("GTX_SPLIT_TILE")) : 4096;
   p.per = tbMax >= 4096 ? 4 : tbMax >= 2048 ? 2 : 1;
   while (p.per > 1 && scatter_lds(nClasses, nB, nCells, p.per, weighted) > 150 * 1024) p.per >>= 1;     // (gtx_set_refs keeps nB and the classes within what per = 1 takes)
+  // whole lines only (LINE of bucket_scatter_kernel): 8 pairs per bucket carried in LDS where that fits next to the tile, else 4.
+  // (100 M reads x 1 M regions, scatter pass alone: as they come 0.68 ms, WRITE_SIZE 1.28 GB for 0.80 GB of pairs; lines of 4: 0.61 ms,
+  //  1.24 GB; of 8: 0.50-0.51 ms, 0.99 GB; of 16 -- GTX_SPLIT_LINE=16 -- 0.54 ms, 0.79 GB = 1.00x: nearly every pair then waits in LDS
+  //  once, and the pass is bound by its instructions again)
+  static const int lineEnv = getenv("GTX_SPLIT_LINE") ? atoi(getenv("GTX_SPLIT_LINE")) : -1;
+  p.line = 0;
+  for (int line : {16, 8, 4})
+    if (!p.line && (lineEnv < 0 ? line != 16 : lineEnv == line) && (size_t)nB * line <= 9 * 1024 && scatter_lds(nClasses, nB, nCells, p.per, weighted, line) <= 150 * 1024) p.line = line;
   const i64 tb = (i64)p.per * 1024, tiles = (n + tb - 1) / tb;
-  const size_t lds = scatter_lds(nClasses, nB, nCells, p.per, weighted);
-  const int fit = perCu > 0 ? perCu : (2 * (lds + 1024) <= 160 * 1024 ? 2 : 1);
+  const size_t lds = scatter_lds(nClasses, nB, nCells, p.per, weighted, p.line);
+  const int fit = perCu > 0 ? perCu : ((!p.line && 2 * (lds + 1024) <= 160 * 1024) ? 2 : 1);      // (the LINE kernels take more than 64 registers: one block of 16 waves per CU)
   const i64 most = (i64)fit * device_cus();
   p.blocks = (unsigned)(tiles < most ? (tiles > 0 ? tiles : 1) : most);
   const i64 tilesPerBlock = (tiles + p.blocks - 1) / p.blocks;
   p.arenaPairs = (size_t)tilesPerBlock * tb + (size_t)nB * kChunk;
   p.pairs = p.arenaPairs * p.blocks;
+  if (p.pairs >= (1ull << 31)) p.line = 0;                       // (the kernel marks a pair that stays in LDS with the top bit of its place)
   p.chunks = p.pairs >> kChunkShift;
   p.matrix = (size_t)nB * p.blocks;
   return p;
@@ -604,17 +672,21 @@ static hipError_t launch_partition(const void *reads, const void *weights, i64 n
   {
     hipError_t e = attr.once([] {
       hipError_t e = hipSuccess;
-      const void *fn[] = {(const void *)bucket_scatter_kernel<false, 1>, (const void *)bucket_scatter_kernel<true, 1>, (const void *)bucket_scatter_kernel<false, 4>,
-                          (const void *)bucket_scatter_kernel<true, 4>, (const void *)bucket_scatter_kernel<false, 2>, (const void *)bucket_scatter_kernel<true, 2>};
+#define GTX_SCATTER_FNS(L) (const void *)bucket_scatter_kernel<false, 1, L>, (const void *)bucket_scatter_kernel<true, 1, L>, (const void *)bucket_scatter_kernel<false, 4, L>, \
+                           (const void *)bucket_scatter_kernel<true, 4, L>, (const void *)bucket_scatter_kernel<false, 2, L>, (const void *)bucket_scatter_kernel<true, 2, L>
+      const void *fn[] = {GTX_SCATTER_FNS(0), GTX_SCATTER_FNS(4), GTX_SCATTER_FNS(8), GTX_SCATTER_FNS(16)};
+#undef GTX_SCATTER_FNS
       for (const void *f : fn) if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
       return e;
     });
     if (e != hipSuccess) return e;
   }
-  const size_t lds = scatter_lds(a.nClasses, t.nB, t.nCells, p.per, weights != nullptr);
-#define GTX_SCATTER(W, P) bucket_scatter_kernel<W, P><<<p.blocks, 1024, lds, st>>>((const Tri3 *)reads, (const int *)weights, n, a, t, w)
-  if (weights) { if (p.per == 4) GTX_SCATTER(true, 4); else if (p.per == 2) GTX_SCATTER(true, 2); else GTX_SCATTER(true, 1); }
-  else { if (p.per == 4) GTX_SCATTER(false, 4); else if (p.per == 2) GTX_SCATTER(false, 2); else GTX_SCATTER(false, 1); }
+  const size_t lds = scatter_lds(a.nClasses, t.nB, t.nCells, p.per, weights != nullptr, p.line);
+#define GTX_SCATTER(W, P, L) bucket_scatter_kernel<W, P, L><<<p.blocks, 1024, lds, st>>>((const Tri3 *)reads, (const int *)weights, n, a, t, w)
+#define GTX_SCATTER_L(W, P) do { if (p.line == 16) GTX_SCATTER(W, P, 16); else if (p.line == 8) GTX_SCATTER(W, P, 8); else if (p.line == 4) GTX_SCATTER(W, P, 4); else GTX_SCATTER(W, P, 0); } while (0)
+  if (weights) { if (p.per == 4) GTX_SCATTER_L(true, 4); else if (p.per == 2) GTX_SCATTER_L(true, 2); else GTX_SCATTER_L(true, 1); }
+  else { if (p.per == 4) GTX_SCATTER_L(false, 4); else if (p.per == 2) GTX_SCATTER_L(false, 2); else GTX_SCATTER_L(false, 1); }
+#undef GTX_SCATTER_L
 #undef GTX_SCATTER
   chunk_rows_kernel<<<(unsigned)t.nB, 256, 0, st>>>(w, p.blocks);
   chunk_offsets_kernel<<<1, 1024, 0, st>>>(w, t.nB);     // (one more launch: the block of chunk_rows_kernel that finishes last doing it was slower, 540 blocks adding to one counter)

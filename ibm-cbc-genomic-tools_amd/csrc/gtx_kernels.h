@@ -150,7 +150,7 @@ struct BucketWork {                // scratch of one call (sizes: bucket_plan)
   unsigned *rowOff;                // [nB + 1] first list entry of every bucket
   unsigned *arenaUsed;             // [blocks] chunks dealt out
 };
-struct BucketPlan { int per; unsigned blocks; size_t arenaPairs, pairs, chunks, matrix; };
+struct BucketPlan { int per, line; unsigned blocks; size_t arenaPairs, pairs, chunks, matrix; };   // line: pairs per whole line of the scatter pass (0: as they come)
 BucketPlan bucket_plan(long long n, int nClasses, int nB, int nCells, bool weighted);
 bool bucket_tables_fit(int nClasses, int nB, int nCells);
 int bucket_e_size();
