@@ -394,31 +394,17 @@ def bench_count_group(args, rank, world, local, device, rehearse, force_dist):
     total_reads = args.reads * (world if args.scaling == "weak" else 1)
     per_chrom = synth.apportion(total_reads, synth.CHROM_LEN)
     flags = gtx.READS_SORTED
-    grp, locals_ = make_group(rank, world, local, device, rehearse, force_dist)
     owner = gtx.lpt_assign(per_chrom, n_members)
     reads_per_rank = [int(per_chrom[owner == r].sum()) for r in range(n_members)]
     kernel_ms, elapsed, hits_final, member_reads = [], 0.0, None, None
-    if grp is not None:
-        assert np.array_equal(grp.assign(per_chrom), owner)
-        grp.set_refs(refs, synth.n_classes())
-        stream = torch.cuda.current_stream()
-        reads = []
-        for m in locals_:
-            grp.set_stream(m, stream.cuda_stream) if not rehearse else None
-            ch = np.nonzero(owner == m)[0].astype(np.int64)
-            reads.append(make_reads_on_device(0, ch, 1000, device, per=per_chrom[ch]))
-            assert reads[-1].shape[0] == reads_per_rank[m]
-        ptrs, ns = [r.data_ptr() for r in reads], [r.shape[0] for r in reads]
-        hits_pp = [torch.zeros(len(refs), dtype=torch.int64, device=device) for _ in range(2)]
-        step_no = [0]
+    grp, locals_, reads, problem = None, [], [], ""
+    step_no = [0]
 
-        def step():
+    def step():
+        if grp is not None:
             b = step_no[0] & 1
             step_no[0] += 1
             grp.count_device(ptrs, ns, hits_pp[b].data_ptr(), flags=flags)
-    else:
-        def step():
-            pass
 
     def fence():
         if grp is not None:
@@ -427,9 +413,57 @@ def bench_count_group(args, rank, world, local, device, rehearse, force_dist):
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 2)):
-        step()
+    # Everything up to the first result is guarded: if the group cannot be made on this machine (librccl not found, the
+    # communicator refused) or its first result is not the sum of the ranks' own counts, EVERY rank leaves this function and the
+    # run goes on with the plain path below (one context per rank + torch.distributed reduce), which says so in its line --
+    # a scaling run then still ends with a valid number, never with a silently different one.
+    try:
+        if os.environ.get("GTX_BENCH_BREAK_GROUP") == "1":          # (a test of the way out below)
+            raise RuntimeError("GTX_BENCH_BREAK_GROUP=1")
+        grp, locals_ = make_group(rank, world, local, device, rehearse, force_dist)
+        if grp is not None:
+            assert np.array_equal(grp.assign(per_chrom), owner)
+            grp.set_refs(refs, synth.n_classes())
+            stream = torch.cuda.current_stream()
+            for m in locals_:
+                grp.set_stream(m, stream.cuda_stream) if not rehearse else None
+                ch = np.nonzero(owner == m)[0].astype(np.int64)
+                reads.append(make_reads_on_device(0, ch, 1000, device, per=per_chrom[ch]))
+                assert reads[-1].shape[0] == reads_per_rank[m]
+            ptrs, ns = [r.data_ptr() for r in reads], [r.shape[0] for r in reads]
+            hits_pp = [torch.zeros(len(refs), dtype=torch.int64, device=device) for _ in range(2)]
+        for _ in range(max(args.warmup, 2)):
+            step()
+    except Exception as e:                                            # noqa: BLE001 -- whatever it is, the other ranks must hear of it
+        problem = "%s: %s" % (type(e).__name__, e)
+    if not agree(not problem, rehearse, device):
+        if grp is not None:
+            grp.close()
+        return "group unavailable" + (": " + problem if problem else " on another rank")
     fence()
+    # always on: the group's result on member 0 against the sum over the ranks of what ONE context counts for the rank's own reads
+    # (gtx_count_device, the N = 1 path the parity tests pin) -- the exchange checked end to end at full size on the real machine
+    own = torch.zeros(len(refs), dtype=torch.int64, device=device)
+    if grp is not None:
+        eng1 = gtx.Engine(local)
+        eng1.set_refs(refs, synth.n_classes())
+        one = torch.zeros_like(own)
+        for r in reads:
+            eng1.count_device(r.data_ptr(), r.shape[0], one.data_ptr(), None, flags)
+            eng1.sync()
+            own += one
+        eng1.close()
+    if rehearse:
+        own_c = own.cpu(); dist.all_reduce(own_c, op=dist.ReduceOp.SUM); own = own_c.to(device)
+    else:
+        dist.all_reduce(own, op=dist.ReduceOp.SUM)
+    same = True
+    if rank == 0:
+        same = bool(torch.equal(hits_pp[(step_no[0] - 1) & 1], own))
+    if not agree(same, rehearse, device):
+        if grp is not None:
+            grp.close()
+        return "the group's result on member 0 differed from the sum of the ranks' own counts"
     if grp is not None:
         grp.profile(locals_[0], PROFILE_EVERY if args.steps >= PROFILE_EVERY else 1)
     fence()
@@ -477,7 +511,8 @@ def bench_count_group(args, rank, world, local, device, rehearse, force_dist):
                        "reduce": ("one-GPU rehearsal of the group code (not a measurement)" if rehearse else
                                   "grouped ncclSend/ncclRecv of each member's piece of the uint64 count vector to member 0 over xGMI, on a stream of "
                                   "its own under the next step's kernels; member 0 restores file order") +
-                                 (" [single-rank self-test: the piece goes out and back through RCCL]" if force_dist else "")},
+                                 (" [single-rank self-test: the piece goes out and back through RCCL]" if force_dist else ""),
+                       "verified": "before the timed steps: result on member 0 == sum over the ranks of gtx_count_device on each rank's own reads"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
                          "kernel": "count_walk_kernel (member 0's launch over its %d reads)" % n0, "kernel_ms": k_ms,
@@ -487,6 +522,14 @@ def bench_count_group(args, rank, world, local, device, rehearse, force_dist):
     if grp is not None:
         grp.close()
     dist.destroy_process_group()
+    return None
+
+
+def agree(ok, rehearse, device):
+    """True when `ok` holds on every rank"""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if rehearse else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
 
 
 def main():
@@ -545,8 +588,12 @@ def main():
 
     if args.workload == "permutation_test":
         return bench_perm(args, rank, world, local, device, rehearse)
+    group_note = None
     if args.workload == "count" and DIST_ON:
-        return bench_count_group(args, rank, world, local, device, rehearse, force_dist)
+        group_note = bench_count_group(args, rank, world, local, device, rehearse, force_dist)
+        if group_note is None:
+            return
+        print("bench.py: %s -- falling back to one context per rank + torch.distributed reduce of the full vectors" % group_note, file=sys.stderr)
 
     # ---- workload -------------------------------------------------------------------------------
     refs = synth.genome_intervals(args.refs, 43, 50, 2000)                 # 1M refs, all chromosomes, every rank
@@ -744,7 +791,8 @@ def main():
                        "total_reads": total_reads, "refs": len(refs), "reads_per_rank": reads_per_rank,
                        "imbalance": max(reads_per_rank) / (sum(reads_per_rank) / world),
                        "parallelism": "%s scaling: one global read set, chromosomes dealt to %d rank(s) by LPT packing of their read counts "
-                                      "(gtx_lpt_assign), reference set replicated" % (args.scaling if world > 1 else "single GPU;", world),
+                                      "(gtx_lpt_assign), reference set replicated" % (args.scaling if world > 1 else "single GPU;", world) +
+                                      (" [FALLBACK: %s; every rank finalizes and reduces the full vector]" % group_note if group_note else ""),
                        "reduce": ("none (one rank)" if not DIST_ON else "gloo rehearsal on one GPU (not a measurement)" if rehearse else
                                   ("RCCL reduce(sum) to rank 0" if pipelined and not use_allreduce else "RCCL all-reduce(sum)") +
                                   (" of the uint64 count vector per step, enqueued on RCCL's stream under the next step's kernels" if pipelined
