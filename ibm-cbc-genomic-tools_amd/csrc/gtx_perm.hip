@@ -31,6 +31,7 @@
 #include <vector>
 #include "gtx.h"
 #include "gtx_perm.h"
+#include "gtx_kernels.h"   // gtx::PerDevice
 
 namespace {
 
@@ -112,6 +113,91 @@ __global__ __launch_bounds__(256) void perm_apply_kernel(const float *__restrict
     Vp[at] = V[src];
     if (Vtp) Vtp[at] = Vt[src];
     if (++R == g.b) { R = 0; L++; }
+  }
+}
+
+// The same slab for tables whose grid sides are small (a, b <= 192: up to ~36 k rows).  The round function of perm_at depends on
+// the permutation, the round and ONE grid coordinate only -- at most max(a, b) values -- so a block that writes one tile of 64
+// permutations first tabulates it: tab[j][i][x] = (fmix32(x + key_j[i]) * side) >> 32, one byte each (10 rounds x <= 192 x 64
+// permutations <= 120 KB of LDS), and a row's image is then ten dependent byte reads with an add and a conditional subtract each
+// -- against two 32-bit multiplies, a multiply-high and the shifts of fmix32 per round, which is what bounds perm_apply_kernel
+// (VALU).  Same arithmetic, same cycle walking: bit-identical images (include/gtx_perm.h).  lane = permutation (a row is one
+// coalesced 256-byte store of the tile), a wave takes kTabRows rows at a time so that their chains of LDS reads overlap.
+// 20 k rows x 10 k permutations: 0.67 ms against 0.75 for perm_apply_kernel -- ~80 vector instructions per row and lane instead of
+// ~145, but ten dependent LDS byte reads in their place; 2, 4 or 8 rows in flight per wave make no difference.
+// Layout: entry (round i, coordinate x, lane j) sits in word ((i * T + x) / 2) * 32 + j % 32, byte 2 * (x & 1) + j / 32 (T even):
+// a lane always reads bank j % 32, so the 32 lanes of a half-wave never meet in a bank whatever their coordinates are.
+constexpr int kTabMaxSide = 192, kTabRows = 4;
+
+__device__ __forceinline__ uint32_t tab_step(const unsigned char *__restrict__ tab, uint32_t base, uint32_t x)
+{
+  // ((x >> 1) << 7) + ((x & 1) << 1) + base = base + (x << 6) - 62 (x & 1): and, shift-add, multiply-add (written out: the compiler
+  // turns the product into a compare and a select, two more instructions in a loop that is bound by their number)
+  uint32_t at;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(at) : "v"(x & 1u), "s"(-62), "v"((x << 6) + base));
+  return tab[at];
+}
+
+__global__ __launch_bounds__(1024) void perm_apply_tab_kernel(const float *__restrict__ V, const float *__restrict__ Vt, float *__restrict__ Vp,
+                                                              float *__restrict__ Vtp, PermGeom g, uint32_t rowsPerBlock, u64 seed,
+                                                              i64 firstPerm, i64 nPerm, uint32_t T)
+{
+  extern __shared__ unsigned char tab[];                            // 10 * T * 64 bytes
+  __shared__ uint32_t keys[64][kRounds];
+  const i64 j0 = (i64)blockIdx.x * 64;
+  if (threadIdx.x < 64) {
+    PermKeys k; perm_keys_init(k, seed, (u64)(firstPerm + j0 + threadIdx.x), g.n);    // (lanes beyond nPerm: some permutation nobody stores)
+#pragma unroll
+    for (int i = 0; i < kRounds; i++) keys[threadIdx.x][i] = k.key[i];
+  }
+  __syncthreads();
+  for (uint32_t idx = threadIdx.x; idx < 64u * kRounds * T; idx += blockDim.x) {
+    const uint32_t j = idx & 63u, y = idx >> 6, i = y / T, x = y - i * T;
+    const uint32_t side = (i & 1) ? g.b : g.a;                        // even rounds move L (argument R < b), odd rounds move R (argument L < a)
+    tab[((y >> 1) * 32 + (j & 31u)) * 4 + ((y & 1u) << 1) + (j >> 5)] = (unsigned char)(((u64)fmix32(x + keys[j][i]) * side) >> 32);
+  }
+  __syncthreads();
+  // (the wave's number as a scalar: the rows it takes, their grid cells and the addresses of their lines are then scalar work)
+  const uint32_t lane = threadIdx.x & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  uint32_t base[kRounds];
+#pragma unroll
+  for (int i = 0; i < kRounds; i++) base[i] = (uint32_t)i * T * 64u + (lane & 31u) * 4u + (lane >> 5);
+  const uint32_t r0 = blockIdx.y * rowsPerBlock, r1 = (uint32_t)min((u64)g.n, (u64)r0 + rowsPerBlock);
+  const bool live = j0 + lane < nPerm;
+  float *__restrict__ tile = Vp + (size_t)blockIdx.x * g.n * 64, *__restrict__ tileT = Vtp ? Vtp + (size_t)blockIdx.x * g.n * 64 : nullptr;
+  for (uint32_t rb = r0 + wv * kTabRows; rb < r1; rb += nw * kTabRows) {
+    uint32_t L[kTabRows], R[kTabRows], x[kTabRows];
+#pragma unroll
+    for (int u = 0; u < kTabRows; u++) { const uint32_t r = min(rb + u, r1 - 1); L[u] = r / g.b; R[u] = r - L[u] * g.b; }
+#pragma unroll
+    for (int i = 0; i < kRounds; i += 2) {
+#pragma unroll
+      for (int u = 0; u < kTabRows; u++) { L[u] += tab_step(tab, base[i], R[u]); L[u] = min(L[u], L[u] - g.a); }
+#pragma unroll
+      for (int u = 0; u < kTabRows; u++) { R[u] += tab_step(tab, base[i + 1], L[u]); R[u] = min(R[u], R[u] - g.b); }
+    }
+    bool spare = false;
+#pragma unroll
+    for (int u = 0; u < kTabRows; u++) { x[u] = L[u] * g.b + R[u]; spare |= x[u] >= g.n; }
+    if (__builtin_amdgcn_ballot_w64(spare)) {                        // (one test for the rows of the step: spare cells are < 2 sqrt n of n)
+      for (int u = 0; u < kTabRows; u++) {
+        while (x[u] >= g.n) {                                         // cycle walking
+          for (int i = 0; i < kRounds; i += 2) {
+            L[u] += tab_step(tab, base[i], R[u]); L[u] = min(L[u], L[u] - g.a);
+            R[u] += tab_step(tab, base[i + 1], L[u]); R[u] = min(R[u], R[u] - g.b);
+          }
+          x[u] = L[u] * g.b + R[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kTabRows; u++) {
+      const uint32_t r = rb + u;
+      if (r < r1 && live) {
+        tile[(size_t)r * 64 + lane] = V[x[u]];
+        if (tileT) tileT[(size_t)r * 64 + lane] = Vt[x[u]];
+      }
+    }
   }
 }
 
@@ -562,11 +648,34 @@ static int run_batches(gtx_perm *p, int stat, int mode, StatArgs a, bool needVt,
   for (i64 done = 0; done < n_perm; done += pb) {
     const i64 cnt = n_perm - done < pb ? n_perm - done : pb;
     PCHK(p, hipEventRecord(p->ev[0], p->stream));
-    uint32_t rpb = 128;                                              // rows per block; grid.y stays below 65536
-    while ((p->nRows + rpb - 1) / rpb > 65535) rpb *= 2;
-    dim3 grid((unsigned)((cnt + 255) / 256), (unsigned)((p->nRows + rpb - 1) / rpb));
-    perm_apply_kernel<<<grid, 256, 0, p->stream>>>(p->d_V, needVt ? p->d_Vt : nullptr, p->d_Vp, needVt ? p->d_Vtp : nullptr, g, rpb, seed,
-                                                    first_perm + done, cnt);
+    const bool noTab = getenv("GTX_PERM_NO_TABLE") != nullptr;                            // (the tests compare both writers)
+    const uint32_t T = (std::max(g.a, g.b) + 1) & ~1u;                                   // (even: see the table's layout)
+    if (!noTab && g.n > 16 && T <= (uint32_t)kTabMaxSide) {
+      // one block per tile of 64 permutations and row range (one block per CU at a time: the table takes most of the LDS); the number
+      // of row ranges balances full rounds of blocks over the CUs against tabulating once more per range
+      const size_t lds = (size_t)64 * kRounds * T;
+      static gtx::PerDevice attr;
+      PCHK(p, attr.once([] { return hipFuncSetAttribute((const void *)perm_apply_tab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); }));
+      const unsigned tiles = (unsigned)((cnt + 63) / 64);
+      int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
+      const unsigned maxChunks = (unsigned)std::max<i64>(1, p->nRows / 1024);
+      unsigned chunks = 1; double best = 1e300;
+      for (unsigned c = 1; c <= maxChunks && c <= 64; c++) {
+        // rounds of blocks over the CUs x (rows of a block + what tabulating costs in rows: ~5.5 T by instruction count)
+        const double cost = ceil((double)tiles * c / cus) * ((double)p->nRows / c + 5.5 * T);
+        if (cost < best) { best = cost; chunks = c; }
+      }
+      if (getenv("GTX_PERM_CHUNKS")) chunks = (unsigned)std::max(1, atoi(getenv("GTX_PERM_CHUNKS")));
+      const uint32_t rpbT = (uint32_t)((p->nRows + chunks - 1) / chunks);
+      perm_apply_tab_kernel<<<dim3(tiles, (unsigned)((p->nRows + rpbT - 1) / rpbT)), 1024, lds, p->stream>>>(
+          p->d_V, needVt ? p->d_Vt : nullptr, p->d_Vp, needVt ? p->d_Vtp : nullptr, g, rpbT, seed, first_perm + done, cnt, T);
+    } else {
+      uint32_t rpb = 128;                                              // rows per block; grid.y stays below 65536
+      while ((p->nRows + rpb - 1) / rpb > 65535) rpb *= 2;
+      dim3 grid((unsigned)((cnt + 255) / 256), (unsigned)((p->nRows + rpb - 1) / rpb));
+      perm_apply_kernel<<<grid, 256, 0, p->stream>>>(p->d_V, needVt ? p->d_Vt : nullptr, p->d_Vp, needVt ? p->d_Vtp : nullptr, g, rpb, seed,
+                                                      first_perm + done, cnt);
+    }
     PCHK(p, hipGetLastError());
     PCHK(p, hipEventRecord(p->ev[1], p->stream));
     a.Vp = p->d_Vp; a.Vtp = needVt ? p->d_Vtp : nullptr; a.nPerm = cnt;

@@ -103,6 +103,25 @@ def test_config5_table_10k_shuffles(pe):
     np.testing.assert_array_equal(pe.count_ge("sum", Y, 2024, 5000, 24), porc.count_ge(t, "sum", Y, 2024, 5000, 24))
 
 
+@pytest.mark.parametrize("n_rows", [1500, 20000, 36000, 37000])
+def test_tabulated_and_direct_slab_writers_agree(pe, monkeypatch, n_rows):
+    """Tables with grid sides <= 192 (up to ~36 k rows) get their slab from perm_apply_tab_kernel (round functions tabulated in
+    LDS); the others, and everything under GTX_PERM_NO_TABLE, from perm_apply_kernel: the same images bit for bit -- counts of a
+    range that ends inside a tile of 64 permutations, one- and two-value tables, against each other and (a short range) the oracle."""
+    for totals in (False, True):
+        t = perm.PermTable.synthetic(n_rows, 300, 60, seed=11, values="gamma", totals=totals)
+        pe.set_table(t)
+        for stat in ("sum", "t"):
+            Y = pe.statistic(stat)
+            monkeypatch.delenv("GTX_PERM_NO_TABLE", raising=False)
+            a = pe.count_ge(stat, Y, 31, 3, 333)
+            monkeypatch.setenv("GTX_PERM_NO_TABLE", "1")
+            b = pe.count_ge(stat, Y, 31, 3, 333)
+            monkeypatch.delenv("GTX_PERM_NO_TABLE")
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(pe.count_ge(stat, Y, 31, 3, 20), porc.count_ge(t, stat, Y, 31, 3, 20))
+
+
 def test_small_slab_budget_batches_give_the_same_counts(pe):
     t = perm.PermTable.synthetic(40000, 100, 60, seed=9, values="gamma", totals=True)
     pe.set_table(t)
