@@ -52,6 +52,7 @@ struct gtx_ctx {
   int64_t bucketMinReads = 1 << 18;                  // below this the per-read search kernel is used (GTX_BUCKET_MIN_READS)
   int *d_posE = nullptr, *d_posS = nullptr, *d_classBase = nullptr;
   u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr, *d_prefA = nullptr, *d_prefB = nullptr;
+  unsigned *d_chainFlags = nullptr; unsigned chainEpoch = 0;    // finalize_scan_chained_kernel: a flag per tile and histogram, the call's epoch
   bool histDirty = false;              // a call was abandoned between begin and end
   // coverage (allocated on first use): 8 histograms, 8 tile-sum arrays, 8 prefix arrays, region coordinates
   // coverage (made on first use): the merged threshold array of the regions (E_k and S_k - 1, sorted per class) with its
@@ -226,7 +227,7 @@ void gtx_destroy(gtx_ctx *c)
   dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab); dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;
   dfree(c->d_placeCls); dfree(c->d_placeRank); dfree(c->d_placeClsT); dfree(c->d_placeRankT); dfree(c->d_shareTiles); dfree(c->d_shareRegions);
   dfree(c->d_bktCnt); dfree(c->d_bktS); dfree(c->d_clsCellS); dfree(c->d_cellTabS); dfree(c->d_scanParts); dfree(c->d_scanInfo); c->nBS = 0;
-  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info);
+  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info); dfree(c->d_chainFlags);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   for (int k = 0; k < 2; k++) {
     dfree(c->d_stage[k]); dfree(c->d_stageW[k]);
@@ -342,7 +343,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab);
   dfree(c->d_placeCls); dfree(c->d_placeRank);
   dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;      // tables over the coverage thresholds: rebuilt by cover_prepare
-  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB);
+  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_chainFlags);
   c->nRefs = -1;
   const int64_t histLen = nv + nClasses;
   const int nTiles = gtx::scan_tiles(histLen);
@@ -363,6 +364,9 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   HIPCHK(c, hipMemset(c->d_histB, 0, sizeof(u64) * histLen));
   HIPCHK(c, hipMemset(c->d_partA, 0, sizeof(u64) * (nTiles + 2)));
   HIPCHK(c, hipMemset(c->d_partB, 0, sizeof(u64) * (nTiles + 2)));
+  HIPCHK(c, hipMalloc(&c->d_chainFlags, sizeof(unsigned) * 8 * (nTiles + 2)));
+  HIPCHK(c, hipMemset(c->d_chainFlags, 0, sizeof(unsigned) * 8 * (nTiles + 2)));
+  c->chainEpoch = 0;
   c->histDirty = false; c->tileSumsValid = true;
   HIPCHK(c, hipMemcpy(c->d_sortedE, sortedE.data(), sizeof(int32_t) * nv, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_sortedS, sortedS.data(), sizeof(int32_t) * nv, hipMemcpyHostToDevice));
@@ -678,9 +682,13 @@ static int count_begin(gtx_ctx *c)
 static int count_end(gtx_ctx *c, void *d_hits, bool share = false)
 {
   gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions};
+  if (++c->chainEpoch == 0) {                       // (after 2^32 calls: the flags start over)
+    HIPCHK(c, hipMemsetAsync(c->d_chainFlags, 0, sizeof(unsigned) * 8 * (gtx::scan_tiles(c->histLen) + 2), c->stream));
+    c->chainEpoch = 1;
+  }
   HIPCHK(c, gtx::launch_finalize(c->d_histA, c->d_histB, c->histLen, c->d_partA, c->d_partB, c->tileSumsValid, c->d_prefA, c->d_prefB,
                                  c->d_posE, c->d_posS, c->d_classBase, c->nRefs, (u64 *)d_hits, c->d_info + (c->infoCur ^ 1), c->stream,
-                                 share ? &fs : nullptr));
+                                 share ? &fs : nullptr, c->d_chainFlags, c->chainEpoch));
   { int rc = merge_end(c, d_hits); if (rc) return rc; }
   c->histDirty = false;
   c->infoCur ^= 1;                                // the block just used stays readable until the call after next

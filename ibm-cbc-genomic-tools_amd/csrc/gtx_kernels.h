@@ -197,7 +197,10 @@ hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB,
                            unsigned long long *tileA, unsigned long long *tileB, bool tileSumsValid,
                            unsigned long long *prefA, unsigned long long *prefB,
                            const int *posE, const int *posS, const int *classBase, long long m,
-                           unsigned long long *hits, DevInfo *nextInfo, hipStream_t st, const FinalizeShare *share = nullptr);
+                           unsigned long long *hits, DevInfo *nextInfo, hipStream_t st, const FinalizeShare *share = nullptr,
+                           unsigned *chainFlags = nullptr, unsigned epoch = 0);
+// chainFlags (may be null): 8 x (tiles + 2) words (two 64-bit words per tile and histogram), zero when made, never written by the caller; epoch: a value no earlier call on these
+// flags used (and not 0).  With them a call whose tile sums are not valid takes one launch for tile sums + scan (finalize_scan_chained_kernel).
 hipError_t launch_coverage(const void *reads, const void *weights, long long n, const CoverArgs &a, hipStream_t st);
 hipError_t launch_coverage_finalize(const CoverArgs &a, long long histLen, const CoverGather &g, long long m,
                                     unsigned long long *cov, DevInfo *nextInfo, hipStream_t st);

@@ -1533,6 +1533,63 @@ __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha
   }
 }
 
+// Tile sums and prefix scan in ONE launch (the streaming kernel of a large call leaves the tile sums to the finalize step): a tile's
+// block publishes its sum -- value, then a flag carrying the call's epoch, released at device scope -- and then adds up the sums of the
+// tiles below it as they turn up.  A block only ever waits for blocks with a lower index of the same histogram, which the
+// dispatcher starts no later than itself: the lowest unfinished block never waits for one that is not running.  ts / fl are indexed
+// by the block's position (tile number, or place in a member's tile list: the tiles outside the list hold no counts).
+__global__ __launch_bounds__(256) void finalize_scan_chained_kernel(u64 *__restrict__ ha, u64 *__restrict__ hb, i64 len,
+                                                                    u64 *fa, u64 *fb, unsigned epoch,
+                                                                    u64 *__restrict__ pa, u64 *__restrict__ pb, const int *__restrict__ tileList)
+{
+  __shared__ u64 lds[4];
+  __shared__ u64 wsum[4];
+  u64 *__restrict__ h = blockIdx.y ? hb : ha;
+  u64 *fl = blockIdx.y ? fb : fa;
+  u64 *__restrict__ p = blockIdx.y ? pb : pa;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int pos = (int)blockIdx.x, tile = tileList ? tileList[pos] : pos;
+  const i64 i0 = (i64)tile * kTile + (i64)threadIdx.x * 4;
+  const bool full = i0 + 4 <= len;
+  u64 v[4];
+  if (full) {
+    const ulonglong2 x = *(const ulonglong2 *)(h + i0), y = *(const ulonglong2 *)(h + i0 + 2);
+    v[0] = x.x; v[1] = x.y; v[2] = y.x; v[3] = y.y;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = i0 + k < len ? h[i0 + k] : 0;
+  }
+  v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+  const u64 x = wave_scan_add64(v[3]);             // inclusive scan of the thread totals across the wave (DPP)
+  if (lane == 63) wsum[wv] = x;
+  __syncthreads();
+  // (no fences: a sum travels as two words, each half of it next to the epoch -- relaxed device-scope atomics, complete when both carry the epoch)
+  if (threadIdx.x < 2) {
+    const u64 s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __hip_atomic_store(fl + 2 * pos + threadIdx.x, ((u64)epoch << 32) | (threadIdx.x ? s >> 32 : s & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  u64 o = 0;
+  for (int t = threadIdx.x; t < pos; t += 256) {
+    u64 lo, hi;
+    while (((lo = __hip_atomic_load(fl + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
+    while (((hi = __hip_atomic_load(fl + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
+    o += (lo & 0xffffffffull) | (hi << 32);
+  }
+  o = block_sum(o, lds);
+  o += x - v[3];
+  for (int k = 0; k < wv; k++) o += wsum[k];
+  if (full) {
+    *(ulonglong2 *)(p + i0) = make_ulonglong2(v[0] + o, v[1] + o);
+    *(ulonglong2 *)(p + i0 + 2) = make_ulonglong2(v[2] + o, v[3] + o);
+    *(ulonglong2 *)(h + i0) = make_ulonglong2(0, 0);
+    *(ulonglong2 *)(h + i0 + 2) = make_ulonglong2(0, 0);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (i0 + k < len) { p[i0 + k] = v[k] + o; h[i0 + k] = 0; }
+  }
+}
+
 __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict__ pa, const u64 *__restrict__ pb,
                                                           const int *__restrict__ posE, const int *__restrict__ posS,
                                                           const int *__restrict__ classBase, i64 m, u64 *__restrict__ hits,
@@ -1892,14 +1949,19 @@ hipError_t launch_tile_sums(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64
 
 hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, bool tileSumsValid, u64 *prefA, u64 *prefB,
                            const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, DevInfo *nextInfo, hipStream_t st,
-                           const FinalizeShare *share)
+                           const FinalizeShare *share, unsigned *chainFlags, unsigned epoch)
 {
   const int nb = scan_tiles(histLen);
   const int nbRun = share ? share->nTiles : nb;                // a group member: the tiles of its classes, its regions (compact)
   const int *tl = share ? share->tileList : nullptr;
+  static const bool chained = !(getenv("GTX_CHAINED_SCAN") && atoi(getenv("GTX_CHAINED_SCAN")) == 0);
   if (nbRun > 0) {
-    if (!tileSumsValid) tile_sums_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, tl);
-    finalize_scan_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB, tl);
+    if (!tileSumsValid && chainFlags && chained)
+      finalize_scan_chained_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, (u64 *)chainFlags, (u64 *)chainFlags + 2 * (nb + 2), epoch, prefA, prefB, tl);
+    else {
+      if (!tileSumsValid) tile_sums_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, tl);
+      finalize_scan_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB, tl);
+    }
   }
   const i64 mm = share ? share->nRegions : m;
   const i64 work = (mm > nb ? mm : nb) > 0 ? (mm > nb ? mm : nb) : 1;
