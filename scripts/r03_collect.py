@@ -19,11 +19,11 @@ def sha16(files=("gtx_kernels.hip", "gtx_kernels.h", "gtx_capi.hip")):
     return h.hexdigest()[:16]
 
 
-for a in ("bench_line", "bench_scans_line", "bench_perm_line", "bench_c5_line", "bench_line_under_rocprof", "bench_rehearse4_line", "bench_selftest_line"):
+for a in ("bench_line", "bench_scans_line", "bench_perm_line", "bench_c5_line", "bench_line_under_rocprof", "bench_rehearse4_line", "bench_selftest_line", "bench_fallback2_line"):
     if os.path.exists(src + a + ".json") and os.path.getsize(src + a + ".json"):
         shutil.copy(src + a + ".json", R + "profiles/%s_%s.json" % (rnd, a))
 for tag, name in (("stats", "bench"), ("stats_scans", "bench_scans"), ("stats_perm", "bench_perm"), ("stats_c5", "c5_bench"), ("stats_bucket", "bucket"), ("stats_covshuf", "cov_shuffled"),
-                  ("stats_cov", "coverage"), ("stats_scanfine", "scan_geometries"), ("stats_share", "share_member")):
+                  ("stats_cov", "coverage"), ("stats_scanfine", "scan_geometries"), ("stats_share", "share_member"), ("stats_pairs", "pairs")):
     f = newest(src + tag + "/*/*kernel_stats.csv")
     if f:
         shutil.copy(f, R + "profiles/%s_%s_kernel_stats.csv" % (rnd, name))
@@ -32,9 +32,9 @@ for t in ("share_timing.txt", "share_timing_1g.txt", "membench_100m.txt", "membe
         shutil.copy(src + t, R + "profiles/%s_%s" % (rnd, t))
 if os.path.exists(src + "wave_trace.txt"):
     open(R + "profiles/%s_wave_trace.txt" % rnd, "w").write("".join(l for l in open(src + "wave_trace.txt") if l.startswith(("{", "alive", "streaming"))))
-for log in ("bench_bucket.log", "bench_cov.log", "bench_scan.log", "bench_covshuf.log", "bench_scanshuf.log"):
+for log in ("bench_bucket.log", "bench_cov.log", "bench_scan.log", "bench_covshuf.log", "bench_scanshuf.log", "bench_pairs.log"):
     if os.path.exists(src + log):
-        keep = [l for l in open(src + log) if ("bucket path" in l or "coverage:" in l or "coverage, " in l or "scan -w" in l or "bit-equal" in l)]
+        keep = [l for l in open(src + log) if ("bucket path" in l or "coverage:" in l or "coverage, " in l or "scan -w" in l or "bit-equal" in l or "per call" in l or "gtx_set_ref_blocks" in l or "gtx_count_add_regions" in l)]
         open(R + "profiles/%s_%s.txt" % (rnd, log[:-4]), "w").write("".join(keep))
 
 

@@ -39,8 +39,9 @@ python3 scripts/share_timing.py 8 100000000 > $out/share_timing.txt 2>&1 && echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_share -- python3 scripts/share_timing.py 8 100000000 > /dev/null 2>> $out/rocprof.err && echo "share stats ok"
 python3 scripts/share_timing.py 8 1000000000 > $out/share_timing_1g.txt 2>&1 && echo "share timing 1G ok"
 ./scripts/membench.bin 100000000 > $out/membench_100m.txt 2>&1; ./scripts/membench.bin 1000000000 > $out/membench_1g.txt 2>&1; echo "membench ok"
-GTX_LIB_PATH=$PWD/ibm-cbc-genomic-tools_amd/csrc/libgtx_trace.so python3 scripts/wave_trace.py --cpw 56 --sched "none;-" --out $out/wave_trace.json > $out/wave_trace.txt 2>&1 && echo "wave trace ok"
 python3 scripts/ab_count.py --rounds 3 new=- none=-,GTX_SCHED=none > $out/ab_sched.txt 2>&1 && echo "ab ok"
 GTX_BENCH_REHEARSE=1 GTX_BENCH_VERIFY=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 4 --steps 5 --warmup 2 --no-e2e --cpu-sample 0 > $out/bench_rehearse4_line.json 2> $out/rehearse4.err && echo "rehearsal (4 members on one GPU, verified) ok"
 GTX_BENCH_FORCE_DIST=1 GTX_BENCH_VERIFY=1 python3 bench.py --steps 5 --warmup 2 --no-e2e --cpu-sample 0 > $out/bench_selftest_line.json 2> $out/selftest.err && echo "single-rank RCCL self-test ok"
+GTX_BENCH_REHEARSE=1 GTX_BENCH_BREAK_GROUP=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29545 bench.py --gpus 2 --steps 5 --warmup 2 --no-e2e --cpu-sample 0 > $out/bench_fallback2_line.json 2> $out/fallback2.err && echo "fallback path (group disabled on purpose, 2 ranks on one GPU) ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_pairs -- python3 scripts/bench_pairs.py > $out/bench_pairs.log 2>&1 && echo "pairs stats ok"
 echo "refresh done"
