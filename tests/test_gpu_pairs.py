@@ -182,3 +182,23 @@ def test_argument_checks(engine, sets, tmp_path):
     hits, _ = engine.count_stream([], regions=[(env, None, f, b)])
     np.testing.assert_array_equal(hits, oracle_counts(tmp_path, flat, (env, f, b)))
     assert 0 < int(hits.sum()) < int(oracle_counts(tmp_path, flat, (env, f, b), ["-gaps"]).sum())
+
+
+def test_edges(engine, tmp_path):
+    """No regions at all, classes nobody knows, a region list without any multi-interval region, the one-shot call."""
+    env = np.array([[0, 10, 50], [7, 10, 50], [-1, 10, 50]], dtype=np.int32); f = np.array([0, 2, 4, 6], dtype=np.int64)
+    b = np.array([[10, 20], [30, 50]] * 3, dtype=np.int32)
+    engine.set_refs(np.zeros((0, 3), dtype=np.int32), 3)
+    engine.set_ref_blocks(np.zeros(1, dtype=np.int64), np.zeros((0, 2), dtype=np.int32))
+    hits, _ = engine.count_stream([(np.array([[0, 1, 5]], dtype=np.int32), None)], regions=[(env, None, f, b)])
+    assert len(hits) == 0
+    refs = np.array([[0, 15, 25], [0, 21, 29], [1, 1, 100], [0, 45, 60]], dtype=np.int32)
+    engine.set_refs(refs, 3)
+    engine.set_ref_blocks(np.arange(5), refs[:, 1:3])                      # every region its one interval: nothing to correct
+    hits, _ = engine.count_stream([], regions=[(env, None, f, b)])          # classes 7 and -1 match nothing
+    assert hits.tolist() == [1, 0, 0, 1]                                   # [10,20] meets [15,25]; [21,29] lies in the gap; [30,50] meets [45,60]
+    blocks = np.array([[15, 17], [24, 25], [21, 22], [28, 29], [1, 100], [45, 60]], dtype=np.int32)
+    engine.set_ref_blocks(np.array([0, 2, 4, 5, 6]), blocks)
+    hits, _ = engine.count(np.array([[0, 18, 23], [0, 23, 23], [0, 16, 16], [1, 5, 5]], dtype=np.int32))   # gtx_count, one shot
+    assert hits.tolist() == [1, 1, 1, 0]                                   # region 0: only [16,16]; region 1: only [18,23] ([21,22]); [23,23] lies in both gaps
+    engine.set_ref_blocks(None)
