@@ -558,7 +558,7 @@ __global__ __launch_bounds__(1024) void bucket_cover_kernel(CoverArgs cv, Bucket
 static constexpr int kScanBins32 = 30720, kScanBins64 = 15360;   // 120 KB of LDS counters
 
 template <bool WEIGHTED>
-__global__ __launch_bounds__(1024) void bucket_scanhist_kernel(ScanArgs sc, BucketTable t, BucketWork w, const ScanPart *__restrict__ parts)
+__global__ __launch_bounds__(1024) void bucket_scanhist_kernel(ScanArgs sc, BucketTable t, BucketWork w, const ScanPart *__restrict__ parts, u64 *__restrict__ out)
 {
   typedef typename std::conditional<WEIGHTED, u64, unsigned>::type ct;
   extern __shared__ unsigned char ldsRaw[];
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(1024) void bucket_scanhist_kernel(ScanArgs sc, Buck
   const ScanPart pt = parts[blockIdx.x];
   const int b = pt.bucket, cls = t.cls[b];
   const unsigned r0 = w.rowOff[b], r1 = w.rowOff[b + 1];
-  if (r0 == r1) return;
+  if (r0 == r1 && !out) return;                                     // (out: the part's windows are written here, zeros included)
   for (int i = threadIdx.x; i < pt.count; i += blockDim.x) h[i] = 0;
   __syncthreads();
   const i64 nm = sc.nMicro[cls];
@@ -604,11 +604,67 @@ __global__ __launch_bounds__(1024) void bucket_scanhist_kernel(ScanArgs sc, Buck
     }
   }
   __syncthreads();
+  if (out) {
+    // The sliding sums straight from the part's histogram (no micro-window array in HBM, no window pass): window k = sum of the
+    // micro-windows k .. k + comb - 1.  A window that lies inside the part is stored; one that reaches into the next part is a
+    // partial sum here and gets the rest from there, both with atomics on a place scan_zero_edges_kernel has cleared -- the
+    // windows that start less than comb - 1 before this part's first micro-window are the other half of that.
+    const i64 nWin = sc.winOff[cls + 1] - sc.winOff[cls];
+    u64 *__restrict__ o = out + sc.outOff[cls];
+    const int comb = sc.comb;
+    // the histogram becomes its own inclusive prefix sum (a thread takes `per` consecutive bins -- an odd number, so that the lanes of
+    // a wave stay on different banks --, wave scan of the threads' totals, offsets added in a second turn): a window is then two reads
+    __shared__ u64 wtot[16];
+    int per = (pt.count + (int)blockDim.x - 1) / (int)blockDim.x; per |= 1;
+    const int lo = min((int)threadIdx.x * per, pt.count), hi = min(lo + per, pt.count);
+    ct run = 0;
+    for (int x = lo; x < hi; x++) { run += h[x]; h[x] = run; }
+    u64 inc = (u64)run;
+#pragma unroll
+    for (int d2 = 1; d2 < 64; d2 <<= 1) { const u64 up = __shfl_up(inc, d2); if ((int)lane >= d2) inc += up; }
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    u64 off = inc - (u64)run;
+    for (unsigned k2 = 0; k2 < wv; k2++) off += wtot[k2];
+    if (off) for (int x = lo; x < hi; x++) h[x] += (ct)off;
+    __syncthreads();
+    for (int i = threadIdx.x; i < pt.count; i += blockDim.x) {
+      const i64 k = (i64)pt.first + i;
+      if (k >= nWin) break;
+      const int top = i + comb < pt.count ? i + comb : pt.count;
+      const u64 s = (u64)h[top - 1] - (i ? (u64)h[i - 1] : 0ull);
+      if (i + comb <= pt.count) o[k] = s;
+      else if (s) atomicAdd(o + k, s);
+    }
+    for (int e = threadIdx.x; e < comb - 1; e += blockDim.x) {
+      const i64 k = (i64)pt.first - (comb - 1) + e;                   // its micro-windows k .. k + comb - 1 end inside (or beyond) this part
+      if (k < 0 || k >= nWin) continue;
+      const i64 top = k + comb - pt.first < pt.count ? k + comb - pt.first : pt.count;
+      const u64 s = top > 0 ? (u64)h[top - 1] : 0ull;
+      if (s) atomicAdd(o + k, s);
+    }
+    return;
+  }
   ct *dst = (ct *)sc.micro + sc.microOff[cls] + pt.first;
   for (int i = threadIdx.x; i < pt.count; i += blockDim.x) { const ct v = h[i]; if (v) atomicAdd(&dst[i], v); }
 }
 
+// the windows that take contributions from two parts (bucket_scanhist_kernel with `out`): cleared before the parts run
+__global__ __launch_bounds__(64) void scan_zero_edges_kernel(ScanArgs sc, BucketTable t, const ScanPart *__restrict__ parts, u64 *__restrict__ out)
+{
+  const ScanPart pt = parts[blockIdx.x];
+  if (pt.first == 0) return;
+  const int cls = t.cls[pt.bucket];
+  const i64 nWin = sc.winOff[cls + 1] - sc.winOff[cls];
+  u64 *__restrict__ o = out + sc.outOff[cls];
+  for (int e = threadIdx.x; e < sc.comb - 1; e += blockDim.x) {
+    const i64 k = (i64)pt.first - (sc.comb - 1) + e;
+    if (k >= 0 && k < nWin) o[k] = 0;
+  }
+}
+
 int scan_part_bins(bool weighted) { return weighted ? kScanBins64 : kScanBins32; }
+int scan_fused_max_comb() { return 64; }
 
 int bucket_e_size() { return kBktE; }
 int bucket_s_size() { return kBktS; }
@@ -718,9 +774,10 @@ hipError_t launch_count_bucketed(const void *reads, const void *weights, i64 n, 
 }
 
 hipError_t launch_scan_bucketed(const void *reads, const void *weights, i64 n, const CountArgs &a, const ScanArgs &sc, const BucketTable &t,
-                                const BucketWork &w, const BucketPlan &p, const ScanPart *parts, int nParts, hipStream_t st)
+                                const BucketWork &w, const BucketPlan &p, const ScanPart *parts, int nParts, hipStream_t st, u64 *out)
 {
   if (n <= 0 || nParts <= 0) return hipSuccess;
+  if (out && sc.comb > 1) scan_zero_edges_kernel<<<(unsigned)nParts, 64, 0, st>>>(sc, t, parts, out);
   hipError_t e = launch_partition(reads, weights, n, a, t, w, p, st);
   if (e != hipSuccess) return e;
   static PerDevice attr;
@@ -731,8 +788,8 @@ hipError_t launch_scan_bucketed(const void *reads, const void *weights, i64 n, c
   });
   if (e != hipSuccess) return e;
   const size_t lds = (size_t)scan_part_bins(weights != nullptr) * (weights ? 8 : 4);
-  if (weights) bucket_scanhist_kernel<true><<<(unsigned)nParts, 1024, lds, st>>>(sc, t, w, parts);
-  else bucket_scanhist_kernel<false><<<(unsigned)nParts, 1024, lds, st>>>(sc, t, w, parts);
+  if (weights) bucket_scanhist_kernel<true><<<(unsigned)nParts, 1024, lds, st>>>(sc, t, w, parts, out);
+  else bucket_scanhist_kernel<false><<<(unsigned)nParts, 1024, lds, st>>>(sc, t, w, parts, out);
   return hipGetLastError();
 }
 

@@ -1477,7 +1477,18 @@ static int scan_bucket_tables(gtx_ctx *c, const int32_t *classLen, int nClasses,
 
 // one batch of reads into the micro-window histogram (zeroed by the caller): the partition path for a batch in no particular order
 // under the unsorted scanner's rule, the general kernel otherwise
-static int scan_hist_any(gtx_ctx *c, const void *dR, const int *dW, int64_t n, const gtx::ScanArgs &a, const int32_t *classLen, bool unsorted)
+// the partition path serves this call (reads in no order, the bin index's rules, a batch worth partitioning, tables that fit)
+static int scan_takes_buckets(gtx_ctx *c, const int *dW, int64_t n, const gtx::ScanArgs &a, const int32_t *classLen, bool unsorted, bool *yes)
+{
+  *yes = false;
+  if (!(unsorted && !a.sortedRule && n >= c->bucketMinReads && n < (1ll << 31))) return GTX_OK;
+  int rc = scan_bucket_tables(c, classLen, a.nClasses, a.winStep, dW != nullptr); if (rc) return rc;
+  *yes = c->nBS > 0 && gtx::bucket_plan(n, a.nClasses, c->nBS, c->nCellsS, dW != nullptr).pairs < (1ull << 32);
+  return GTX_OK;
+}
+
+// d_windows (may be null): the partition path writes the windows itself (gtx::launch_scan_bucketed)
+static int scan_hist_any(gtx_ctx *c, const void *dR, const int *dW, int64_t n, const gtx::ScanArgs &a, const int32_t *classLen, bool unsorted, u64 *d_windows = nullptr)
 {
   if (unsorted && !a.sortedRule && n >= c->bucketMinReads && n < (1ll << 31)) {
     int rc = scan_bucket_tables(c, classLen, a.nClasses, a.winStep, dW != nullptr); if (rc) return rc;
@@ -1489,11 +1500,12 @@ static int scan_hist_any(gtx_ctx *c, const void *dR, const int *dW, int64_t n, c
         const gtx::BucketTable t = bucket_table(c->d_bktS, c->nBS, c->d_clsCellS, c->d_cellTabS, c->nCellsS, c->cellShiftS);
         gtx::CountArgs ca = {};                                      // what the partition pass reads of it; its counts of dropped reads go nowhere
         ca.nClasses = a.nClasses; ca.zeroLenOk = 0; ca.coverRule = 1; ca.keyCenter = a.center; ca.info = c->d_scanInfo; ca.indexBase = 0;
-        HIPCHK(c, gtx::launch_scan_bucketed(dR, dW, n, ca, a, t, w, p, c->d_scanParts, c->nScanParts, c->stream));
+        HIPCHK(c, gtx::launch_scan_bucketed(dR, dW, n, ca, a, t, w, p, c->d_scanParts, c->nScanParts, c->stream, d_windows));
         return GTX_OK;
       }
     }
   }
+  if (d_windows) return fail(c, GTX_E_STATE, "gtx_scan: internal: the partition path was announced and not taken");
   HIPCHK(c, gtx::launch_scan_hist(dR, dW, n, a, c->stream));
   return GTX_OK;
 }
@@ -1523,6 +1535,18 @@ static int scan_launch(gtx_ctx *c, const void *d_reads, const void *d_weights, i
     if (microBytes) HIPCHK(c, gtx::launch_scan_zero(c->d_micro, (long long)microBytes, runIf, c->stream));
     HIPCHK(c, gtx::launch_scan_hist(d_reads, d_weights, n, a, c->stream, runIf));
   } else {
+    // reads in no order through the partition path: its parts write the windows themselves (no micro-window array, no window pass)
+    static const bool fuseOff = getenv("GTX_SCAN_FUSED") && atoi(getenv("GTX_SCAN_FUSED")) == 0;
+    bool buckets = false;
+    if (!fuseOff && a.comb <= gtx::scan_fused_max_comb() && c->scanTotalWindows > 0) {
+      rc = scan_takes_buckets(c, (const int *)d_weights, n, a, classLen, (flags & GTX_READS_UNSORTED) != 0, &buckets); if (rc) return rc;
+    }
+    if (buckets) {
+      if (profile) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+      rc = scan_hist_any(c, d_reads, (const int *)d_weights, n, a, classLen, true, (u64 *)d_out); if (rc) return rc;
+      if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+      return GTX_OK;
+    }
     if (microBytes) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, microBytes, c->stream));
     if (profile) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     rc = scan_hist_any(c, d_reads, (const int *)d_weights, n, a, classLen, (flags & GTX_READS_UNSORTED) != 0); if (rc) return rc;

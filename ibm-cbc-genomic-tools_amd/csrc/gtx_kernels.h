@@ -170,7 +170,11 @@ hipError_t launch_cover_bucketed(const void *reads, const void *weights, long lo
 struct ScanPart { int bucket, first, count, pad; };
 int scan_part_bins(bool weighted);     // micro-windows one part keeps in LDS
 hipError_t launch_scan_bucketed(const void *reads, const void *weights, long long n, const CountArgs &a, const ScanArgs &sc, const BucketTable &t,
-                                const BucketWork &w, const BucketPlan &p, const ScanPart *parts, int nParts, hipStream_t st);
+                                const BucketWork &w, const BucketPlan &p, const ScanPart *parts, int nParts, hipStream_t st,
+                                unsigned long long *out = nullptr);
+// out (may be null): the caller's window vector -- the parts then write their windows themselves (sliding sums from the LDS histogram,
+// the windows across a part's edge by atomics on cleared places): no micro-window array, no window pass.  comb <= scan_fused_max_comb().
+int scan_fused_max_comb();
 hipError_t launch_tile_sums(unsigned long long *histA, unsigned long long *histB, long long histLen, unsigned long long *tileA, unsigned long long *tileB, hipStream_t st);
 
 // ---- intervals the rank difference does not cover (gtx_special.hip): plain pair tests, reference semantics of the sorted merge
