@@ -1415,10 +1415,11 @@ static int scan_bucket_tables(gtx_ctx *c, const int32_t *classLen, int nClasses,
   long long total = 0;
   for (int i = 0; i < nClasses; i++) total += classLen[i] < 0 ? 0 : classLen[i] / step;
   static const long long want = getenv("GTX_SCAN_BUCKETS") && atoll(getenv("GTX_SCAN_BUCKETS")) > 0 ? atoll(getenv("GTX_SCAN_BUCKETS")) : 2000;     // (100 M shuffled reads, -d 25: 500 -> 2.77 ms, 1000 -> 2.30, 2000 -> 2.15, 3000 -> 2.10)
-  const long long per = std::max<long long>(16384, (total + want - 1) / want);     // micro-windows per bucket
+  long long per = std::max<long long>(16384, (total + want - 1) / want);           // micro-windows per bucket
   std::vector<int32_t> posHi, eLo, eHi, sLo, sHi, cls, clsStart(nClasses + 1, 0);
   std::vector<gtx::ScanPart> parts;
   const int bins = gtx::scan_part_bins(weighted);
+  if (per > bins) per = per / bins * bins;          // whole parts: every part of a bucket reads all of the bucket's chunks, a short last one as well
   for (int cl = 0; cl < nClasses; cl++) {
     clsStart[cl] = (int32_t)posHi.size();
     const long long nm = classLen[cl] < 0 ? 0 : classLen[cl] / step;
