@@ -53,6 +53,12 @@ struct gtx_ctx {
   int *d_posE = nullptr, *d_posS = nullptr, *d_classBase = nullptr;
   u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr, *d_prefA = nullptr, *d_prefB = nullptr;
   unsigned *d_chainFlags = nullptr; unsigned chainEpoch = 0;    // finalize_scan_chained_kernel: a flag per tile and histogram, the call's epoch
+  // The group's device calls (gtxi_count_device_share_async) finalize call k on the group's exchange stream UNDER the streaming kernel
+  // of call k+1: two more sets of histograms, tile sums, prefix arrays and chain flags in turn (never set 0: the other entry points
+  // stay as they are), three info blocks (call k counts into block k % 3, its finalize resets block (k + 2) % 3 -- the one call k+1
+  // uses was reset by the finalize of call k-1, which the streaming kernel of call k+1 is made to wait for anyway).
+  struct HistSet { u64 *histA = nullptr, *histB = nullptr, *partA = nullptr, *partB = nullptr, *prefA = nullptr, *prefB = nullptr; unsigned *flags = nullptr; unsigned epoch = 0; } alt[2];
+  gtx::DevInfo *d_info3 = nullptr; unsigned shareSeq = 0; const gtx::DevInfo *lastShareInfo = nullptr;
   bool histDirty = false;              // a call was abandoned between begin and end
   // coverage (allocated on first use): 8 histograms, 8 tile-sum arrays, 8 prefix arrays, region coordinates
   // coverage (made on first use): the merged threshold array of the regions (E_k and S_k - 1, sorted per class) with its
@@ -135,7 +141,15 @@ struct gtx_ctx {
 
 static int fail(gtx_ctx *c, int code, const char *msg) { c->err = msg; return code; }
 
+template <class T> static void dfree(T *&p);
+static void free_alt_sets(gtx_ctx *c);
+
 template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+static void free_alt_sets(gtx_ctx *c)
+{
+  for (auto &h : c->alt) { dfree(h.histA); dfree(h.histB); dfree(h.partA); dfree(h.partB); dfree(h.prefA); dfree(h.prefB); dfree(h.flags); h.epoch = 0; }
+  c->shareSeq = 0; c->lastShareInfo = nullptr;
+}
 
 // direct placement (gtx::PlaceTable) over two boundary arrays with the class segments `seg` (the same array twice for the
 // coverage thresholds): cells of 2^sh positions, sh the smallest shift that keeps the table at about one cell per eight
@@ -227,7 +241,7 @@ void gtx_destroy(gtx_ctx *c)
   dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab); dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;
   dfree(c->d_placeCls); dfree(c->d_placeRank); dfree(c->d_placeClsT); dfree(c->d_placeRankT); dfree(c->d_shareTiles); dfree(c->d_shareRegions);
   dfree(c->d_bktCnt); dfree(c->d_bktS); dfree(c->d_clsCellS); dfree(c->d_cellTabS); dfree(c->d_scanParts); dfree(c->d_scanInfo); c->nBS = 0;
-  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info); dfree(c->d_chainFlags);
+  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info); dfree(c->d_chainFlags); free_alt_sets(c); dfree(c->d_info3);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   for (int k = 0; k < 2; k++) {
     dfree(c->d_stage[k]); dfree(c->d_stageW[k]);
@@ -343,7 +357,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab);
   dfree(c->d_placeCls); dfree(c->d_placeRank);
   dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;      // tables over the coverage thresholds: rebuilt by cover_prepare
-  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_chainFlags);
+  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_chainFlags); free_alt_sets(c);
   c->nRefs = -1;
   const int64_t histLen = nv + nClasses;
   const int nTiles = gtx::scan_tiles(histLen);
@@ -505,12 +519,13 @@ extern "C" int gtx_debug_trace_read(unsigned long long *out, long long nWaves)
 }
 #endif
 
-static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int64_t indexBase = 0)
+static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int64_t indexBase = 0, const gtx_ctx::HistSet *set = nullptr)
 {
   gtx::CountArgs a;
   a.indexBase = indexBase;
   a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart;
   a.histA = c->d_histA; a.histB = c->d_histB; a.partA = c->d_partA; a.partB = c->d_partB; a.info = c->d_info + c->infoCur;
+  if (set) { a.histA = set->histA; a.histB = set->histB; a.partA = set->partA; a.partB = set->partB; }
   a.nClasses = c->nClasses;
   // Large batches: the streaming kernel leaves the per-tile sums alone and the finalize step rebuilds them from the
   // histograms (tile_sums_kernel, one pass over 16 B per region: 6 us at 1 M regions).  Keeping them up to date costs two
@@ -675,6 +690,7 @@ static int count_begin(gtx_ctx *c)
   if (c->histDirty && c->d_pairAcc) HIPCHK(c, hipMemsetAsync(c->d_pairAcc, 0, sizeof(u64) * 2 * (size_t)std::max<int64_t>(c->nRefs, 1), c->stream));
   c->sideUsed = false; c->pairUsed = false;
   c->histDirty = true; c->tileSumsValid = true;
+  c->lastShareInfo = nullptr;
   return GTX_OK;
 }
 
@@ -1837,6 +1853,67 @@ int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weigh
   rc = count_end(c, dst, true); if (rc) return rc;
   if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   *d_piece = dst; *pieceLen = c->nShareRegions;
+  return GTX_OK;
+}
+
+// The same with the finalize step on `fin` (the group's exchange stream of this member) behind the streaming kernel, which runs on
+// the context's stream: the streaming kernel of the NEXT call need not wait for it.  The caller has made the context's stream wait for
+// the finalize of the call before last (same slot: same histogram set, same piece of the output vector).  Reads in stream order only
+// (a batch in no order takes gtxi_count_device_share).
+int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, hipStream_t fin,
+                                  hipEvent_t evCounted, void **d_piece, int64_t *pieceLen)
+{
+  if (!c->shareOn) return fail(c, GTX_E_STATE, "gtxi_count_device_share_async: no share set");
+  if (c->refBlocks || (flags & GTX_ZERO_LENGTH_OK) || !(flags & GTX_READS_SORTED) || n < 0 || (n > 0 && !d_reads))
+    return fail(c, GTX_E_ARG, "gtxi_count_device_share_async: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  gtx_ctx::HistSet &h = c->alt[slot & 1];
+  const int nTiles = gtx::scan_tiles(c->histLen);
+  if (!h.histA) {
+    u64 **arr[] = {&h.histA, &h.histB, &h.prefA, &h.prefB};
+    for (u64 **p : arr) HIPCHK(c, hipMalloc(p, sizeof(u64) * c->histLen));
+    HIPCHK(c, hipMalloc(&h.partA, sizeof(u64) * (nTiles + 2))); HIPCHK(c, hipMalloc(&h.partB, sizeof(u64) * (nTiles + 2)));
+    HIPCHK(c, hipMalloc(&h.flags, sizeof(unsigned) * 8 * (nTiles + 2)));
+    HIPCHK(c, hipMemset(h.histA, 0, sizeof(u64) * c->histLen)); HIPCHK(c, hipMemset(h.histB, 0, sizeof(u64) * c->histLen));
+    HIPCHK(c, hipMemset(h.partA, 0, sizeof(u64) * (nTiles + 2))); HIPCHK(c, hipMemset(h.partB, 0, sizeof(u64) * (nTiles + 2)));
+    HIPCHK(c, hipMemset(h.flags, 0, sizeof(unsigned) * 8 * (nTiles + 2)));
+    h.epoch = 0;
+  }
+  if (!c->d_info3) {
+    HIPCHK(c, hipMalloc(&c->d_info3, 3 * sizeof(gtx::DevInfo)));
+    for (int k = 0; k < 3; k++) HIPCHK(c, hipMemcpy(c->d_info3 + k, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice));
+  }
+  const unsigned k = c->shareSeq++;
+  gtx::DevInfo *info = c->d_info3 + k % 3, *infoNext = c->d_info3 + (k + 2) % 3;
+  c->profThis = c->prof && (c->profEvery <= 1 || (c->profSeq++ % c->profEvery) == 0);
+  if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
+  const bool keepDefault = c->tileSumsValid;
+  c->tileSumsValid = true;
+  gtx::CountArgs a = count_args(c, flags, n, 0, &h);               // (clears c->tileSumsValid when the kernel leaves the tile sums to the finalize step)
+  a.info = info;
+  const bool sumsValid = c->tileSumsValid;
+  c->tileSumsValid = keepDefault;
+  if (n > 0) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, a, true, c->stream));
+  if (c->profThis) { HIPCHK(c, hipEventRecord(c->ev[2], c->stream)); if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
+  HIPCHK(c, hipEventRecord(evCounted, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(fin, evCounted, 0));
+  u64 *dst = c->d_out + (slot & 1) * c->nRefs + c->shareOffset;
+  gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions};
+  if (++h.epoch == 0) { HIPCHK(c, hipMemsetAsync(h.flags, 0, sizeof(unsigned) * 8 * (nTiles + 2), fin)); h.epoch = 1; }
+  HIPCHK(c, gtx::launch_finalize(h.histA, h.histB, c->histLen, h.partA, h.partB, sumsValid, h.prefA, h.prefB, c->d_posE, c->d_posS, c->d_classBase,
+                                 c->nRefs, dst, infoNext, fin, &fs, h.flags, h.epoch));
+  c->lastShareInfo = info;
+  *d_piece = dst; *pieceLen = c->nShareRegions;
+  return GTX_OK;
+}
+
+// what the last gtxi_count_device_share_async call observed (the caller has waited for its streams)
+int gtxi_last_share_info(gtx_ctx *c, gtx_count_info *info)
+{
+  if (!c->lastShareInfo) return gtx_last_info(c, info);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy(&c->h_info[0], c->lastShareInfo, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost));
+  info_out(c->h_info[0], info, 0);
   return GTX_OK;
 }
 

@@ -110,6 +110,7 @@ struct gtx_group {
   std::vector<int64_t> memberReads;        // reads routed to each member in the open call
   bool countOpen = false, coverOpen = false;
   unsigned long long regionsTurn = 0;                 // gtx_group_count_add_regions: next member
+  bool lastAsync = false;                             // the last device count call finalized on the exchange streams
   bool rehearse = false;                   // GTX_GROUP_REHEARSE=1
   bool selfExchange = false;               // GTX_GROUP_SELF_EXCHANGE=1 (test hook): member 0's own piece travels through RCCL to itself
   int64_t nRefs = 0; uint32_t refFlags = 0; int32_t nClasses = 0;
@@ -415,9 +416,19 @@ int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void 
     GCHK_HIP(g, hipSetDevice(g->dev[li]));
     // compact vector `slot` is free again when the exchange of the call before last is over (a device-side wait)
     if (g->xchgUsed[slot]) GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[slot][li], 0));
-    GCHK_CTX(g, li, gtxi_count_device_share(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, slot, &piece[li], &len));
-    GCHK_HIP(g, hipEventRecord(g->evFinal[slot][li], gtxi_stream(g->ctx[li])));
-    GCHK_HIP(g, hipStreamWaitEvent(g->xs[li], g->evFinal[slot][li], 0));
+    // reads in stream order: the member's finalize step goes to its exchange stream, under the streaming kernel of the next call
+    // (GTX_GROUP_ASYNC_FINALIZE=0, or a batch in no order: on the member's own stream, in front of it)
+    static const bool asyncOff = getenv("GTX_GROUP_ASYNC_FINALIZE") && atoi(getenv("GTX_GROUP_ASYNC_FINALIZE")) == 0;
+    if (!asyncOff && (flags & GTX_READS_SORTED) && !(flags & GTX_ZERO_LENGTH_OK)) {
+      GCHK_CTX(g, li, gtxi_count_device_share_async(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, slot,
+                                                     g->xs[li], g->evFinal[slot][li], &piece[li], &len));
+      g->lastAsync = true;
+    } else {
+      GCHK_CTX(g, li, gtxi_count_device_share(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, slot, &piece[li], &len));
+      GCHK_HIP(g, hipEventRecord(g->evFinal[slot][li], gtxi_stream(g->ctx[li])));
+      GCHK_HIP(g, hipStreamWaitEvent(g->xs[li], g->evFinal[slot][li], 0));
+      g->lastAsync = false;
+    }
   }
   const int l0 = g->local(0);
   unsigned long long *root = l0 >= 0 ? (unsigned long long *)gtxi_out_buffer(g->ctx[l0]) + (size_t)slot * (size_t)g->nRefs : nullptr;
@@ -455,6 +466,10 @@ int gtx_group_last_info(gtx_group *g, gtx_count_info *info)
   gtx_count_info tot; tot.first_unsorted = -1; tot.first_degenerate = -1; tot.n_no_class = 0; tot.n_degenerate = 0; tot.n_unplaced = 0;
   for (size_t li = 0; li < g->ctx.size(); li++) {
     gtx_count_info one;
+    if (g->lastAsync) {                                          // (the member's finalize ran on its exchange stream)
+      if (li < g->xs.size() && g->xs[li]) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamSynchronize(g->xs[li])); }
+      GCHK_CTX(g, li, gtxi_last_share_info(g->ctx[li], &one));
+    } else
     GCHK_CTX(g, li, gtx_last_info(g->ctx[li], &one));
     tot.n_no_class += one.n_no_class; tot.n_degenerate += one.n_degenerate; tot.n_unplaced += one.n_unplaced;
   }
@@ -647,6 +662,8 @@ int gtx_group_count_begin(gtx_group *g)
 {
   if (!g) return GTX_E_ARG;
   NEED_ALL_LOCAL(g, "gtx_group_count_begin");
+  { int rcw = wait_exchanges(g); if (rcw) return rcw; }            // (device calls still finalizing / exchanging: their output vector is about to be reused)
+  g->lastAsync = false;
   for (size_t i = 0; i < g->ctx.size(); i++) GCHK_CTX(g, i, gtx_count_begin(g->ctx[i]));
   std::fill(g->memberReads.begin(), g->memberReads.end(), 0);
   g->countOpen = true;

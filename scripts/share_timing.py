@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""What ONE member of an 8-member group does per call on the fixed 100 M x 1 M shape, timed on one GPU (GTX_GROUP_NO_EXCHANGE=1:
+"""(With the finalize step on the exchange stream -- the default for reads in stream order -- "kernel+finalize" below is the streaming
+kernel alone: the events sit on the member's own stream; "per call back to back" is the number that counts.)
+What ONE member of an 8-member group does per call on the fixed 100 M x 1 M shape, timed on one GPU (GTX_GROUP_NO_EXCHANGE=1:
 the member exists without a communicator, nothing travels): the member with the largest LPT share, and member 0 (which also puts
 the compact vector into file order).  Prints kernel ms / whole-call ms by events; run under rocprofv3 for the per-kernel CSV."""
 import os
