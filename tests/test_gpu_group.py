@@ -204,6 +204,42 @@ def test_device_resident_count_pieces_to_member_zero(rehearsal_group):
     np.testing.assert_array_equal(got, np.insert(orc.count(np.delete(refs, 17, axis=0), reads, algo=orc.BIN_INDEX), 17, 0))
 
 
+def test_device_calls_back_to_back_alternate_their_state(rehearsal_group):
+    """Device calls without a wait in between: a member finalizes call k on its exchange stream while its streaming kernel of call k+1
+    counts into the other set of histograms -- two read sets in turn into two output vectors, seven calls; every result, and what the
+    LAST call saw (a read of a class nobody has), must be the call's own."""
+    import torch
+    g = rehearsal_group
+    refs = synth.genome_intervals(40_000, 95, 50, 2000)
+    g.set_refs(refs, synth.n_classes())
+    sets = []
+    for seed, n in ((96, 700_000), (97, 1_300_000)):                 # (the second one is large enough to leave the tile sums to the finalize step)
+        reads = synth.genome_intervals(n, seed, 50, 51)
+        if seed == 97:
+            reads[5, 0] = 200                                        # no such class: counted as such by its member
+        sets.append(reads)
+    owner = g.assign(np.bincount(sets[0][:, 0], minlength=24))
+    dev = []
+    for reads in sets:
+        own = np.where(reads[:, 0] < 24, owner[np.minimum(reads[:, 0], 23)], 0)
+        parts = [np.ascontiguousarray(reads[own == m]) for m in range(3)]
+        dev.append(([torch.from_numpy(p).cuda() for p in parts], [len(p) for p in parts]))
+    want = [orc.count(refs, sets[0], algo=orc.SORTED_MERGE), orc.count(refs, np.delete(sets[1], [5], axis=0), algo=orc.SORTED_MERGE)]
+    hits = [torch.zeros(len(refs), dtype=torch.int64, device="cuda") for _ in range(2)]
+    for k in range(7):
+        d, ns = dev[k & 1]
+        g.count_device([x.data_ptr() for x in d], ns, hits[k & 1].data_ptr(), flags=gtx.READS_SORTED)
+    g.sync()
+    np.testing.assert_array_equal(hits[0].cpu().numpy().view(np.uint64), want[0])        # call 6 (set 0)
+    np.testing.assert_array_equal(hits[1].cpu().numpy().view(np.uint64), want[1])        # call 5 (set 1)
+    assert g.last_info()["n_no_class"] == 0                                              # the last call counted set 0
+    d, ns = dev[1]
+    g.count_device([x.data_ptr() for x in d], ns, hits[1].data_ptr(), flags=gtx.READS_SORTED)
+    g.sync()
+    assert g.last_info()["n_no_class"] == 1
+    np.testing.assert_array_equal(hits[1].cpu().numpy().view(np.uint64), want[1])
+
+
 def test_device_resident_scan_pieces_to_member_zero(rehearsal_group):
     import torch
     g = rehearsal_group
