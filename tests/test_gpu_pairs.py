@@ -202,3 +202,50 @@ def test_edges(engine, tmp_path):
     hits, _ = engine.count(np.array([[0, 18, 23], [0, 23, 23], [0, 16, 16], [1, 5, 5]], dtype=np.int32))   # gtx_count, one shot
     assert hits.tolist() == [1, 1, 1, 0]                                   # region 0: only [16,16]; region 1: only [18,23] ([21,22]); [23,23] lies in both gaps
     engine.set_ref_blocks(None)
+
+
+def test_large_batch_properties_and_one_class_against_the_oracle(engine, tmp_path):
+    """20 M plain reads resident in HBM x 200 k regions of which a third are multi-interval: regions with one interval keep their
+    envelope count, the others can only lose reads; one class (the smallest) against the oracle CLI read by read."""
+    import torch
+    from gtx import synth
+    from bench import make_reads_on_device
+    rng = np.random.default_rng(9)
+    refs = synth.genome_intervals(200_000, 51, 200, 4000)
+    multi = rng.random(len(refs)) < 0.33
+    first = np.zeros(len(refs) + 1, dtype=np.int64); blocks = []
+    for k in range(len(refs)):
+        s, e = int(refs[k, 1]), int(refs[k, 2])
+        if multi[k] and e - s >= 40:
+            cuts = np.sort(rng.choice(np.arange(s + 1, e), size=4, replace=False))
+            blocks += [(s, int(cuts[0])), (int(cuts[1]), int(cuts[2])), (int(cuts[3]), e)]
+        else:
+            multi[k] = False
+            blocks.append((s, e))
+        first[k + 1] = len(blocks)
+    blocks = np.array(blocks, dtype=np.int32)
+    dev = torch.device("cuda", 0)
+    n = 20_000_000
+    reads = make_reads_on_device(n, np.arange(24), 1000, dev)
+    out = torch.zeros(len(refs), dtype=torch.int64, device=dev)
+    engine.set_refs(refs, 24)
+    engine.count_device(reads.data_ptr(), n, out.data_ptr(), None, gtx.READS_SORTED); torch.cuda.synchronize()
+    env = out.cpu().numpy().copy()
+    engine.set_ref_blocks(first, blocks)
+    engine.count_device(reads.data_ptr(), n, out.data_ptr(), None, gtx.READS_SORTED); torch.cuda.synchronize()
+    got = out.cpu().numpy().copy()
+    assert np.array_equal(got[~multi], env[~multi])
+    assert np.all(got[multi] <= env[multi]) and int((env - got).sum()) > 10_000
+    # one class read by read: chr21 (class id by name order)
+    r = reads.cpu().numpy()
+    cls = int(np.argmin(np.bincount(r[:, 0], minlength=24)))
+    sub = r[r[:, 0] == cls]
+    keep = refs[:, 0] == cls
+    idx = np.nonzero(keep)[0]
+    sref = refs[keep].copy(); sref[:, 0] = 0
+    sfirst = np.concatenate(([0], np.cumsum(np.diff(first)[keep])))
+    sblocks = np.concatenate([blocks[first[k]:first[k + 1]] for k in idx])
+    sreads = sub.copy(); sreads[:, 0] = 0
+    want = oracle_counts(tmp_path, (sref, sfirst, sblocks), (sreads, np.arange(len(sreads) + 1), sreads[:, 1:3]))
+    np.testing.assert_array_equal(got[keep].view(np.uint64), want)
+    engine.set_ref_blocks(None)
