@@ -217,7 +217,7 @@ def scan_reads(n, seed):
     return r
 
 
-@pytest.mark.parametrize("step,size", [(1000, 1000), (25, 500), (100, 300), (7, 7 * 13), (1, 4)])
+@pytest.mark.parametrize("step,size", [(1000, 1000), (25, 500), (100, 300), (7, 7 * 13), (1, 4), (25, 1600), (10, 1000)])   # (the last: more micro-windows per window than the parts sum themselves)
 def test_scan_shuffled_reads(beng, step, size):
     rng = np.random.default_rng(61)
     reads = scan_reads(300_000, 61)
