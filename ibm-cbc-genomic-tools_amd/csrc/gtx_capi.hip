@@ -17,6 +17,7 @@
 #include "gtx_kernels.h"
 #include "gtx_pairs.h"
 #include "gtx_text.h"
+#include "gtx_internal.h"
 
 typedef unsigned long long u64;
 
@@ -52,13 +53,13 @@ struct gtx_ctx {
   int64_t bucketMinReads = 1 << 18;                  // below this the per-read search kernel is used (GTX_BUCKET_MIN_READS)
   int *d_posE = nullptr, *d_posS = nullptr, *d_classBase = nullptr;
   u64 *d_histA = nullptr, *d_histB = nullptr, *d_partA = nullptr, *d_partB = nullptr, *d_prefA = nullptr, *d_prefB = nullptr;
-  unsigned *d_chainFlags = nullptr; unsigned chainEpoch = 0;    // finalize_scan_chained_kernel: a flag per tile and histogram, the call's epoch
+  unsigned *d_chainFlags = nullptr; unsigned chainEpoch = 0; unsigned long long chainDraws = 0;    // finalize_scan_chained_kernel: a flag per tile and histogram, the call's epoch
   // The group's device calls (gtxi_count_device_share_async) finalize call k on the group's exchange stream UNDER the streaming kernel
   // of call k+1: two more sets of histograms, tile sums, prefix arrays and chain flags in turn (never set 0: the other entry points
   // stay as they are), three info blocks (call k counts into block k % 3, its finalize resets block (k + 2) % 3 -- the one call k+1
   // uses was reset by the finalize of call k-1, which the streaming kernel of call k+1 is made to wait for anyway).
-  struct HistSet { u64 *histA = nullptr, *histB = nullptr, *partA = nullptr, *partB = nullptr, *prefA = nullptr, *prefB = nullptr; unsigned *flags = nullptr; unsigned epoch = 0; } alt[2];
-  gtx::DevInfo *d_info3 = nullptr; unsigned shareSeq = 0; const gtx::DevInfo *lastShareInfo = nullptr;
+  struct HistSet { u64 *histA = nullptr, *histB = nullptr, *partA = nullptr, *partB = nullptr, *prefA = nullptr, *prefB = nullptr; unsigned *flags = nullptr; unsigned epoch = 0; unsigned long long draws = 0; } alt[GTXI_SHARE_STREAMS];
+  gtx::DevInfo *d_info3 = nullptr; unsigned shareSeq = 0; unsigned shareTurn[GTXI_SHARE_STREAMS] = {}; const gtx::DevInfo *lastShareInfo = nullptr;
   bool histDirty = false;              // a call was abandoned between begin and end
   // coverage (allocated on first use): 8 histograms, 8 tile-sum arrays, 8 prefix arrays, region coordinates
   // coverage (made on first use): the merged threshold array of the regions (E_k and S_k - 1, sorted per class) with its
@@ -147,8 +148,9 @@ static void free_alt_sets(gtx_ctx *c);
 template <class T> static void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 static void free_alt_sets(gtx_ctx *c)
 {
-  for (auto &h : c->alt) { dfree(h.histA); dfree(h.histB); dfree(h.partA); dfree(h.partB); dfree(h.prefA); dfree(h.prefB); dfree(h.flags); h.epoch = 0; }
-  c->shareSeq = 0; c->lastShareInfo = nullptr;
+  for (auto &h : c->alt) { dfree(h.histA); dfree(h.histB); dfree(h.partA); dfree(h.partB); dfree(h.prefA); dfree(h.prefB); dfree(h.flags); h.epoch = 0; h.draws = 0; }
+  c->shareSeq = 0; c->lastShareInfo = nullptr; for (unsigned &t : c->shareTurn) t = 0;
+  dfree(c->d_info3);                              // (the ring restarts with clean blocks: the last calls' blocks are cleared by calls that never came)
 }
 
 // direct placement (gtx::PlaceTable) over two boundary arrays with the class segments `seg` (the same array twice for the
@@ -208,7 +210,7 @@ gtx_ctx *gtx_create(int device_id)
   if (hipMalloc(&c->d_info, 2 * sizeof(gtx::DevInfo)) != hipSuccess || hipHostMalloc(&c->h_info, 2 * sizeof(gtx::DevInfo)) != hipSuccess) {
     g_create_error = "gtx_create: allocation failed"; delete c; return nullptr;
   }
-  c->h_info[1].first_unsorted = INT64_MAX; c->h_info[1].n_no_class = 0; c->h_info[1].n_degenerate = 0; c->h_info[1].first_degenerate = INT64_MAX; c->h_info[1].n_unplaced = 0;
+  c->h_info[1].first_unsorted = INT64_MAX; c->h_info[1].n_no_class = 0; c->h_info[1].n_degenerate = 0; c->h_info[1].first_degenerate = INT64_MAX; c->h_info[1].n_unplaced = 0; c->h_info[1].fault = 0;
   c->h_info[0] = c->h_info[1];
   if (hipMemcpy(c->d_info, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->d_info + 1, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice) != hipSuccess) {
@@ -380,7 +382,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   HIPCHK(c, hipMemset(c->d_partB, 0, sizeof(u64) * (nTiles + 2)));
   HIPCHK(c, hipMalloc(&c->d_chainFlags, sizeof(unsigned) * 8 * (nTiles + 2)));
   HIPCHK(c, hipMemset(c->d_chainFlags, 0, sizeof(unsigned) * 8 * (nTiles + 2)));
-  c->chainEpoch = 0;
+  c->chainEpoch = 0; c->chainDraws = 0;
   c->histDirty = false; c->tileSumsValid = true;
   HIPCHK(c, hipMemcpy(c->d_sortedE, sortedE.data(), sizeof(int32_t) * nv, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_sortedS, sortedS.data(), sizeof(int32_t) * nv, hipMemcpyHostToDevice));
@@ -540,7 +542,9 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int
   // compact piece of the stream (100 M reads: flat from 48 to 64 chunks, +3 % at 96, +12 % at 192 = one round;
   // 1 G reads: 1.74 ms at 48, 1.76 at 64-96, 1.82 at 128; the bare load pattern behaves the same, scripts/membench.hip)
   int cpw = c->chunksPerWave;
-  if (cpw <= 0) { int64_t nChunks = (nReads + 63) >> 6; cpw = (int)std::min<int64_t>(56, std::max<int64_t>(8, nChunks / 24576)); }
+  // (launches of one to three rounds -- a group member's share of 100 M reads -- take 16 chunks per wave from a full round of
+  // 16-chunk spans on: the start of a span is paid once per 16 chunks instead of 8, 0.039 -> 0.034 ms for 12.9 M reads; scripts/r04_share.sh)
+  if (cpw <= 0) { int64_t nChunks = (nReads + 63) >> 6; cpw = (int)std::min<int64_t>(56, std::max<int64_t>(nChunks >= 16 * c->waveSlots ? 16 : 8, nChunks / 24576)); }
   const int r = std::max(1, std::min(4, c->prefetch));
   a.chunksPerWave = (cpw + r - 1) / r * r;
   a.sched = gtx::span_schedule((nReads + 63) >> 6, a.chunksPerWave, r, c->waveSlots);
@@ -553,7 +557,9 @@ static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int
   a.place.cls = c->d_placeCls; a.place.rank = c->d_placeRank; a.place.shift = c->placeShift;
   // dense references (>= 4 boundaries per 256 reads and array): all boundaries of a window at once instead of the
   // per-boundary loop (100 M reads x 4 M regions: 0.41 -> 0.28 ms; at 1 M regions the loop is 3 % faster).  GTX_FLIP=0|1 forces.
-  { static const char *fl = getenv("GTX_FLIP"); a.flip = fl ? atoi(fl) : (c->nValid * 256 >= 4 * std::max<int64_t>(nReads, 1)); }
+  // (a group member streams the reads of ITS classes only: their density is against its own regions, not the whole set's)
+  { static const char *fl = getenv("GTX_FLIP"); const int64_t regions = set && c->shareOn ? std::min<int64_t>(c->nValid, c->nShareRegions) : c->nValid;
+    a.flip = fl ? atoi(fl) : (regions * 256 >= 4 * std::max<int64_t>(nReads, 1)); }
 #ifdef GTX_WAVE_TRACE
   a.trace = gtx_debug_trace_buffer();
 #endif
@@ -700,11 +706,11 @@ static int count_end(gtx_ctx *c, void *d_hits, bool share = false)
   gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions};
   if (++c->chainEpoch == 0) {                       // (after 2^32 calls: the flags start over)
     HIPCHK(c, hipMemsetAsync(c->d_chainFlags, 0, sizeof(unsigned) * 8 * (gtx::scan_tiles(c->histLen) + 2), c->stream));
-    c->chainEpoch = 1;
+    c->chainEpoch = 1; c->chainDraws = 0;
   }
   HIPCHK(c, gtx::launch_finalize(c->d_histA, c->d_histB, c->histLen, c->d_partA, c->d_partB, c->tileSumsValid, c->d_prefA, c->d_prefB,
                                  c->d_posE, c->d_posS, c->d_classBase, c->nRefs, (u64 *)d_hits, c->d_info + (c->infoCur ^ 1), c->stream,
-                                 share ? &fs : nullptr, c->d_chainFlags, c->chainEpoch));
+                                 share ? &fs : nullptr, c->d_chainFlags, c->chainEpoch, c->d_info + c->infoCur, &c->chainDraws));
   { int rc = merge_end(c, d_hits); if (rc) return rc; }
   c->histDirty = false;
   c->infoCur ^= 1;                                // the block just used stays readable until the call after next
@@ -742,6 +748,12 @@ static void info_out(const gtx::DevInfo &d, gtx_count_info *o, int64_t base)
   o->n_unplaced = d.n_unplaced;
 }
 
+// a kernel of the call gave up a bounded wait (DevInfo::fault): its result vector is void
+static int fault_check(gtx_ctx *c, const gtx::DevInfo &d)
+{
+  return d.fault ? fail(c, GTX_E_HIP, "the finalize step gave up waiting for a tile sum (finalize_scan_chained_kernel): the result of this call is void; GTX_CHAINED_SCAN=0 takes the two-launch finalize") : GTX_OK;
+}
+
 int gtx_last_info(gtx_ctx *c, gtx_count_info *info)
 {
   if (!c || !info) return GTX_E_ARG;
@@ -749,7 +761,7 @@ int gtx_last_info(gtx_ctx *c, gtx_count_info *info)
   HIPCHK(c, hipMemcpyAsync(&c->h_info[0], c->d_info + (c->infoCur ^ 1), sizeof(gtx::DevInfo), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   info_out(c->h_info[0], info, 0);
-  return GTX_OK;
+  return fault_check(c, c->h_info[0]);
 }
 
 } // extern "C" (templates below)
@@ -926,7 +938,7 @@ int gtx_count_end(gtx_ctx *c, uint64_t *hits, gtx_count_info *info)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipStreamSynchronize(c->copyStream));
   if (info) gtxi_fetch_info(c, info);
-  return GTX_OK;
+  return fault_check(c, c->h_info[0]);
 }
 
 int gtx_count(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, uint32_t flags, uint64_t *hits, gtx_count_info *info)
@@ -1826,7 +1838,7 @@ int gtxi_set_share(gtx_ctx *c, const uint8_t *owned, int32_t nClasses, const int
   if (!tiles.empty()) HIPCHK(c, hipMemcpy(c->d_shareTiles, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice));
   if (nRegions > 0) HIPCHK(c, hipMemcpy(c->d_shareRegions, regions, sizeof(int32_t) * (size_t)nRegions, hipMemcpyHostToDevice));
   c->nShareTiles = (int)tiles.size(); c->nShareRegions = nRegions; c->shareOffset = offset; c->shareOn = true;
-  return ensure_out(c, 2 * (size_t)c->nRefs);                    // two compact vectors: gtxi_count_device_share alternates (slot)
+  return ensure_out(c, GTXI_SHARE_SLOTS * (size_t)c->nRefs);     // the compact vectors gtxi_count_device_share[_async] takes in turn (slot)
 }
 
 // gtx_count_device for a group member: the reads (of the member's classes, resident on its device) are counted and the member's
@@ -1849,25 +1861,27 @@ int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weigh
     else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n)); if (rc) return rc; }
   }
   if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  u64 *dst = c->d_out + (slot & 1) * c->nRefs + c->shareOffset;
+  u64 *dst = c->d_out + (size_t)(slot % GTXI_SHARE_SLOTS) * c->nRefs + c->shareOffset;
   rc = count_end(c, dst, true); if (rc) return rc;
   if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   *d_piece = dst; *pieceLen = c->nShareRegions;
   return GTX_OK;
 }
 
-// The same with the finalize step on `fin` (the group's exchange stream of this member) behind the streaming kernel, which runs on
-// the context's stream: the streaming kernel of the NEXT call need not wait for it.  The caller has made the context's stream wait for
-// the finalize of the call before last (same slot: same histogram set, same piece of the output vector).  Reads in stream order only
-// (a batch in no order takes gtxi_count_device_share).
-int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, hipStream_t fin,
-                                  hipEvent_t evCounted, void **d_piece, int64_t *pieceLen)
+// The same for reads in stream order, without a wait between successive calls: the streaming kernel and the finalize step of the
+// member's share run on `run` -- the group alternates between two streams of its own, so that the kernel of call k+1 is not ordered
+// behind the kernel of call k and takes the wave slots its tail frees -- with histogram set `set` (0 | 1: one per stream; the stream's
+// order is what keeps call k+2's kernel out of what call k's finalize step is scanning and zeroing).  The finalize step writes the
+// member's piece of compact vector `slot`; the caller has made `run` wait for whatever last read that piece.
+static constexpr int kInfoRing = 2 * GTXI_SHARE_STREAMS;
+int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, int set, hipStream_t run,
+                                  void **d_piece, int64_t *pieceLen)
 {
   if (!c->shareOn) return fail(c, GTX_E_STATE, "gtxi_count_device_share_async: no share set");
   if (c->refBlocks || (flags & GTX_ZERO_LENGTH_OK) || !(flags & GTX_READS_SORTED) || n < 0 || (n > 0 && !d_reads))
     return fail(c, GTX_E_ARG, "gtxi_count_device_share_async: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
-  gtx_ctx::HistSet &h = c->alt[slot & 1];
+  gtx_ctx::HistSet &h = c->alt[set % GTXI_SHARE_STREAMS];
   const int nTiles = gtx::scan_tiles(c->histLen);
   if (!h.histA) {
     u64 **arr[] = {&h.histA, &h.histB, &h.prefA, &h.prefB};
@@ -1877,31 +1891,34 @@ int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d
     HIPCHK(c, hipMemset(h.histA, 0, sizeof(u64) * c->histLen)); HIPCHK(c, hipMemset(h.histB, 0, sizeof(u64) * c->histLen));
     HIPCHK(c, hipMemset(h.partA, 0, sizeof(u64) * (nTiles + 2))); HIPCHK(c, hipMemset(h.partB, 0, sizeof(u64) * (nTiles + 2)));
     HIPCHK(c, hipMemset(h.flags, 0, sizeof(unsigned) * 8 * (nTiles + 2)));
-    h.epoch = 0;
+    h.epoch = 0; h.draws = 0;
   }
   if (!c->d_info3) {
-    HIPCHK(c, hipMalloc(&c->d_info3, 3 * sizeof(gtx::DevInfo)));
-    for (int k = 0; k < 3; k++) HIPCHK(c, hipMemcpy(c->d_info3 + k, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_info3, kInfoRing * sizeof(gtx::DevInfo)));
+    for (int k = 0; k < kInfoRing; k++) HIPCHK(c, hipMemcpy(c->d_info3 + k, &c->h_info[1], sizeof(gtx::DevInfo), hipMemcpyHostToDevice));
   }
-  const unsigned k = c->shareSeq++;
-  gtx::DevInfo *info = c->d_info3 + k % 3, *infoNext = c->d_info3 + (k + 2) % 3;
+  // info blocks: the calls on stream `set` take two blocks in turn; a call's finalize step clears the other one -- the block of the
+  // call that ran on this stream before, for the call that runs on it next
+  const int st = set % GTXI_SHARE_STREAMS;
+  const unsigned turn = c->shareTurn[st]++;
+  c->shareSeq++;
+  gtx::DevInfo *info = c->d_info3 + 2 * st + (turn & 1), *infoNext = c->d_info3 + 2 * st + ((turn + 1) & 1);
   c->profThis = c->prof && (c->profEvery <= 1 || (c->profSeq++ % c->profEvery) == 0);
-  if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], c->stream)); }
+  if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], run)); }
   const bool keepDefault = c->tileSumsValid;
   c->tileSumsValid = true;
   gtx::CountArgs a = count_args(c, flags, n, 0, &h);               // (clears c->tileSumsValid when the kernel leaves the tile sums to the finalize step)
   a.info = info;
   const bool sumsValid = c->tileSumsValid;
   c->tileSumsValid = keepDefault;
-  if (n > 0) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, a, true, c->stream));
-  if (c->profThis) { HIPCHK(c, hipEventRecord(c->ev[2], c->stream)); if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
-  HIPCHK(c, hipEventRecord(evCounted, c->stream));
-  HIPCHK(c, hipStreamWaitEvent(fin, evCounted, 0));
-  u64 *dst = c->d_out + (slot & 1) * c->nRefs + c->shareOffset;
+  if (n > 0) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, a, true, run));
+  if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], run));
+  u64 *dst = c->d_out + (size_t)(slot % GTXI_SHARE_SLOTS) * c->nRefs + c->shareOffset;
   gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions};
-  if (++h.epoch == 0) { HIPCHK(c, hipMemsetAsync(h.flags, 0, sizeof(unsigned) * 8 * (nTiles + 2), fin)); h.epoch = 1; }
+  if (++h.epoch == 0) { HIPCHK(c, hipMemsetAsync(h.flags, 0, sizeof(unsigned) * 8 * (nTiles + 2), run)); h.epoch = 1; h.draws = 0; }
   HIPCHK(c, gtx::launch_finalize(h.histA, h.histB, c->histLen, h.partA, h.partB, sumsValid, h.prefA, h.prefB, c->d_posE, c->d_posS, c->d_classBase,
-                                 c->nRefs, dst, infoNext, fin, &fs, h.flags, h.epoch));
+                                 c->nRefs, dst, infoNext, run, &fs, h.flags, h.epoch, info, &h.draws));
+  if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], run)); c->profCalls++; }
   c->lastShareInfo = info;
   *d_piece = dst; *pieceLen = c->nShareRegions;
   return GTX_OK;
@@ -1914,7 +1931,7 @@ int gtxi_last_share_info(gtx_ctx *c, gtx_count_info *info)
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpy(&c->h_info[0], c->lastShareInfo, sizeof(gtx::DevInfo), hipMemcpyDeviceToHost));
   info_out(c->h_info[0], info, 0);
-  return GTX_OK;
+  return fault_check(c, c->h_info[0]);
 }
 
 void *gtxi_out_buffer(gtx_ctx *c) { return c->d_out; }

@@ -98,6 +98,8 @@ __global__ __launch_bounds__(256) void unpermute_kernel(const unsigned long long
 
 }  // namespace
 
+static constexpr int kSlots = GTXI_SHARE_SLOTS;
+
 struct gtx_group {
   int nm = 0;                              // members of the group (all processes together)
   int rank = -1;                           // >= 0: one process per member, this process holds member `rank` only
@@ -121,7 +123,12 @@ struct gtx_group {
   hipEvent_t evPiece = nullptr;            // rehearsal (scans): a member's piece is ready
   // gtx_group_count_device: the pieces travel on a stream of their own per local member, behind an event of the member's
   // finalize step, into one of two compact vectors in turn -- call k+1's kernels run under call k's exchange
-  std::vector<hipStream_t> xs; std::vector<hipEvent_t> evFinal[2], evXchg[2]; bool xchgUsed[2] = {false, false}; long long seq = 0;
+  std::vector<hipStream_t> xs; std::vector<hipEvent_t> evFinal[kSlots], evXchg[kSlots]; bool xchgUsed[kSlots] = {}; long long seq = 0;
+  // ... and the streaming kernels of successive calls (reads in stream order) alternate between two streams of the group's own per
+  // local member: nothing orders the kernel of call k+1 behind the kernel of call k (they count into different histogram sets), so
+  // its waves take the slots the tail of call k frees -- a member's launch at 1/8 of the reads is short enough for start and tail to
+  // be a third of it.  evReady: the caller's stream at the moment of the call (the reads are resident behind it).
+  std::vector<hipStream_t> ks[GTXI_SHARE_STREAMS]; int nks = 3; std::vector<hipEvent_t> evReady[kSlots];
   // scratch of the router for interleaved input
   std::vector<std::vector<int32_t>> partTri, partW;
 
@@ -207,8 +214,13 @@ void gtx_group_destroy(gtx_group *g)
   for (ncclComm_t c : g->comm) if (c) g->rccl.CommDestroy(c);
   for (size_t li = 0; li < g->xs.size(); li++) {
     (void)hipSetDevice(g->dev[li]);
+    for (int k = 0; k < GTXI_SHARE_STREAMS; k++) if (li < g->ks[k].size() && g->ks[k][li]) { (void)hipStreamSynchronize(g->ks[k][li]); (void)hipStreamDestroy(g->ks[k][li]); }
     if (g->xs[li]) { (void)hipStreamSynchronize(g->xs[li]); (void)hipStreamDestroy(g->xs[li]); }
-    for (int k = 0; k < 2; k++) { if (li < g->evFinal[k].size() && g->evFinal[k][li]) (void)hipEventDestroy(g->evFinal[k][li]); if (li < g->evXchg[k].size() && g->evXchg[k][li]) (void)hipEventDestroy(g->evXchg[k][li]); }
+    for (int k = 0; k < kSlots; k++) {
+      if (li < g->evFinal[k].size() && g->evFinal[k][li]) (void)hipEventDestroy(g->evFinal[k][li]);
+      if (li < g->evXchg[k].size() && g->evXchg[k][li]) (void)hipEventDestroy(g->evXchg[k][li]);
+      if (li < g->evReady[k].size() && g->evReady[k][li]) (void)hipEventDestroy(g->evReady[k][li]);
+    }
   }
   if (!g->ctx.empty()) {
     (void)hipSetDevice(g->dev[0]);
@@ -274,6 +286,7 @@ int gtx_group_assign(gtx_group *g, const int64_t *class_load, int32_t n_classes,
 int gtx_group_set_refs(gtx_group *g, const int32_t *tri, int64_t m, int32_t n_classes, uint32_t flags)
 {
   if (!g) return GTX_E_ARG;
+  { int rcs = gtx_group_sync(g); if (rcs) return rcs; }        // (device calls in flight on the group's own streams read what is about to be replaced)
   const int n = (int)g->ctx.size();
   std::vector<int> rc(n, GTX_OK);
   std::vector<std::thread> th;                               // the host-side sorts of the members run side by side
@@ -304,6 +317,7 @@ int gtx_group_set_refs(gtx_group *g, const int32_t *tri, int64_t m, int32_t n_cl
 static int ensure_plan(gtx_group *g)
 {
   if (g->planValid) return GTX_OK;
+  { int rcs = gtx_group_sync(g); if (rcs) return rcs; }        // (a finalize step in flight on an exchange stream reads the share lists about to be replaced)
   const int64_t m = g->nRefs;
   g->segOff.assign(g->nm + 1, 0); g->perm.assign((size_t)std::max<int64_t>(m, 1), 0);
   int rc = gtx_group_plan(g->refClass.data(), 1, m, g->owner.data(), (int32_t)g->owner.size(), g->nm, g->segOff.data(), g->perm.data());
@@ -380,6 +394,8 @@ static int unpermute(gtx_group *g, const unsigned long long *root, void *d_hits,
   return GTX_OK;
 }
 
+static bool pipeOffNow() { static const bool off = getenv("GTX_GROUP_PIPELINE") && atoi(getenv("GTX_GROUP_PIPELINE")) == 0; return off; }
+
 extern "C" {
 
 int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void *const *d_weights, const int64_t *n_reads, uint32_t flags, void *d_hits)
@@ -391,7 +407,9 @@ int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void 
   const size_t nl = g->ctx.size();
   if (g->xs.empty()) {
     g->xs.assign(nl, nullptr);
-    for (int k = 0; k < 2; k++) { g->evFinal[k].assign(nl, nullptr); g->evXchg[k].assign(nl, nullptr); }
+    for (int k = 0; k < kSlots; k++) { g->evFinal[k].assign(nl, nullptr); g->evXchg[k].assign(nl, nullptr); g->evReady[k].assign(nl, nullptr); }
+    for (int k = 0; k < GTXI_SHARE_STREAMS; k++) g->ks[k].assign(nl, nullptr);
+    if (const char *ns = getenv("GTX_GROUP_STREAMS")) g->nks = std::min(GTXI_SHARE_STREAMS, std::max(1, atoi(ns)));
     for (size_t li = 0; li < nl; li++) {
       GCHK_HIP(g, hipSetDevice(g->dev[li]));
       // A process that holds ONE member (a rank of a multi-process group: bench.py, a caller per GPU) makes the exchange stream with the
@@ -405,25 +423,50 @@ int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void 
       static const int prEnv = getenv("GTX_GROUP_XS_PRIORITY") ? atoi(getenv("GTX_GROUP_XS_PRIORITY")) : -1;    // 0 / 1 override
       const bool high = prEnv >= 0 ? prEnv != 0 : nl == 1;
       GCHK_HIP(g, hipStreamCreateWithPriority(&g->xs[li], hipStreamNonBlocking, high ? prHigh : 0));
-      for (int k = 0; k < 2; k++) { GCHK_HIP(g, hipEventCreateWithFlags(&g->evFinal[k][li], hipEventDisableTiming)); GCHK_HIP(g, hipEventCreateWithFlags(&g->evXchg[k][li], hipEventDisableTiming)); }
+      for (int k = 0; k < kSlots; k++) {
+        GCHK_HIP(g, hipEventCreateWithFlags(&g->evFinal[k][li], hipEventDisableTiming)); GCHK_HIP(g, hipEventCreateWithFlags(&g->evXchg[k][li], hipEventDisableTiming));
+        GCHK_HIP(g, hipEventCreateWithFlags(&g->evReady[k][li], hipEventDisableTiming));
+      }
+      for (int k = 0; k < g->nks; k++) GCHK_HIP(g, hipStreamCreateWithFlags(&g->ks[k][li], hipStreamNonBlocking));
     }
   }
-  const int slot = (int)(g->seq++ & 1);
+  const long long call = g->seq++;
+  const int slot = (int)(call % kSlots);
   std::vector<void *> piece(nl, nullptr);
+  std::vector<char> exchanges(nl, 1);
+  std::vector<hipStream_t> ran(nl, nullptr);                    // where each member's finalize step was enqueued
   for (size_t li = 0; li < nl; li++) {
     int64_t len = 0;
     g->memberReads[g->member((int)li)] = n_reads[li];
     GCHK_HIP(g, hipSetDevice(g->dev[li]));
-    // compact vector `slot` is free again when the exchange of the call before last is over (a device-side wait)
-    if (g->xchgUsed[slot]) GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[slot][li], 0));
-    // reads in stream order: the member's finalize step goes to its exchange stream, under the streaming kernel of the next call
-    // (GTX_GROUP_ASYNC_FINALIZE=0, or a batch in no order: on the member's own stream, in front of it)
+    // Reads in stream order: kernel and finalize step go to one of the group's two streams of this member in turn, histogram set with
+    // the stream (GTX_GROUP_PIPELINE=0: always the first stream -- every call behind the one before, for A/B runs).  The stream
+    // waits for the caller's stream as it stands now (the reads are resident behind it) and for the exchange that last read compact
+    // vector `slot` (call k - 3) -- device-side waits, both long over when the stream gets there in a run of calls; the caller's
+    // stream is not held up, and nothing orders the kernel of this call behind the kernel of the call before: its waves take the
+    // slots that one's tail frees.
+    // A batch in no order (or GTX_GROUP_ASYNC_FINALIZE=0): everything on the member's own stream.
     static const bool asyncOff = getenv("GTX_GROUP_ASYNC_FINALIZE") && atoi(getenv("GTX_GROUP_ASYNC_FINALIZE")) == 0;
+    const bool pipeOff = pipeOffNow();
     if (!asyncOff && (flags & GTX_READS_SORTED) && !(flags & GTX_ZERO_LENGTH_OK)) {
-      GCHK_CTX(g, li, gtxi_count_device_share_async(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, slot,
-                                                     g->xs[li], g->evFinal[slot][li], &piece[li], &len));
+      const int q = pipeOff ? 0 : (int)(call % g->nks);
+      hipStream_t run = g->ks[q][li];
+      // (a wait that is already over is not enqueued: hipStreamWaitEvent costs the host 8 us, a query 0.1 -- scripts/api_cost.hip --
+      // and a member's whole call is to fit 30)
+      if (hipStreamQuery(gtxi_stream(g->ctx[li])) != hipSuccess) {
+        GCHK_HIP(g, hipEventRecord(g->evReady[slot][li], gtxi_stream(g->ctx[li])));
+        GCHK_HIP(g, hipStreamWaitEvent(run, g->evReady[slot][li], 0));
+      }
+      if (g->xchgUsed[slot] && hipEventQuery(g->evXchg[slot][li]) != hipSuccess) GCHK_HIP(g, hipStreamWaitEvent(run, g->evXchg[slot][li], 0));
+      GCHK_CTX(g, li, gtxi_count_device_share_async(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, slot, q,
+                                                     run, &piece[li], &len));
+      // a member with nothing to exchange (a rank other than member 0 without a communicator: the measurement mode
+      // GTX_GROUP_NO_EXCHANGE) keeps its exchange stream out of it: the call's last event is the finalize step's, on `run`
+      exchanges[li] = !(g->rank > 0 && g->comm.empty()); ran[li] = run;
+      if (exchanges[li]) { GCHK_HIP(g, hipEventRecord(g->evFinal[slot][li], run)); GCHK_HIP(g, hipStreamWaitEvent(g->xs[li], g->evFinal[slot][li], 0)); }
       g->lastAsync = true;
     } else {
+      if (g->xchgUsed[slot]) GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[slot][li], 0));
       GCHK_CTX(g, li, gtxi_count_device_share(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, slot, &piece[li], &len));
       GCHK_HIP(g, hipEventRecord(g->evFinal[slot][li], gtxi_stream(g->ctx[li])));
       GCHK_HIP(g, hipStreamWaitEvent(g->xs[li], g->evFinal[slot][li], 0));
@@ -436,7 +479,10 @@ int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void 
     for (size_t li = 0; li < nl; li++) GCHK_HIP(g, hipStreamWaitEvent(g->xs[l0], g->evFinal[slot][li], 0));
   rc = gather_pieces(g, piece, root, g->xs); if (rc) return rc;
   rc = unpermute(g, root, d_hits, l0 >= 0 ? g->xs[l0] : nullptr); if (rc) return rc;
-  for (size_t li = 0; li < nl; li++) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipEventRecord(g->evXchg[slot][li], g->xs[li])); }
+  for (size_t li = 0; li < nl; li++) {
+    GCHK_HIP(g, hipSetDevice(g->dev[li]));
+    GCHK_HIP(g, hipEventRecord(g->evXchg[slot][li], exchanges[li] ? g->xs[li] : ran[li]));
+  }
   g->xchgUsed[slot] = true;
   return GTX_OK;
 }
@@ -445,7 +491,7 @@ int gtx_group_wait_result(gtx_group *g)
 {
   if (!g) return GTX_E_ARG;
   if (g->seq == 0) return GTX_OK;
-  const int slot = (int)((g->seq - 1) & 1);
+  const int slot = (int)((g->seq - 1) % kSlots);
   for (size_t li = 0; li < g->ctx.size(); li++) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[slot][li], 0)); }
   return GTX_OK;
 }
@@ -455,7 +501,11 @@ int gtx_group_sync(gtx_group *g)
   if (!g) return GTX_E_ARG;
   for (size_t li = 0; li < g->ctx.size(); li++) {
     GCHK_CTX(g, li, gtx_sync(g->ctx[li]));
-    if (li < g->xs.size() && g->xs[li]) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamSynchronize(g->xs[li])); }
+    if (li < g->xs.size() && g->xs[li]) {
+      GCHK_HIP(g, hipSetDevice(g->dev[li]));
+      for (int k = 0; k < g->nks; k++) GCHK_HIP(g, hipStreamSynchronize(g->ks[k][li]));
+      GCHK_HIP(g, hipStreamSynchronize(g->xs[li]));
+    }
   }
   return GTX_OK;
 }
@@ -609,7 +659,7 @@ static int reduce_to_root(gtx_group *g, std::vector<void *> &d, int64_t count)
 // earlier gtx_group_count_device that is still on its way (device-side waits)
 static int wait_exchanges(gtx_group *g)
 {
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < kSlots; k++) {
     if (!g->xchgUsed[k]) continue;
     for (size_t li = 0; li < g->ctx.size(); li++) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[k][li], 0)); }
   }

@@ -3,6 +3,12 @@
 #include <hip/hip_runtime.h>
 #include "gtx.h"
 
+// device calls of a group whose exchange may be on its way at once: compact vectors and events are dealt in turn (call k takes slot
+// k % GTXI_SHARE_SLOTS); call k + GTXI_SHARE_SLOTS waits for the exchange of call k
+#define GTXI_SHARE_SLOTS 4
+// the streams of a group's own that the device calls of one member take in turn, each with a histogram set of its own
+#define GTXI_SHARE_STREAMS 4
+
 extern "C" {
 int gtxi_count_finish(gtx_ctx *c, void **d_out, int share);   // close the open count stream: result in the context's HBM vector (enqueued);
                                                                // share: only the member's classes, *d_out = its piece of the compact vector
@@ -12,8 +18,8 @@ int gtxi_scan_enqueue(gtx_ctx *c, const int32_t *reads, const int32_t *weights, 
                       int32_t step, int32_t size, char prep, uint32_t flags, const int64_t *class_offsets, void **d_out, int64_t *extent);
 int gtxi_set_share(gtx_ctx *c, const uint8_t *owned, int32_t nClasses, const int32_t *regions, int64_t nRegions, int64_t offset);
 int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, void **d_piece, int64_t *pieceLen);
-int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, hipStream_t fin,
-                                  hipEvent_t evCounted, void **d_piece, int64_t *pieceLen);   // finalize on `fin`, under the next call's streaming kernel
+int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, int set, hipStream_t run,
+                                  void **d_piece, int64_t *pieceLen);   // kernel + finalize on `run` with histogram set `set` (0 | 1), into the piece of compact vector `slot`
 int gtxi_last_share_info(gtx_ctx *c, gtx_count_info *info);
 void *gtxi_out_buffer(gtx_ctx *c);                      // the context's result vector in HBM (n_refs uint64)
 int gtxi_ensure_out(gtx_ctx *c, int64_t n);             // ... with room for n uint64

@@ -30,6 +30,7 @@ struct DevInfo {
   long long n_degenerate;
   long long first_degenerate;
   long long n_unplaced;          // inverted reads that did not fit the side buffer (counts incomplete: the caller must fail)
+  long long fault;               // a kernel gave up a bounded wait (finalize_scan_chained_kernel): the call's result is void
 };
 
 // Direct placement of a wave's two windows at the start of its span: the positions of a class are cut into cells of
@@ -202,9 +203,11 @@ hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB,
                            unsigned long long *prefA, unsigned long long *prefB,
                            const int *posE, const int *posS, const int *classBase, long long m,
                            unsigned long long *hits, DevInfo *nextInfo, hipStream_t st, const FinalizeShare *share = nullptr,
-                           unsigned *chainFlags = nullptr, unsigned epoch = 0);
-// chainFlags (may be null): 8 x (tiles + 2) words (two 64-bit words per tile and histogram), zero when made, never written by the caller; epoch: a value no earlier call on these
-// flags used (and not 0).  With them a call whose tile sums are not valid takes one launch for tile sums + scan (finalize_scan_chained_kernel).
+                           unsigned *chainFlags = nullptr, unsigned epoch = 0, DevInfo *info = nullptr, unsigned long long *chainDraws = nullptr);
+// chainFlags (may be null): 8 x (tiles + 2) words (two 64-bit words per tile and histogram; the word behind each histogram's is the kernel's ticket counter), zero when
+// made, never written by the caller; epoch: a value no earlier call on these flags used (and not 0); info: the call's block (DevInfo::fault); chainDraws: the host's count of
+// the tickets drawn from these flags so far (0 when they are made; the launcher advances it).  With them a call whose tile sums are not valid and whose tiles are few
+// enough takes one launch for tile sums + scan (finalize_scan_chained_kernel).
 hipError_t launch_coverage(const void *reads, const void *weights, long long n, const CoverArgs &a, hipStream_t st);
 hipError_t launch_coverage_finalize(const CoverArgs &a, long long histLen, const CoverGather &g, long long m,
                                     unsigned long long *cov, DevInfo *nextInfo, hipStream_t st);

@@ -1534,21 +1534,33 @@ __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha
 }
 
 // Tile sums and prefix scan in ONE launch (the streaming kernel of a large call leaves the tile sums to the finalize step): a tile's
-// block publishes its sum -- value, then a flag carrying the call's epoch, released at device scope -- and then adds up the sums of the
-// tiles below it as they turn up.  A block only ever waits for blocks with a lower index of the same histogram, which the
-// dispatcher starts no later than itself: the lowest unfinished block never waits for one that is not running.  ts / fl are indexed
-// by the block's position (tile number, or place in a member's tile list: the tiles outside the list hold no counts).
+// block publishes its sum and then adds up the sums of the tiles below it as they turn up.  A block's place in the chain is a TICKET
+// drawn when it starts (one counter per histogram, never reset: `base` is what the calls before have drawn from it, kept by the host;
+// position = the tile number, or the place in a member's tile list: the tiles outside the list hold no counts), so a block only ever
+// waits for blocks that started before it -- resident or done, whatever order the dispatcher starts workgroups in and whatever else
+// runs on the device (a second chained scan on another stream, a streaming kernel that fills the chip): the lowest unfinished
+// ticket never waits, so every wait ends.  Same-address returning atomics serialise at ~12 ns (scripts/membench.hip), which is why the
+// launcher takes this kernel for at most kChainMaxTiles tiles.  The wait is bounded all the same: a block that has polled
+// kChainSpinMax times gives up, raises DevInfo::fault (the call's result is then refused by gtx_last_info) and finishes with what it has.
+static constexpr unsigned kChainSpinMax = 1u << 22;           // polls of one word (~1 us each under load): seconds
+static constexpr int kChainMaxTiles = 512;
 __global__ __launch_bounds__(256) void finalize_scan_chained_kernel(u64 *__restrict__ ha, u64 *__restrict__ hb, i64 len,
-                                                                    u64 *fa, u64 *fb, unsigned epoch,
-                                                                    u64 *__restrict__ pa, u64 *__restrict__ pb, const int *__restrict__ tileList)
+                                                                    u64 *fa, u64 *fb, u64 *ctlA, u64 *ctlB, u64 base, unsigned epoch, int nRun,
+                                                                    u64 *__restrict__ pa, u64 *__restrict__ pb, const int *__restrict__ tileList,
+                                                                    DevInfo *info)
 {
   __shared__ u64 lds[4];
   __shared__ u64 wsum[4];
-  u64 *__restrict__ h = blockIdx.y ? hb : ha;
-  u64 *fl = blockIdx.y ? fb : fa;
-  u64 *__restrict__ p = blockIdx.y ? pb : pa;
+  __shared__ u64 tk;
+  const bool second = blockIdx.y != 0;
+  if (threadIdx.x == 0) tk = atomicAdd(second ? ctlB : ctlA, 1ull) - base;
+  __syncthreads();
+  if (tk >= (u64)nRun) { if (threadIdx.x == 0) atomicAdd((u64 *)&info->fault, 1ull); return; }   // (the host's count of draws is off: touch nothing)
+  u64 *__restrict__ h = second ? hb : ha;
+  u64 *fl = second ? fb : fa;
+  u64 *__restrict__ p = second ? pb : pa;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int pos = (int)blockIdx.x, tile = tileList ? tileList[pos] : pos;
+  const int pos = (int)tk, tile = tileList ? tileList[pos] : pos;
   const i64 i0 = (i64)tile * kTile + (i64)threadIdx.x * 4;
   const bool full = i0 + 4 <= len;
   u64 v[4];
@@ -1569,12 +1581,15 @@ __global__ __launch_bounds__(256) void finalize_scan_chained_kernel(u64 *__restr
     __hip_atomic_store(fl + 2 * pos + threadIdx.x, ((u64)epoch << 32) | (threadIdx.x ? s >> 32 : s & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   u64 o = 0;
+  bool gaveUp = false;
   for (int t = threadIdx.x; t < pos; t += 256) {
-    u64 lo, hi;
-    while (((lo = __hip_atomic_load(fl + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
-    while (((hi = __hip_atomic_load(fl + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
+    u64 lo, hi; unsigned spins = 0;
+    while (((lo = __hip_atomic_load(fl + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch && ++spins < kChainSpinMax) __builtin_amdgcn_s_sleep(1);
+    while (((hi = __hip_atomic_load(fl + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch && ++spins < kChainSpinMax) __builtin_amdgcn_s_sleep(1);
+    if (spins >= kChainSpinMax) { gaveUp = true; break; }
     o += (lo & 0xffffffffull) | (hi << 32);
   }
+  if (gaveUp) atomicAdd((u64 *)&info->fault, 1ull);
   o = block_sum(o, lds);
   o += x - v[3];
   for (int k = 0; k < wv; k++) o += wsum[k];
@@ -1599,7 +1614,7 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict_
   // regionList (may be null): m entries, hits[j] = the count of region regionList[j] -- a group member's own regions, compact
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < nTiles) { ta[k] = 0; tb[k] = 0; }         // the tile sums have been consumed: clean for the next call
-  if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; nextInfo->n_unplaced = 0; }
+  if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; nextInfo->n_unplaced = 0; nextInfo->fault = 0; }
   if (k >= m) return;
   const i64 outIdx = k;
   if (regionList) k = regionList[k];
@@ -1620,7 +1635,7 @@ __global__ __launch_bounds__(256) void gather_coverage_kernel(CoverGather g, i64
 #pragma unroll
     for (int q = 0; q < 4; q++) g.part[q][k] = 0;
   }
-  if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; nextInfo->n_unplaced = 0; }
+  if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; nextInfo->n_unplaced = 0; nextInfo->fault = 0; }
   if (k >= m) return;
   const int pe = g.posTE[k];
   u64 c = 0;
@@ -1949,15 +1964,18 @@ hipError_t launch_tile_sums(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64
 
 hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, bool tileSumsValid, u64 *prefA, u64 *prefB,
                            const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, DevInfo *nextInfo, hipStream_t st,
-                           const FinalizeShare *share, unsigned *chainFlags, unsigned epoch)
+                           const FinalizeShare *share, unsigned *chainFlags, unsigned epoch, DevInfo *info, unsigned long long *chainDraws)
 {
   const int nb = scan_tiles(histLen);
   const int nbRun = share ? share->nTiles : nb;                // a group member: the tiles of its classes, its regions (compact)
   const int *tl = share ? share->tileList : nullptr;
   static const bool chained = !(getenv("GTX_CHAINED_SCAN") && atoi(getenv("GTX_CHAINED_SCAN")) == 0);
   if (nbRun > 0) {
-    if (!tileSumsValid && chainFlags && chained)
-      finalize_scan_chained_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, (u64 *)chainFlags, (u64 *)chainFlags + 2 * (nb + 2), epoch, prefA, prefB, tl);
+    if (!tileSumsValid && chainFlags && chained && info && chainDraws && nbRun <= kChainMaxTiles) {
+      finalize_scan_chained_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, (u64 *)chainFlags, (u64 *)chainFlags + 2 * (nb + 2), (u64 *)chainFlags + 2 * nb,
+                                                                   (u64 *)chainFlags + 2 * (nb + 2) + 2 * nb, *chainDraws, epoch, nbRun, prefA, prefB, tl, info);
+      *chainDraws += (unsigned long long)nbRun;
+    }
     else {
       if (!tileSumsValid) tile_sums_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, tl);
       finalize_scan_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB, tl);

@@ -47,7 +47,8 @@ for member in sorted({big, 0}):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(50):
         g.count_device([reads.data_ptr()], [reads.shape[0]], hits[i & 1].data_ptr())
+    th = (time.perf_counter() - t0) / 50                         # what the host spends enqueueing one call
     g.sync(); dt = (time.perf_counter() - t0) / 50
-    print("member %d of %d: %d reads (largest share: member %d), kernel %.4f ms, kernel+finalize %.4f ms (medians of 20, events), %.4f ms per call back to back"
-          % (member, world, reads.shape[0], big, k[10][0], k[10][1], dt * 1e3), flush=True)
+    print("member %d of %d: %d reads (largest share: member %d), kernel %.4f ms, kernel+finalize %.4f ms (medians of 20, events), %.4f ms per call back to back (host enqueue %.4f ms per call)"
+          % (member, world, reads.shape[0], big, k[10][0], k[10][1], dt * 1e3, th * 1e3), flush=True)
     g.close()
