@@ -701,9 +701,9 @@ static int count_begin(gtx_ctx *c)
 }
 
 // share: the context is a group member -- finalize its classes only, d_hits receives its regions in the group's compact order
-static int count_end(gtx_ctx *c, void *d_hits, bool share = false)
+static int count_end(gtx_ctx *c, void *d_hits, bool share = false, bool scatter = false)
 {
-  gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions};
+  gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions, scatter};
   if (++c->chainEpoch == 0) {                       // (after 2^32 calls: the flags start over)
     HIPCHK(c, hipMemsetAsync(c->d_chainFlags, 0, sizeof(unsigned) * 8 * (gtx::scan_tiles(c->histLen) + 2), c->stream));
     c->chainEpoch = 1; c->chainDraws = 0;
@@ -1844,7 +1844,7 @@ int gtxi_set_share(gtx_ctx *c, const uint8_t *owned, int32_t nClasses, const int
 // gtx_count_device for a group member: the reads (of the member's classes, resident on its device) are counted and the member's
 // regions finalized into its piece of compact vector `slot` (0 | 1), c->d_out + slot * nRefs + shareOffset.  Enqueued on the
 // context's stream.
-int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, void **d_piece, int64_t *pieceLen)
+int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, void *direct_out, void **d_piece, int64_t *pieceLen)
 {
   if (!c->shareOn) return fail(c, GTX_E_STATE, "gtxi_count_device_share: no share set");
   if (c->refBlocks) return fail(c, GTX_E_STATE, "gtx_group_count_device: multi-interval regions (gtx_set_ref_blocks) are outside the members' shares");
@@ -1861,8 +1861,8 @@ int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weigh
     else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n)); if (rc) return rc; }
   }
   if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  u64 *dst = c->d_out + (size_t)(slot % GTXI_SHARE_SLOTS) * c->nRefs + c->shareOffset;
-  rc = count_end(c, dst, true); if (rc) return rc;
+  u64 *dst = direct_out ? (u64 *)direct_out : c->d_out + (size_t)(slot % GTXI_SHARE_SLOTS) * c->nRefs + c->shareOffset;
+  rc = count_end(c, dst, true, direct_out != nullptr); if (rc) return rc;
   if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   *d_piece = dst; *pieceLen = c->nShareRegions;
   return GTX_OK;
@@ -1875,7 +1875,7 @@ int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weigh
 // member's piece of compact vector `slot`; the caller has made `run` wait for whatever last read that piece.
 static constexpr int kInfoRing = 2 * GTXI_SHARE_STREAMS;
 int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, int set, hipStream_t run,
-                                  void **d_piece, int64_t *pieceLen)
+                                  void *direct_out, void **d_piece, int64_t *pieceLen)
 {
   if (!c->shareOn) return fail(c, GTX_E_STATE, "gtxi_count_device_share_async: no share set");
   if (c->refBlocks || (flags & GTX_ZERO_LENGTH_OK) || !(flags & GTX_READS_SORTED) || n < 0 || (n > 0 && !d_reads))
@@ -1913,8 +1913,9 @@ int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d
   c->tileSumsValid = keepDefault;
   if (n > 0) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, a, true, run));
   if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], run));
-  u64 *dst = c->d_out + (size_t)(slot % GTXI_SHARE_SLOTS) * c->nRefs + c->shareOffset;
-  gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions};
+  // direct_out (may be null): the caller's result vector in file order (n_refs entries) -- the member's regions go to their places in it
+  u64 *dst = direct_out ? (u64 *)direct_out : c->d_out + (size_t)(slot % GTXI_SHARE_SLOTS) * c->nRefs + c->shareOffset;
+  gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions, direct_out != nullptr};
   if (++h.epoch == 0) { HIPCHK(c, hipMemsetAsync(h.flags, 0, sizeof(unsigned) * 8 * (nTiles + 2), run)); h.epoch = 1; h.draws = 0; }
   HIPCHK(c, gtx::launch_finalize(h.histA, h.histB, c->histLen, h.partA, h.partB, sumsValid, h.prefA, h.prefB, c->d_posE, c->d_posS, c->d_classBase,
                                  c->nRefs, dst, infoNext, run, &fs, h.flags, h.epoch, info, &h.draws));

@@ -23,6 +23,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -88,6 +89,46 @@ __global__ void rehearse_add_kernel(unsigned long long *__restrict__ root, const
   if (i < n) root[i] += other[i];
 }
 
+// The runtime maps a process's streams onto a handful of hardware queues, and two streams on one queue run their kernels one after
+// the other -- the streaming kernels of successive device calls are meant to run side by side (seen: of three streams made in a row
+// two shared a queue, 0.045 ms per call of a member instead of 0.029; scripts/queue_probe.hip).  So the group makes more streams than
+// it needs and keeps `want` of them that were SEEN to overlap pairwise: two kernels that idle for 100 us, one per stream, take 100 us
+// together or 200.  A few milliseconds, once per member.
+__global__ void queue_probe_kernel(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8); }
+
+static hipError_t make_overlapping_streams(int want, hipStream_t *out)
+{
+  constexpr int kCand = 8;
+  hipStream_t cand[kCand] = {};
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < kCand && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking);
+  bool clash[kCand][kCand] = {};
+  if (e == hipSuccess && want > 1) {
+    const long long ticks = 10000;                           // wall_clock64 runs at 100 MHz
+    queue_probe_kernel<<<1, 64, 0, cand[0]>>>(100);
+    e = hipDeviceSynchronize();
+    auto usNow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    for (int i = 0; i < kCand && e == hipSuccess; i++)
+      for (int j = i + 1; j < kCand && e == hipSuccess; j++) {
+        const double t0 = usNow();
+        queue_probe_kernel<<<1, 64, 0, cand[i]>>>(ticks); queue_probe_kernel<<<1, 64, 0, cand[j]>>>(ticks);
+        e = hipStreamSynchronize(cand[i]); if (e == hipSuccess) e = hipStreamSynchronize(cand[j]);
+        clash[i][j] = clash[j][i] = usNow() - t0 > 160.0;
+      }
+  }
+  // greedy: the first streams that clash with none already taken (then, if the probe found fewer than `want`, any that are left)
+  int taken[kCand], nt = 0; bool used[kCand] = {};
+  for (int i = 0; i < kCand && nt < want; i++) {
+    bool ok = true;
+    for (int k = 0; k < nt; k++) ok = ok && !clash[i][taken[k]];
+    if (ok) { taken[nt++] = i; used[i] = true; }
+  }
+  for (int i = 0; i < kCand && nt < want; i++) if (!used[i]) { taken[nt++] = i; used[i] = true; }
+  for (int k = 0; k < nt; k++) out[k] = cand[taken[k]];
+  for (int i = 0; i < kCand; i++) if (cand[i] && (!used[i] || e != hipSuccess)) (void)hipStreamDestroy(cand[i]);
+  return e;
+}
+
 // member 0: the compact vector (regions ordered by owner, then file position) into file order
 __global__ __launch_bounds__(256) void unpermute_kernel(const unsigned long long *__restrict__ compact, const int *__restrict__ perm, long long m,
                                                         unsigned long long *__restrict__ hits)
@@ -119,6 +160,11 @@ struct gtx_group {
   std::vector<int32_t> refClass;           // class of every reference region (file order)
   // compact layout (gtx_group_plan): piece of member m = compact positions segOff[m] .. segOff[m+1]
   bool planValid = false; std::vector<int64_t> segOff; std::vector<int32_t> perm;
+  // runs of a member's piece that are consecutive in the FILE as well (a reference file in class order: one run per class): with few
+  // of them the pieces travel run by run straight to their places in the caller's vector -- no compact vector on member 0, no reordering
+  struct Run { int64_t compact, file, len; };
+  std::vector<std::vector<Run>> runs;      // per member
+  bool direct = false;
   int *d_perm = nullptr; unsigned long long *d_selfTmp = nullptr; size_t capSelfTmp = 0;
   hipEvent_t evPiece = nullptr;            // rehearsal (scans): a member's piece is ready
   // gtx_group_count_device: the pieces travel on a stream of their own per local member, behind an event of the member's
@@ -128,7 +174,9 @@ struct gtx_group {
   // local member: nothing orders the kernel of call k+1 behind the kernel of call k (they count into different histogram sets), so
   // its waves take the slots the tail of call k frees -- a member's launch at 1/8 of the reads is short enough for start and tail to
   // be a third of it.  evReady: the caller's stream at the moment of the call (the reads are resident behind it).
-  std::vector<hipStream_t> ks[GTXI_SHARE_STREAMS]; int nks = 3; std::vector<hipEvent_t> evReady[kSlots];
+  std::vector<hipStream_t> ks[GTXI_SHARE_STREAMS]; int nks = 3; std::vector<hipEvent_t> evReady[kSlots], evJoin[GTXI_SHARE_STREAMS + 1];
+  std::vector<hipStream_t> lastRan;        // where each local member's finalize step of the last device call was enqueued
+  bool resultPending = false;
   // scratch of the router for interleaved input
   std::vector<std::vector<int32_t>> partTri, partW;
 
@@ -216,6 +264,7 @@ void gtx_group_destroy(gtx_group *g)
     (void)hipSetDevice(g->dev[li]);
     for (int k = 0; k < GTXI_SHARE_STREAMS; k++) if (li < g->ks[k].size() && g->ks[k][li]) { (void)hipStreamSynchronize(g->ks[k][li]); (void)hipStreamDestroy(g->ks[k][li]); }
     if (g->xs[li]) { (void)hipStreamSynchronize(g->xs[li]); (void)hipStreamDestroy(g->xs[li]); }
+    for (int k = 0; k <= GTXI_SHARE_STREAMS; k++) if (li < g->evJoin[k].size() && g->evJoin[k][li]) (void)hipEventDestroy(g->evJoin[k][li]);
     for (int k = 0; k < kSlots; k++) {
       if (li < g->evFinal[k].size() && g->evFinal[k][li]) (void)hipEventDestroy(g->evFinal[k][li]);
       if (li < g->evXchg[k].size() && g->evXchg[k][li]) (void)hipEventDestroy(g->evXchg[k][li]);
@@ -322,6 +371,18 @@ static int ensure_plan(gtx_group *g)
   g->segOff.assign(g->nm + 1, 0); g->perm.assign((size_t)std::max<int64_t>(m, 1), 0);
   int rc = gtx_group_plan(g->refClass.data(), 1, m, g->owner.data(), (int32_t)g->owner.size(), g->nm, g->segOff.data(), g->perm.data());
   if (rc) return gfail(g, rc, "gtx_group: planning the compact layout failed");
+  g->runs.assign(g->nm, {});
+  size_t nRuns = 0;
+  for (int mem = 0; mem < g->nm; mem++)
+    for (int64_t j = g->segOff[mem]; j < g->segOff[mem + 1];) {
+      int64_t e = j + 1;
+      while (e < g->segOff[mem + 1] && g->perm[e] == g->perm[e - 1] + 1) e++;
+      g->runs[mem].push_back({j, g->perm[j], e - j}); nRuns++;
+      j = e;
+    }
+  // (GTX_GROUP_DIRECT=0 keeps the compact vector; the test hook that sends member 0's own piece through RCCL works on it too)
+  const bool directOff = getenv("GTX_GROUP_DIRECT") && atoi(getenv("GTX_GROUP_DIRECT")) == 0;      // (read when a plan is made)
+  g->direct = !directOff && !g->selfExchange && nRuns <= 64 * (size_t)g->nm;
   std::vector<uint8_t> owned(std::max<size_t>(g->owner.size(), 1));
   for (size_t li = 0; li < g->ctx.size(); li++) {
     const int mem = g->member((int)li);
@@ -383,6 +444,44 @@ static int gather_pieces(gtx_group *g, const std::vector<void *> &piece, unsigne
   return GTX_OK;
 }
 
+// The same run by run, straight into the caller's vector on member 0 (g->direct): a run of a member's piece is consecutive in the
+// file as well, so member 0 receives it at d_hits + its file position; its own regions its finalize step has written there already.
+static int gather_runs(gtx_group *g, const std::vector<void *> &piece, unsigned long long *d_hits, const std::vector<hipStream_t> &st)
+{
+  const int l0 = g->local(0);
+  if (g->rehearse) {                                       // one device, no RCCL: copies on member 0's stream behind the members' events
+    if (l0 < 0) return GTX_OK;
+    GCHK_HIP(g, hipSetDevice(g->dev[l0]));
+    for (size_t li = 0; li < g->ctx.size(); li++) {
+      const int mem = g->member((int)li);
+      if (mem == 0) continue;
+      for (const gtx_group::Run &r : g->runs[mem])
+        GCHK_HIP(g, hipMemcpyAsync(d_hits + r.file, (const unsigned long long *)piece[li] + (r.compact - g->segOff[mem]), sizeof(uint64_t) * (size_t)r.len, hipMemcpyDeviceToDevice, st[l0]));
+    }
+    return GTX_OK;
+  }
+  if (g->comm.empty()) return GTX_OK;
+  GCHK_NCCL(g, g->rccl.GroupStart());
+  ncclResult_t r = ncclSuccess;
+  for (size_t li = 0; li < g->ctx.size() && r == ncclSuccess; li++) {
+    const int mem = g->member((int)li);
+    if (mem == 0) continue;
+    for (const gtx_group::Run &run : g->runs[mem]) {
+      if (r != ncclSuccess) break;
+      r = g->rccl.Send((const unsigned long long *)piece[li] + (run.compact - g->segOff[mem]), (size_t)run.len, ncclUint64, 0, g->comm[li], st[li]);
+    }
+  }
+  if (l0 >= 0)
+    for (int mem = 1; mem < g->nm && r == ncclSuccess; mem++)
+      for (const gtx_group::Run &run : g->runs[mem]) {
+        if (r != ncclSuccess) break;
+        r = g->rccl.Recv(d_hits + run.file, (size_t)run.len, ncclUint64, mem, g->comm[l0], st[l0]);
+      }
+  if (r != ncclSuccess) { g->rccl.GroupEnd(); g->err = std::string("ncclSend/ncclRecv: ") + g->rccl.GetErrorString(r); return GTX_E_HIP; }
+  GCHK_NCCL(g, g->rccl.GroupEnd());
+  return GTX_OK;
+}
+
 // member 0: compact -> file order into d_hits (enqueued on its stream)
 static int unpermute(gtx_group *g, const unsigned long long *root, void *d_hits, hipStream_t st)
 {
@@ -409,6 +508,7 @@ int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void 
     g->xs.assign(nl, nullptr);
     for (int k = 0; k < kSlots; k++) { g->evFinal[k].assign(nl, nullptr); g->evXchg[k].assign(nl, nullptr); g->evReady[k].assign(nl, nullptr); }
     for (int k = 0; k < GTXI_SHARE_STREAMS; k++) g->ks[k].assign(nl, nullptr);
+    for (int k = 0; k <= GTXI_SHARE_STREAMS; k++) g->evJoin[k].assign(nl, nullptr);
     if (const char *ns = getenv("GTX_GROUP_STREAMS")) g->nks = std::min(GTXI_SHARE_STREAMS, std::max(1, atoi(ns)));
     for (size_t li = 0; li < nl; li++) {
       GCHK_HIP(g, hipSetDevice(g->dev[li]));
@@ -427,73 +527,115 @@ int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void 
         GCHK_HIP(g, hipEventCreateWithFlags(&g->evFinal[k][li], hipEventDisableTiming)); GCHK_HIP(g, hipEventCreateWithFlags(&g->evXchg[k][li], hipEventDisableTiming));
         GCHK_HIP(g, hipEventCreateWithFlags(&g->evReady[k][li], hipEventDisableTiming));
       }
-      for (int k = 0; k < g->nks; k++) GCHK_HIP(g, hipStreamCreateWithFlags(&g->ks[k][li], hipStreamNonBlocking));
+      // a process with one member looks for streams that run side by side; several members on one device (rehearsals) take them as they come
+      static const bool probeOff = getenv("GTX_GROUP_QUEUE_PROBE") && atoi(getenv("GTX_GROUP_QUEUE_PROBE")) == 0;
+      if (nl == 1 && !probeOff && g->nks > 1) {
+        hipStream_t got[GTXI_SHARE_STREAMS] = {};
+        GCHK_HIP(g, make_overlapping_streams(g->nks, got));
+        for (int k = 0; k < g->nks; k++) g->ks[k][li] = got[k];
+      } else
+        for (int k = 0; k < g->nks; k++) GCHK_HIP(g, hipStreamCreateWithFlags(&g->ks[k][li], hipStreamNonBlocking));
+      for (int k = 0; k <= g->nks; k++) GCHK_HIP(g, hipEventCreateWithFlags(&g->evJoin[k][li], hipEventDisableTiming));
     }
   }
   const long long call = g->seq++;
   const int slot = (int)(call % kSlots);
+  const int l0 = g->local(0);
+  // g->direct: the pieces travel run by run to their places in d_hits, member 0's own regions are written there by its finalize step;
+  // otherwise pieces of compact vector `slot`, which member 0 reorders into d_hits
+  const bool direct = g->direct;
   std::vector<void *> piece(nl, nullptr);
-  std::vector<char> exchanges(nl, 1);
-  std::vector<hipStream_t> ran(nl, nullptr);                    // where each member's finalize step was enqueued
+  std::vector<char> onXs(nl, 0);                                // the member's part of the exchange goes through its exchange stream
+  g->lastRan.assign(nl, nullptr);
   for (size_t li = 0; li < nl; li++) {
     int64_t len = 0;
-    g->memberReads[g->member((int)li)] = n_reads[li];
+    const int mem = g->member((int)li);
+    g->memberReads[mem] = n_reads[li];
     GCHK_HIP(g, hipSetDevice(g->dev[li]));
-    // Reads in stream order: kernel and finalize step go to one of the group's two streams of this member in turn, histogram set with
+    void *directOut = direct && mem == 0 ? d_hits : nullptr;
+    // what of this member's call goes through its exchange stream: its piece on the way to member 0 (a communicator, or the copies of a
+    // rehearsal), and on member 0 the reordering of the compact vector.  Otherwise (member 0 in direct mode; a rank without a
+    // communicator: the measurement mode GTX_GROUP_NO_EXCHANGE) the exchange stream stays out of it.
+    const bool sends = mem != 0 && (!g->comm.empty() || g->rehearse);
+    onXs[li] = direct ? sends : (mem == 0 || sends);
+    // Reads in stream order: kernel and finalize step go to one of the group's streams of this member in turn, histogram set with
     // the stream (GTX_GROUP_PIPELINE=0: always the first stream -- every call behind the one before, for A/B runs).  The stream
-    // waits for the caller's stream as it stands now (the reads are resident behind it) and for the exchange that last read compact
-    // vector `slot` (call k - 3) -- device-side waits, both long over when the stream gets there in a run of calls; the caller's
-    // stream is not held up, and nothing orders the kernel of this call behind the kernel of the call before: its waves take the
-    // slots that one's tail frees.
+    // waits for the caller's stream as it stands now (the reads are resident behind it) and for the exchange that last read the
+    // member's piece of compact vector `slot` (call k - GTXI_SHARE_SLOTS) -- device-side waits, both long over when the stream gets
+    // there in a run of calls; the caller's stream is not held up, and nothing orders the kernel of this call behind the kernel of
+    // the call before: its waves take the slots that one's tail frees.
     // A batch in no order (or GTX_GROUP_ASYNC_FINALIZE=0): everything on the member's own stream.
     static const bool asyncOff = getenv("GTX_GROUP_ASYNC_FINALIZE") && atoi(getenv("GTX_GROUP_ASYNC_FINALIZE")) == 0;
-    const bool pipeOff = pipeOffNow();
+    hipStream_t run = gtxi_stream(g->ctx[li]);
     if (!asyncOff && (flags & GTX_READS_SORTED) && !(flags & GTX_ZERO_LENGTH_OK)) {
-      const int q = pipeOff ? 0 : (int)(call % g->nks);
-      hipStream_t run = g->ks[q][li];
-      // (a wait that is already over is not enqueued: hipStreamWaitEvent costs the host 8 us, a query 0.1 -- scripts/api_cost.hip --
-      // and a member's whole call is to fit 30)
+      const int q = pipeOffNow() ? 0 : (int)(call % g->nks);
+      run = g->ks[q][li];
+      // (a wait that is already over is not enqueued: an event pair between two streams costs the host 2.5-10 us and the command
+      // processor ~5, a query 0.1 -- scripts/api_cost.hip -- and a member's whole call is to fit 30)
       if (hipStreamQuery(gtxi_stream(g->ctx[li])) != hipSuccess) {
         GCHK_HIP(g, hipEventRecord(g->evReady[slot][li], gtxi_stream(g->ctx[li])));
         GCHK_HIP(g, hipStreamWaitEvent(run, g->evReady[slot][li], 0));
       }
       if (g->xchgUsed[slot] && hipEventQuery(g->evXchg[slot][li]) != hipSuccess) GCHK_HIP(g, hipStreamWaitEvent(run, g->evXchg[slot][li], 0));
       GCHK_CTX(g, li, gtxi_count_device_share_async(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, slot, q,
-                                                     run, &piece[li], &len));
-      // a member with nothing to exchange (a rank other than member 0 without a communicator: the measurement mode
-      // GTX_GROUP_NO_EXCHANGE) keeps its exchange stream out of it: the call's last event is the finalize step's, on `run`
-      exchanges[li] = !(g->rank > 0 && g->comm.empty()); ran[li] = run;
-      if (exchanges[li]) { GCHK_HIP(g, hipEventRecord(g->evFinal[slot][li], run)); GCHK_HIP(g, hipStreamWaitEvent(g->xs[li], g->evFinal[slot][li], 0)); }
+                                                     run, directOut, &piece[li], &len));
       g->lastAsync = true;
     } else {
-      if (g->xchgUsed[slot]) GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[slot][li], 0));
-      GCHK_CTX(g, li, gtxi_count_device_share(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, slot, &piece[li], &len));
-      GCHK_HIP(g, hipEventRecord(g->evFinal[slot][li], gtxi_stream(g->ctx[li])));
-      GCHK_HIP(g, hipStreamWaitEvent(g->xs[li], g->evFinal[slot][li], 0));
+      if (g->xchgUsed[slot]) GCHK_HIP(g, hipStreamWaitEvent(run, g->evXchg[slot][li], 0));
+      GCHK_CTX(g, li, gtxi_count_device_share(g->ctx[li], d_reads[li], d_weights ? d_weights[li] : nullptr, n_reads[li], flags & ~GTX_CHECK_SORTED, slot, directOut, &piece[li], &len));
       g->lastAsync = false;
     }
+    g->lastRan[li] = run;
+    if (onXs[li]) {
+      GCHK_HIP(g, hipEventRecord(g->evFinal[slot][li], run));
+      // (a rehearsal's copies all run on member 0's exchange stream)
+      GCHK_HIP(g, hipStreamWaitEvent(g->rehearse && l0 >= 0 ? g->xs[l0] : g->xs[li], g->evFinal[slot][li], 0));
+    }
   }
-  const int l0 = g->local(0);
-  unsigned long long *root = l0 >= 0 ? (unsigned long long *)gtxi_out_buffer(g->ctx[l0]) + (size_t)slot * (size_t)g->nRefs : nullptr;
-  if (g->rehearse && l0 >= 0)                                  // (one device: member 0's exchange stream copies behind every member's finalize)
-    for (size_t li = 0; li < nl; li++) GCHK_HIP(g, hipStreamWaitEvent(g->xs[l0], g->evFinal[slot][li], 0));
-  rc = gather_pieces(g, piece, root, g->xs); if (rc) return rc;
-  rc = unpermute(g, root, d_hits, l0 >= 0 ? g->xs[l0] : nullptr); if (rc) return rc;
+  if (direct) {
+    rc = gather_runs(g, piece, (unsigned long long *)d_hits, g->xs); if (rc) return rc;
+  } else {
+    unsigned long long *root = l0 >= 0 ? (unsigned long long *)gtxi_out_buffer(g->ctx[l0]) + (size_t)slot * (size_t)g->nRefs : nullptr;
+    rc = gather_pieces(g, piece, root, g->xs); if (rc) return rc;
+    rc = unpermute(g, root, d_hits, l0 >= 0 ? g->xs[l0] : nullptr); if (rc) return rc;
+  }
+  // the event behind which the member's piece of compact vector `slot` may be overwritten: the end of its part of the exchange, or of
+  // its finalize step when nothing of it travels
   for (size_t li = 0; li < nl; li++) {
     GCHK_HIP(g, hipSetDevice(g->dev[li]));
-    GCHK_HIP(g, hipEventRecord(g->evXchg[slot][li], exchanges[li] ? g->xs[li] : ran[li]));
+    const bool recvs = (int)li == l0 && (g->rehearse || !g->comm.empty());         // member 0's exchange stream receives (or copies)
+    if (onXs[li] || recvs) GCHK_HIP(g, hipEventRecord(g->evXchg[slot][li], g->xs[li]));
+    else if (!(direct && (int)li == l0)) GCHK_HIP(g, hipEventRecord(g->evXchg[slot][li], g->lastRan[li]));
+    else continue;                                               // (member 0 in direct mode with nothing to receive: no piece of a compact vector in use)
   }
   g->xchgUsed[slot] = true;
+  g->resultPending = true;
+  return GTX_OK;
+}
+
+// everything the group's own streams of the local members hold, joined into the members' own streams (device-side waits)
+static int join_streams(gtx_group *g)
+{
+  if (g->xs.empty()) return GTX_OK;
+  for (size_t li = 0; li < g->ctx.size(); li++) {
+    GCHK_HIP(g, hipSetDevice(g->dev[li]));
+    hipStream_t own = gtxi_stream(g->ctx[li]);
+    for (int k = 0; k <= g->nks; k++) {
+      hipStream_t s = k < g->nks ? g->ks[k][li] : g->xs[li];
+      if (hipStreamQuery(s) == hipSuccess) continue;
+      GCHK_HIP(g, hipEventRecord(g->evJoin[k][li], s));
+      GCHK_HIP(g, hipStreamWaitEvent(own, g->evJoin[k][li], 0));
+    }
+  }
+  g->resultPending = false;
   return GTX_OK;
 }
 
 int gtx_group_wait_result(gtx_group *g)
 {
   if (!g) return GTX_E_ARG;
-  if (g->seq == 0) return GTX_OK;
-  const int slot = (int)((g->seq - 1) % kSlots);
-  for (size_t li = 0; li < g->ctx.size(); li++) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[slot][li], 0)); }
-  return GTX_OK;
+  if (g->seq == 0 || !g->resultPending) return GTX_OK;
+  return join_streams(g);
 }
 
 int gtx_group_sync(gtx_group *g)
@@ -516,8 +658,8 @@ int gtx_group_last_info(gtx_group *g, gtx_count_info *info)
   gtx_count_info tot; tot.first_unsorted = -1; tot.first_degenerate = -1; tot.n_no_class = 0; tot.n_degenerate = 0; tot.n_unplaced = 0;
   for (size_t li = 0; li < g->ctx.size(); li++) {
     gtx_count_info one;
-    if (g->lastAsync) {                                          // (the member's finalize ran on its exchange stream)
-      if (li < g->xs.size() && g->xs[li]) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamSynchronize(g->xs[li])); }
+    if (g->lastAsync) {                                          // (the member's finalize step ran on one of the group's streams)
+      if (li < g->lastRan.size() && g->lastRan[li]) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamSynchronize(g->lastRan[li])); }
       GCHK_CTX(g, li, gtxi_last_share_info(g->ctx[li], &one));
     } else
     GCHK_CTX(g, li, gtx_last_info(g->ctx[li], &one));
@@ -657,14 +799,8 @@ static int reduce_to_root(gtx_group *g, std::vector<void *> &d, int64_t count)
 
 // the host-buffer calls and the scans work on the members' own streams and on compact vector 0: behind any exchange of an
 // earlier gtx_group_count_device that is still on its way (device-side waits)
-static int wait_exchanges(gtx_group *g)
-{
-  for (int k = 0; k < kSlots; k++) {
-    if (!g->xchgUsed[k]) continue;
-    for (size_t li = 0; li < g->ctx.size(); li++) { GCHK_HIP(g, hipSetDevice(g->dev[li])); GCHK_HIP(g, hipStreamWaitEvent(gtxi_stream(g->ctx[li]), g->evXchg[k][li], 0)); }
-  }
-  return GTX_OK;
-}
+static int join_streams(gtx_group *g);
+static int wait_exchanges(gtx_group *g) { return join_streams(g); }
 
 static int finish(gtx_group *g, bool coverage, uint64_t *out, gtx_count_info *info)
 {

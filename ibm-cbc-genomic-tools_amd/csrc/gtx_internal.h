@@ -17,9 +17,10 @@ void gtxi_fetch_info(gtx_ctx *c, gtx_count_info *info); // after a wait for the 
 int gtxi_scan_enqueue(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, const int32_t *class_len, int32_t n_classes,
                       int32_t step, int32_t size, char prep, uint32_t flags, const int64_t *class_offsets, void **d_out, int64_t *extent);
 int gtxi_set_share(gtx_ctx *c, const uint8_t *owned, int32_t nClasses, const int32_t *regions, int64_t nRegions, int64_t offset);
-int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, void **d_piece, int64_t *pieceLen);
+int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, void *direct_out, void **d_piece, int64_t *pieceLen);
+                                                        // direct_out (may be null): a result vector in file order that receives the member's regions at their places, instead of the compact piece
 int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d_weights, int64_t n, uint32_t flags, int slot, int set, hipStream_t run,
-                                  void **d_piece, int64_t *pieceLen);   // kernel + finalize on `run` with histogram set `set` (0 | 1), into the piece of compact vector `slot`
+                                  void *direct_out, void **d_piece, int64_t *pieceLen);   // kernel + finalize on `run` with histogram set `set` (0 | 1), into the piece of compact vector `slot`
 int gtxi_last_share_info(gtx_ctx *c, gtx_count_info *info);
 void *gtxi_out_buffer(gtx_ctx *c);                      // the context's result vector in HBM (n_refs uint64)
 int gtxi_ensure_out(gtx_ctx *c, int64_t n);             // ... with room for n uint64

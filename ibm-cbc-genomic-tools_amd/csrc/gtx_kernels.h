@@ -197,7 +197,7 @@ hipError_t launch_count(const void *reads, const void *weights, long long n, con
 // Leaves histA/histB and the tile sums zeroed for the next call.
 // share (may be null): the finalize step of a group member -- only the histogram tiles that cover the classes it owns (a class
 // has slots seg+cls-1 .. segEnd+cls; other tiles hold no counts) and only its regions, written in the group's compact order
-struct FinalizeShare { const int *tileList; int nTiles; const int *regionList; long long nRegions; };
+struct FinalizeShare { const int *tileList; int nTiles; const int *regionList; long long nRegions; bool scatter; };   // scatter: hits[region] instead of hits[place in the list]
 hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB, long long histLen,
                            unsigned long long *tileA, unsigned long long *tileB, bool tileSumsValid,
                            unsigned long long *prefA, unsigned long long *prefB,

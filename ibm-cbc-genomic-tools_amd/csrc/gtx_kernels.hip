@@ -1609,15 +1609,16 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict_
                                                           const int *__restrict__ posE, const int *__restrict__ posS,
                                                           const int *__restrict__ classBase, i64 m, u64 *__restrict__ hits,
                                                           u64 *__restrict__ ta, u64 *__restrict__ tb, int nTiles, DevInfo *nextInfo,
-                                                          const int *__restrict__ regionList)
+                                                          const int *__restrict__ regionList, int scatter)
 {
   // regionList (may be null): m entries, hits[j] = the count of region regionList[j] -- a group member's own regions, compact
+  // (scatter: hits[regionList[j]] -- the same regions at their places in the file's order, the other entries untouched)
   i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < nTiles) { ta[k] = 0; tb[k] = 0; }         // the tile sums have been consumed: clean for the next call
   if (k == 0) { nextInfo->first_unsorted = INT64_MAX; nextInfo->n_no_class = 0; nextInfo->n_degenerate = 0; nextInfo->first_degenerate = INT64_MAX; nextInfo->n_unplaced = 0; nextInfo->fault = 0; }
   if (k >= m) return;
-  const i64 outIdx = k;
-  if (regionList) k = regionList[k];
+  i64 outIdx = k;
+  if (regionList) { k = regionList[k]; if (scatter) outIdx = k; }
   int pe = posE[k];
   u64 h = 0;
   if (pe >= 0) {
@@ -1984,7 +1985,7 @@ hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 
   const i64 mm = share ? share->nRegions : m;
   const i64 work = (mm > nb ? mm : nb) > 0 ? (mm > nb ? mm : nb) : 1;
   gather_hits_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(prefA, prefB, posE, posS, classBase, mm, hits, tileA, tileB, nb, nextInfo,
-                                                                     share ? share->regionList : nullptr);
+                                                                     share ? share->regionList : nullptr, share && share->scatter ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -26,7 +26,8 @@ per = synth.apportion(total, synth.CHROM_LEN)
 owner = gtx.lpt_assign(per, world)
 share = [int(per[owner == m].sum()) for m in range(world)]
 big = int(np.argmax(share))
-for member in sorted({big, 0}):
+order = sorted({big, 0}, reverse=len(sys.argv) > 3 and sys.argv[3] == "rev")
+for member in order:
     g = gtx.Group(rank=member, world=world, device=0, unique_id=None)
     g.assign(per)
     g.set_refs(refs, synth.n_classes())

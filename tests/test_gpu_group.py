@@ -344,3 +344,52 @@ def test_rccl_leaves_stdout_alone(tmp_path):
     r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, env=env)
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout.decode().strip() == "RESULT", r.stdout.decode()
+
+
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_pieces_in_file_order_and_through_the_compact_vector(direct):
+    """A reference file in class order: a member's piece is a few runs that are consecutive in the file too, and they travel straight to
+    their places in the caller's vector (no compact vector on member 0, no reordering); GTX_GROUP_DIRECT=0 keeps the compact vector.
+    Both must give the oracle's counts -- ten calls in flight on two read sets and two vectors, the result read behind
+    gtx_group_wait_result on the member's own stream (no host synchronisation in between), then once more after a new assignment."""
+    import torch
+    os.environ["GTX_GROUP_REHEARSE"] = "1"; os.environ["GTX_GROUP_DIRECT"] = direct
+    try:
+        g = gtx.Group([0, 0, 0])
+        for m in range(3):
+            g.set_stream(m, torch.cuda.current_stream().cuda_stream)
+        refs = synth.genome_intervals(60_000, 101, 50, 2000)            # sorted by (class, start): class order
+        assert np.all(np.diff(refs[:, 0]) >= 0)
+        sets = [synth.genome_intervals(n, seed, 50, 51) for seed, n in ((102, 600_000), (103, 1_500_000))]
+        g.set_refs(refs, synth.n_classes())
+        for round_, load in enumerate((np.bincount(sets[0][:, 0], minlength=24), np.arange(24, 0, -1))):
+            owner = g.assign(load)
+            dev = []
+            for reads in sets:
+                own = owner[reads[:, 0]]
+                parts = [np.ascontiguousarray(reads[own == m]) for m in range(3)]
+                dev.append(([torch.from_numpy(p).cuda() for p in parts], [len(p) for p in parts]))
+            want = [orc.count(refs, r, algo=orc.SORTED_MERGE) for r in sets]
+            hits = [torch.full((len(refs),), -1, dtype=torch.int64, device="cuda") for _ in range(2)]
+            for k in range(10):
+                d, ns = dev[k & 1]
+                g.count_device([x.data_ptr() for x in d], ns, hits[k & 1].data_ptr(), flags=gtx.READS_SORTED)
+            g.wait_result()
+            got1 = hits[1].clone()                                      # on torch's current stream = the members' own: behind the wait
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(got1.cpu().numpy().view(np.uint64), want[1])
+            g.sync()
+            np.testing.assert_array_equal(hits[0].cpu().numpy().view(np.uint64), want[0])
+            assert g.last_info()["n_no_class"] == 0
+        # reads in no order take the members' own streams, same pieces
+        rng = np.random.default_rng(5)
+        own = owner[sets[0][:, 0]]
+        parts = [np.ascontiguousarray(sets[0][own == m][rng.permutation(int((own == m).sum()))]) for m in range(3)]
+        dv = [torch.from_numpy(p).cuda() for p in parts]
+        hits[0].fill_(-1)
+        g.count_device([x.data_ptr() for x in dv], [len(p) for p in parts], hits[0].data_ptr(), flags=0)
+        g.sync()
+        np.testing.assert_array_equal(hits[0].cpu().numpy().view(np.uint64), want[0])
+        g.close()
+    finally:
+        del os.environ["GTX_GROUP_REHEARSE"]; del os.environ["GTX_GROUP_DIRECT"]
