@@ -44,14 +44,6 @@ void GtxFinish(int code)
 {
   if (getenv("GTX_TIMING")) fprintf(stderr, "[gtx leaving at epoch ms %lld]\n", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count());
   fflush(stdout); fflush(stderr);
-  if (const char *x = getenv("GTX_EXIT_EXPERIMENT")) {             // (diagnostic: what makes the process go away in 2 ms instead of 150)
-    const int mode = atoi(x);
-    static std::vector<std::thread> th;
-    static volatile bool stop = false;
-    if (mode == 1 || mode == 2) { for (int i = 0; i < 8; i++) th.emplace_back([] { while (!stop) usleep(1000); }); usleep(3000); }
-    if (mode == 1) { stop = true; for (auto &t : th) t.join(); }
-    if (mode == 3) usleep(20000);
-  }
   const char *pre = getenv("LD_PRELOAD");
   if (getenv("GTX_FULL_EXIT") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("HSA_TOOLS_LIB") ||
       (pre && strstr(pre, "rocprof")))
@@ -893,7 +885,8 @@ unsigned long int *GenomicRegionSetOverlaps::CalcIndexCoverage(bool match_gaps, 
 unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_gaps, bool ignore_strand, long int max_label_value)
 {
   const long int M = IndexSet->n_regions;
-  const bool sorted = UsesSortedMerge(), by_strand = SortedByStrand();
+  const SortedGenomicRegionSetOverlaps *merge = dynamic_cast<const SortedGenomicRegionSetOverlaps *>(this);
+  const bool sorted = merge != NULL, by_strand = merge && merge->sorted_by_strand;
   for (long int k = 0; k < M; k++) IndexSet->R[k]->n_line = k;                       // :5309
   Mark("CountIndexOverlaps: start");
 
@@ -1087,43 +1080,60 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
 }
 
 // ---- per-query iteration (host side, like the reference's: these calls hand out GenomicRegion pointers) -------------------
+// What GetMatch/NextMatch deliver are candidates on the envelopes; the filter of genomic_intervals.cpp:5224-5248 decides which of them
+// are overlaps: under match_gaps the envelope is all that counts, otherwise some interval pair must overlap; and unless strands are
+// ignored both regions must lie on the same strand (that of their first interval).
+namespace {
+struct OverlapFilter {
+  GenomicRegion *query; bool gaps, any_strand;
+  bool operator()(GenomicRegion *cand) const
+  {
+    if (!any_strand && query->I.front()->STRAND != cand->I.front()->STRAND) return false;
+    return gaps || query->OverlapsWith(cand, any_strand);
+  }
+};
+
+// value(r) summed over the overlaps of the current query, in `unsigned long` like the reference's accumulators (:5254-5263, :5291-5296)
+template <class Value>
+unsigned long int sum_over_overlaps(GenomicRegionSetOverlaps *o, bool match_gaps, bool ignore_strand, Value value)
+{
+  unsigned long int total = 0;
+  GenomicRegion *r = o->GetOverlap(match_gaps, ignore_strand);
+  while (r != NULL) { total += (unsigned long int)value(r); r = o->NextOverlap(match_gaps, ignore_strand); }
+  return total;
+}
+}  // namespace
+
 GenomicRegion *GenomicRegionSetOverlaps::GetOverlap(bool match_gaps, bool ignore_strand)
 {
-  for (GenomicRegion *r = GetMatch(); r != NULL; r = NextMatch())
-    if (match_gaps || current_qreg->OverlapsWith(r, ignore_strand)) {
-      if (ignore_strand) return r;
-      if (current_qreg->I.front()->STRAND == r->I.front()->STRAND) return r;
-    }
-  return NULL;
+  const OverlapFilter overlaps = {current_qreg, match_gaps, ignore_strand};
+  GenomicRegion *cand = GetMatch();
+  while (cand != NULL && !overlaps(cand)) cand = NextMatch();
+  return cand;
 }
 
 GenomicRegion *GenomicRegionSetOverlaps::NextOverlap(bool match_gaps, bool ignore_strand)
 {
-  for (GenomicRegion *r = NextMatch(); r != NULL; r = NextMatch())
-    if (match_gaps || current_qreg->OverlapsWith(r, ignore_strand)) {
-      if (ignore_strand) return r;
-      if (current_qreg->I.front()->STRAND == r->I.front()->STRAND) return r;
-    }
-  return NULL;
+  const OverlapFilter overlaps = {current_qreg, match_gaps, ignore_strand};
+  GenomicRegion *cand = NextMatch();
+  while (cand != NULL && !overlaps(cand)) cand = NextMatch();
+  return cand;
 }
 
 unsigned long int GenomicRegionSetOverlaps::CalcQueryCoverage(bool match_gaps, bool ignore_strand, long int max_label_value)
 {
-  unsigned long int c = 0;
-  for (GenomicRegion *r = GetOverlap(match_gaps, ignore_strand); r != NULL; r = NextOverlap(match_gaps, ignore_strand)) {
-    long int cc = match_gaps ? std::min(r->I.back()->STOP, current_qreg->I.back()->STOP) - std::max(r->I.front()->START, current_qreg->I.front()->START) + 1
-                             : current_qreg->CalcOverlap(r, ignore_strand);
-    cc *= r->GetLabelValue(max_label_value);
-    c += cc;
-  }
-  return c;
+  GenomicRegion *q = current_qreg;
+  return sum_over_overlaps(this, match_gaps, ignore_strand, [=](GenomicRegion *r) -> long int {
+    // envelope against envelope under match_gaps (not clamped: :5258), interval pairs otherwise; times the INDEX region's label value
+    const long int len = match_gaps ? std::min(r->I.back()->STOP, q->I.back()->STOP) - std::max(r->I.front()->START, q->I.front()->START) + 1
+                                    : q->CalcOverlap(r, ignore_strand);
+    return len * r->GetLabelValue(max_label_value);
+  });
 }
 
 unsigned long int GenomicRegionSetOverlaps::CountQueryOverlaps(bool match_gaps, bool ignore_strand, long int max_label_value)
 {
-  unsigned long int c = 0;
-  for (GenomicRegion *r = GetOverlap(match_gaps, ignore_strand); r != NULL; r = NextOverlap(match_gaps, ignore_strand)) c += r->GetLabelValue(max_label_value);
-  return c;
+  return sum_over_overlaps(this, match_gaps, ignore_strand, [=](GenomicRegion *r) -> long int { return r->GetLabelValue(max_label_value); });
 }
 
 // The bin index of UnsortedGenomicRegionSetOverlaps (genomic_intervals.cpp:5593-5675) for GetMatch/NextMatch: a region lives at the
@@ -1514,6 +1524,18 @@ UnsortedGenomicRegionSetScanner::UnsortedGenomicRegionSetScanner(GenomicRegionSe
 {
   Compute(false);
 }
+
+// the reference's scanners override the five virtuals (genomic_intervals.h:2291-2295, :2349-2353); here both run the shared body
+#define GTX_SCANNER_OVERRIDES(CLS)                                                                                  \
+  CLS::~CLS() {}                                                                                                    \
+  void CLS::PrintInterval(FILE *out_file) { GenomicRegionSetScanner::PrintInterval(out_file); }                     \
+  GenomicInterval *CLS::GetInterval() { return GenomicRegionSetScanner::GetInterval(); }                            \
+  long int CLS::Next() { return GenomicRegionSetScanner::Next(); }                                                  \
+  long int CLS::Next(GenomicRegionSet *Ref) { return GenomicRegionSetScanner::Next(Ref); }                          \
+  long int CLS::Next(GenomicRegionSetIndex *index) { return GenomicRegionSetScanner::Next(index); }
+GTX_SCANNER_OVERRIDES(SortedGenomicRegionSetScanner)
+GTX_SCANNER_OVERRIDES(UnsortedGenomicRegionSetScanner)
+#undef GTX_SCANNER_OVERRIDES
 
 // ---------------------------------------------------------------------------------------------------
 StringLIntMap *ReadBounds(char *genome_reg_file, bool verbose)

@@ -179,9 +179,10 @@ class GenomicRegionSetOverlaps
   GenomicRegion *current_ireg;
 
  protected:
+  // the two reductions on the device.  Which reference algorithm's input rules apply is read off the object's type: a
+  // SortedGenomicRegionSetOverlaps (or a class derived from it) has the merge's, anything else the bin index's -- the class adds no
+  // virtual member to the reference's five, so a subclass written against gtools/genomic_intervals.h compiles and overrides unchanged
   unsigned long int *Reduce(bool coverage, bool match_gaps, bool ignore_strand, long int max_label_value);
-  virtual bool UsesSortedMerge() const = 0;      // which reference algorithm's input rules apply
-  virtual bool SortedByStrand() const { return false; }
 };
 
 // genomic_intervals.h:2607 -- query rules of the bin-index algorithm (any order; a query with
@@ -198,8 +199,6 @@ class UnsortedGenomicRegionSetOverlaps : public GenomicRegionSetOverlaps
   GenomicRegion *GetMatch();
   GenomicRegion *NextMatch();
   bool Done();
- protected:
-  bool UsesSortedMerge() const { return false; }
  private:
   struct MatchIndex;
   MatchIndex *match;
@@ -220,9 +219,6 @@ class SortedGenomicRegionSetOverlaps : public GenomicRegionSetOverlaps
   GenomicRegion *GetMatch();
   GenomicRegion *NextMatch();
   bool Done();
- protected:
-  bool UsesSortedMerge() const { return true; }
-  bool SortedByStrand() const { return sorted_by_strand; }
   bool sorted_by_strand;
  private:
   void LoadIndexBuffer();
@@ -256,14 +252,17 @@ class GenomicRegionSetScanner
                           bool ignore_strand, char preprocess);
   virtual ~GenomicRegionSetScanner();
 
-  void PrintInterval(FILE *out_file = stdout);                    // "chr strand start stop" of the current window
-  GenomicInterval *GetInterval();                                 // heap object owned by the caller
-  long int Next();                                                // next window's value, -1 at the end
+  // the reference's five pure virtuals (genomic_intervals.h:2213-2217): a scanner written against it derives from this class and
+  // implements them.  The two scanners of this package share one implementation, which lives in the bodies of these members (a
+  // pure virtual may have one) and which their overrides call.
+  virtual void PrintInterval(FILE *out_file = stdout) = 0;        // "chr strand start stop" of the current window
+  virtual GenomicInterval *GetInterval() = 0;                     // heap object owned by the caller
+  virtual long int Next() = 0;                                    // next window's value, -1 at the end
+  virtual long int Next(GenomicRegionSet *Ref) = 0;               // ... of the next window that overlaps a region of the sorted set (:4960-4977, :5144-5163)
+  virtual long int Next(GenomicRegionSetIndex *index) = 0;        // ... of the indexed set (:4982-4991, :5168-5178)
   // MI355X path: sum of GetLabelValue(max_label_value) over every region of the input, collected by the same pass that
   // fills the windows -- what the reference gets from a separate read of the file (CountGenomicRegions, :6206-6214)
   long int TotalLabelValue();
-  long int Next(GenomicRegionSet *Ref);                           // ... of the next window that overlaps a region of the sorted set (:4960-4977, :5144-5163)
-  long int Next(GenomicRegionSetIndex *index);                    // ... of the indexed set (:4982-4991, :5168-5178)
 
   GenomicRegionSet *R;
   StringLIntMap *bounds;
@@ -288,6 +287,12 @@ class SortedGenomicRegionSetScanner : public GenomicRegionSetScanner
  public:
   SortedGenomicRegionSetScanner(GenomicRegionSet *R, StringLIntMap *bounds, long int win_step, long int win_size, long int max_label_value,
                                 bool ignore_strand, char preprocess);
+  virtual ~SortedGenomicRegionSetScanner();
+  virtual void PrintInterval(FILE *out_file = stdout);
+  virtual GenomicInterval *GetInterval();
+  virtual long int Next();
+  virtual long int Next(GenomicRegionSet *Ref);
+  virtual long int Next(GenomicRegionSetIndex *index);
 };
 
 class UnsortedGenomicRegionSetScanner : public GenomicRegionSetScanner
@@ -295,6 +300,12 @@ class UnsortedGenomicRegionSetScanner : public GenomicRegionSetScanner
  public:
   UnsortedGenomicRegionSetScanner(GenomicRegionSet *R, StringLIntMap *bounds, long int win_step, long int win_size, long int max_label_value,
                                   bool ignore_strand, char preprocess);
+  virtual ~UnsortedGenomicRegionSetScanner();
+  virtual void PrintInterval(FILE *out_file = stdout);
+  virtual GenomicInterval *GetInterval();
+  virtual long int Next();
+  virtual long int Next(GenomicRegionSet *Ref);
+  virtual long int Next(GenomicRegionSetIndex *index);
 };
 
 void GtxSetDevices(int n_gpus);                                // MI355X path: GPUs the reductions are spread over (--ngpu; not in the reference)

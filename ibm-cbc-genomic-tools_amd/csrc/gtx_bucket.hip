@@ -160,7 +160,9 @@ __global__ __launch_bounds__(1024, ((WEIGHTED && PER == 4) || LINE) ? 4 : 8) voi
       const unsigned i = tile * TB + k * 1024 + threadIdx.x;
       const Tri3 r = nx[k];
       rc[k] = r.c; rs[k] = r.s; re[k] = r.e; rw[k] = nw[k]; rank[k] = 0;
-      const bool in = i < un, ok = (unsigned)r.c < (unsigned)a.nClasses && r.s <= r.e + a.zeroLenOk;
+      bool cls = (unsigned)r.c < (unsigned)a.nClasses;
+      if (a.owned) cls = cls && a.owned[cls ? r.c : 0];             // (a group member: reads of other members' classes count as reads of no class)
+      const bool in = i < un, ok = cls && r.s <= r.e + a.zeroLenOk;
       want[k] = in && ok; other |= in && !ok;
     }
     if (__builtin_amdgcn_ballot_w64(other)) {                        // (rare: kept out of the way of the common path, which is bound by instruction issue)
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(1024, ((WEIGHTED && PER == 4) || LINE) ? 4 : 8) voi
       for (int k = 0; k < PER; k++) {
         const unsigned i = tile * TB + k * 1024 + threadIdx.x;
         if (i < un && !want[k]) {
-          if ((unsigned)rc[k] >= (unsigned)a.nClasses) nNoClass++;
+          if ((unsigned)rc[k] >= (unsigned)a.nClasses || (a.owned && !a.owned[rc[k]])) nNoClass++;
           else if (!a.coverRule || rs[k] > re[k] + 1) {
             nDegen++; if (i < firstDegen) firstDegen = i;
             if (a.side) { const unsigned q = atomicAdd(a.sideCount, 1u); if (q < (unsigned)a.sideCap) a.side[q] = make_int4(rc[k], rs[k], re[k], rw[k]); }   // see CountArgs::side

@@ -40,7 +40,7 @@ struct gtx_ctx {
   int4 *d_placeClsT = nullptr; int *d_placeRankT = nullptr; int placeShiftT = 0;      // ... over the coverage thresholds (cover_prepare)
   std::vector<int32_t> h_seg;                        // [nClasses+1] class segments of the sorted boundary arrays (host copy)
   // a group member's share of the finalize step (gtxi_set_share): tiles of its classes, its regions in the group's compact order
-  bool shareOn = false; int *d_shareTiles = nullptr; int nShareTiles = 0; int *d_shareRegions = nullptr; int64_t nShareRegions = 0, shareOffset = 0;
+  bool shareOn = false; int *d_shareTiles = nullptr; int nShareTiles = 0; int *d_shareRegions = nullptr; int64_t nShareRegions = 0, shareOffset = 0; unsigned char *d_shareOwned = nullptr;
   // unsorted reads, bucket path (gtx_bucket.hip): table built with the references, scratch sized by the largest call
   void *d_clsCell = nullptr, *d_cellTab = nullptr; int nCells = 0, cellShift = 0;   // direct-address bucket lookup (BucketTable)
   int *d_bktT = nullptr; void *d_clsCellT = nullptr, *d_cellTabT = nullptr; int nBT = 0, nCellsT = 0, cellShiftT = 0;   // the same tables over the coverage thresholds (cover_prepare)
@@ -241,7 +241,7 @@ void gtx_destroy(gtx_ctx *c)
   (void)hipSetDevice(c->device);
   dfree(c->d_sortedE); dfree(c->d_sortedS); dfree(c->d_segStart); dfree(c->d_posE); dfree(c->d_posS); dfree(c->d_classBase);
   dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab); dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;
-  dfree(c->d_placeCls); dfree(c->d_placeRank); dfree(c->d_placeClsT); dfree(c->d_placeRankT); dfree(c->d_shareTiles); dfree(c->d_shareRegions);
+  dfree(c->d_placeCls); dfree(c->d_placeRank); dfree(c->d_placeClsT); dfree(c->d_placeRankT); dfree(c->d_shareTiles); dfree(c->d_shareRegions); dfree(c->d_shareOwned);
   dfree(c->d_bktCnt); dfree(c->d_bktS); dfree(c->d_clsCellS); dfree(c->d_cellTabS); dfree(c->d_scanParts); dfree(c->d_scanInfo); c->nBS = 0;
   dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info); dfree(c->d_chainFlags); free_alt_sets(c); dfree(c->d_info3);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
@@ -496,7 +496,7 @@ int gtx_set_refs_ex(gtx_ctx *c, const int32_t *tri, int64_t m, int32_t nClasses,
   c->pairMulti = gtx_ctx::PairIdx(); c->pairAll = gtx_ctx::PairIdx(); c->refBlocks = false; c->pairUsed = false;
   c->nRefs = m; c->nValid = nv; c->nClasses = nClasses; c->histLen = histLen;
   c->h_seg = seg;
-  c->shareOn = false; dfree(c->d_shareTiles); dfree(c->d_shareRegions); c->nShareTiles = 0; c->nShareRegions = 0; c->shareOffset = 0;
+  c->shareOn = false; dfree(c->d_shareTiles); dfree(c->d_shareRegions); dfree(c->d_shareOwned); c->nShareTiles = 0; c->nShareRegions = 0; c->shareOffset = 0;
   return GTX_OK;
 }
 
@@ -521,10 +521,11 @@ extern "C" int gtx_debug_trace_read(unsigned long long *out, long long nWaves)
 }
 #endif
 
-static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int64_t indexBase = 0, const gtx_ctx::HistSet *set = nullptr)
+static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int64_t indexBase = 0, const gtx_ctx::HistSet *set = nullptr, bool share = false)
 {
   gtx::CountArgs a;
   a.indexBase = indexBase;
+  a.owned = (share || set) && c->shareOn ? c->d_shareOwned : nullptr;
   a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart;
   a.histA = c->d_histA; a.histB = c->d_histB; a.partA = c->d_partA; a.partB = c->d_partB; a.info = c->d_info + c->infoCur;
   if (set) { a.histA = set->histA; a.histB = set->histB; a.partA = set->partA; a.partB = set->partB; }
@@ -1832,7 +1833,13 @@ int gtxi_set_share(gtx_ctx *c, const uint8_t *owned, int32_t nClasses, const int
   }
   std::vector<int32_t> tiles;
   for (int t = 0; t < nTilesAll; t++) if (mark[t]) tiles.push_back(t);
-  dfree(c->d_shareTiles); dfree(c->d_shareRegions);
+  dfree(c->d_shareTiles); dfree(c->d_shareRegions); dfree(c->d_shareOwned);
+  {
+    std::vector<uint8_t> own((size_t)std::max(c->nClasses, 1), 0);
+    for (int cl = 0; cl < c->nClasses && cl < nClasses; cl++) own[cl] = owned[cl] ? 1 : 0;
+    HIPCHK(c, hipMalloc(&c->d_shareOwned, own.size()));
+    HIPCHK(c, hipMemcpy(c->d_shareOwned, own.data(), own.size(), hipMemcpyHostToDevice));
+  }
   HIPCHK(c, hipMalloc(&c->d_shareTiles, sizeof(int32_t) * (tiles.size() + 1)));
   HIPCHK(c, hipMalloc(&c->d_shareRegions, sizeof(int32_t) * (size_t)(nRegions + 1)));
   if (!tiles.empty()) HIPCHK(c, hipMemcpy(c->d_shareTiles, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice));
@@ -1857,8 +1864,8 @@ int gtxi_count_device_share(gtx_ctx *c, const void *d_reads, const void *d_weigh
   const bool streaming = (flags & (GTX_READS_SORTED | GTX_CHECK_SORTED)) != 0;
   if (!streaming) c->tileSumsValid = false;
   if (n > 0) {
-    if (streaming) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), true, c->stream));
-    else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n)); if (rc) return rc; }
+    if (streaming) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n, 0, nullptr, true), true, c->stream));
+    else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n, 0, nullptr, true)); if (rc) return rc; }
   }
   if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   u64 *dst = direct_out ? (u64 *)direct_out : c->d_out + (size_t)(slot % GTXI_SHARE_SLOTS) * c->nRefs + c->shareOffset;

@@ -65,6 +65,8 @@ struct CountArgs {
   unsigned long long *partB;
   DevInfo *info;
   int nClasses;
+  const unsigned char *owned;    // [nClasses] (may be null): a group member's classes -- a read of any other class is counted like a read of no class
+                                 //   (n_no_class) and nowhere else: its tiles are not in the member's share of the finalize step
   int chunksPerWave;             // 64-read chunks one wave streams
   int checkSorted;               // verify (class >> sortClassShift, start) order
   int sortClassShift;

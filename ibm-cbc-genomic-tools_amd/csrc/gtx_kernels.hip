@@ -318,6 +318,9 @@ struct Win {
 
 struct __attribute__((packed, aligned(4))) Tri { int c, s, e; };
 
+// a class the call counts: known, and -- for a group member -- one of its own (CountArgs::owned)
+__device__ __forceinline__ bool class_counts(const CountArgs &a, int c) { return (unsigned)c < (unsigned)a.nClasses && (!a.owned || a.owned[c]); }
+
 // sets the reads of the lanes in `m` aside for the pair kernels (see CountArgs::side); any control flow
 template <class ARGS>
 __device__ __forceinline__ void side_append(const ARGS &a, int c, int s, int e, int w, bool mine)
@@ -369,7 +372,7 @@ __device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountA
   }
 
   const u64 degen = __ballot(t.s > t.e + a.zeroLenOk) & active;
-  const u64 noclass = __ballot((unsigned)t.c >= (unsigned)a.nClasses) & active;
+  const u64 noclass = __ballot(!class_counts(a, t.c)) & active;
   if (degen | noclass) {
     st.nNoClass += __popcll(noclass);
     u64 dg = degen & ~noclass;
@@ -808,7 +811,7 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
     // under load, a quarter of a wave's life).  Nothing here is trusted: the step's real keys decide below.
     int preA = 0, preB = 0, preCls = -1; Seg preSeg; preSeg.start = 0; preSeg.end = 0; preSeg.cls = -1;
     {
-      if ((unsigned)fc < (unsigned)a.nClasses) {
+      if (class_counts(a, fc)) {
         const int4 pc = a.place.cls[fc];
         preSeg.start = rfl(pc.x); preSeg.end = rfl(pc.y); preSeg.cls = fc;
         if (preSeg.start != preSeg.end) {
@@ -827,7 +830,7 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
       odd |= t[r].c ^ c0; ks[r] = t[r].s; ke[r] = t[r].e;
       dg |= __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(t[r].e, zl), t[r].s);
     }
-    if ((unsigned)c0 < (unsigned)a.nClasses && !__ballot((odd != 0) | (dg < 0))) {
+    if (class_counts(a, c0) && !__ballot((odd != 0) | (dg < 0))) {
       if (c0 == preCls) st.sg = preSeg;
       else { st.sg.start = rfl(a.segStart[c0]); st.sg.end = rfl(a.segStart[c0 + 1]); st.sg.cls = c0; }
       if (st.sg.start != st.sg.end) {
@@ -1416,8 +1419,9 @@ __global__ __launch_bounds__(1024) void count_search_kernel(const Tri *__restric
     if (i < n) {
       const Tri t = reads[i];
       if (WEIGHTED) w = (i64)weights[i];
-      const int s0 = (unsigned)t.c < (unsigned)a.nClasses ? a.segStart[t.c] : 0, s1 = (unsigned)t.c < (unsigned)a.nClasses ? a.segStart[t.c + 1] : 0;
-      if ((unsigned)t.c >= (unsigned)a.nClasses) nNoClass++;
+      const bool known = class_counts(a, t.c);
+      const int s0 = known ? a.segStart[t.c] : 0, s1 = known ? a.segStart[t.c + 1] : 0;
+      if (!known) nNoClass++;
       else if (t.s > t.e + a.zeroLenOk) { nDegen++; if (i < firstDegen) firstDegen = i; side_append(a, t.c, t.s, t.e, (int)w, true); }
       else if (s0 != s1) {
         // samples i0..i1-1 are the ones that lie inside the class segment [s0, s1)
@@ -1972,7 +1976,8 @@ hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 
   const int *tl = share ? share->tileList : nullptr;
   static const bool chained = !(getenv("GTX_CHAINED_SCAN") && atoi(getenv("GTX_CHAINED_SCAN")) == 0);
   if (nbRun > 0) {
-    if (!tileSumsValid && chainFlags && chained && info && chainDraws && nbRun <= kChainMaxTiles) {
+    static const int chainMax = getenv("GTX_CHAIN_MAX_TILES") ? atoi(getenv("GTX_CHAIN_MAX_TILES")) : kChainMaxTiles;
+    if (!tileSumsValid && chainFlags && chained && info && chainDraws && nbRun <= chainMax) {
       finalize_scan_chained_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, (u64 *)chainFlags, (u64 *)chainFlags + 2 * (nb + 2), (u64 *)chainFlags + 2 * nb,
                                                                    (u64 *)chainFlags + 2 * (nb + 2) + 2 * nb, *chainDraws, epoch, nbRun, prefA, prefB, tl, info);
       *chainDraws += (unsigned long long)nbRun;

@@ -1,4 +1,3 @@
-for rep in 1 2; do for ns in 2 3 4; do
-echo "rep $rep streams $ns: $(GTX_GROUP_STREAMS=$ns python scripts/share_timing.py 8 100000000 2>&1 | grep '^member' | sed 's/ of 8.*finalize [0-9.]* ms (medians of 20, events), / /' | tr '\n' '|')"
-echo "rep $rep streams $ns reversed: $(GTX_GROUP_STREAMS=$ns python scripts/share_timing.py 8 100000000 rev 2>&1 | grep '^member' | sed 's/ of 8.*finalize [0-9.]* ms (medians of 20, events), / /' | tr '\n' '|')"
+for rep in 1 2; do for mx in 512 4096; do
+echo "chain max $mx: $(GTX_CHAIN_MAX_TILES=$mx python bench.py --steps 40 --warmup 5 --no-e2e --cpu-sample 0 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(d["ms_per_step"], d["roofline"]["kernel_ms"])')"
 done; done

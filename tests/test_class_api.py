@@ -166,3 +166,22 @@ def test_in_memory_set_reports_the_first_bad_line(tmp_path, threads):
     want = subprocess.run([orc.CLI, "pairs", "-i", "refs.bed", "q.bed"], capture_output=True, cwd=tmp_path)
     assert got.returncode == want.returncode == 1
     assert got.stderr.decode().strip() == want.stderr.decode().strip() and "Line 41000" in got.stderr.decode()
+
+
+@pytest.mark.parametrize("opts", [["-i"], [], ["-i", "-gaps"]], ids=["-i", "strand", "-i -gaps"])
+def test_subclasses_written_against_the_reference_header(api_beds, opts):
+    """A caller's own subclasses of the two abstract bases -- implementing exactly the reference's pure virtuals
+    (gtools/genomic_intervals.h:2403-2419, :2213-2217) -- compile against csrc/genomic_intervals.h and are driven through base-class
+    pointers: GetOverlap/NextOverlap must walk the SUBCLASS's GetQuery/GetMatch/NextMatch (here: every other query of the plain walk),
+    and the scanner's members must dispatch to the caller's overrides."""
+    refs, reads = ("refs12.bed", "reads12.bed") if "-gaps" in opts else ("refs.bed", "reads.bed")
+    rc, out, err = run_caller(["subclass"] + opts + [refs, reads], api_beds)
+    assert rc == 0, err
+    lines = out.splitlines()
+    at = lines.index("virtual calls seen")
+    plain = subprocess.run([orc.CLI, "pairs"] + opts + [refs, reads], capture_output=True, cwd=api_beds).stdout.decode().splitlines()
+    n_lines = sum(1 for _ in open(os.path.join(api_beds, reads)))
+    kept = set(range(1, n_lines + 1, 2))                                        # the subclass hands out queries 1, 3, 5, ...
+    assert lines[:at] == [l for l in plain if int(l.split("\t")[0]) in kept]
+    assert len(lines[:at]) > 100
+    assert lines[at + 1:] == ["100\twindow 1", "101\twindow 2", "102\twindow 3"]

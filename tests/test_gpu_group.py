@@ -390,6 +390,27 @@ def test_pieces_in_file_order_and_through_the_compact_vector(direct):
         g.count_device([x.data_ptr() for x in dv], [len(p) for p in parts], hits[0].data_ptr(), flags=0)
         g.sync()
         np.testing.assert_array_equal(hits[0].cpu().numpy().view(np.uint64), want[0])
+        # reads handed to a member that does not own their class are counted as reads of no class and nowhere else: not into
+        # histogram tiles nobody finalizes, where they would survive into later calls (sorted and shuffled routes)
+        own = owner[sets[0][:, 0]]
+        stray = sets[0][own == 1][:5]
+        for flags in (gtx.READS_SORTED, 0):
+            parts = [np.ascontiguousarray(sets[0][own == m]) for m in range(3)]
+            parts[1] = parts[1][5:]
+            parts[2] = np.ascontiguousarray(np.concatenate([parts[2], stray]))      # member 2 gets five reads of member 1's classes (at the end: still in order per class run)
+            if flags == 0:
+                parts = [p[rng.permutation(len(p))] for p in parts]
+            dv = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in parts]
+            hits[0].fill_(-1)
+            g.count_device([x.data_ptr() for x in dv], [len(p) for p in parts], hits[0].data_ptr(), flags=flags)
+            g.sync()
+            keep = np.ones(len(sets[0]), dtype=bool); keep[np.nonzero(own == 1)[0][:5]] = False
+            np.testing.assert_array_equal(hits[0].cpu().numpy().view(np.uint64), orc.count(refs, sets[0][keep], algo=orc.BIN_INDEX))
+            assert g.last_info()["n_no_class"] == 5
+        d, ns = dev[0]
+        g.count_device([x.data_ptr() for x in d], ns, hits[0].data_ptr(), flags=gtx.READS_SORTED)
+        g.sync()
+        np.testing.assert_array_equal(hits[0].cpu().numpy().view(np.uint64), want[0])
         g.close()
     finally:
         del os.environ["GTX_GROUP_REHEARSE"]; del os.environ["GTX_GROUP_DIRECT"]
