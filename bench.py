@@ -134,16 +134,25 @@ def measure_host_to_result(eng, reads, n, hits, flags):
     return out
 
 
-def measure_text_to_stdout(n, m):
+def measure_text_to_stdout(n, m, cli_sample=None):
     """(iii) the product CLI `genomic_overlaps count -S -i REFS READS` from BED text and from a packed region file (.gtx) of the
-    same reads, wall time of the whole process with stdout going to a file; workload files made by gtx_packtool synth."""
+    same reads, wall time of the whole process with stdout going to a file; workload files made by gtx_packtool synth.
+    Second result (`text_cli`, the bench line's cpu_baseline.text_cli): the CPU restatement's CLI -- `gtx_oracle count -S -i`, the
+    reference's own parser, tokenizer, region objects and sorted merge restated (oracle/gtx_oracle.c follows genomic_overlaps.cpp:408-431
+    and what it calls) -- on the SAME BED file (all of it unless `cli_sample` says fewer lines), on one core and as one process per chromosome shard,
+    its output byte-equal to the product CLI's on that sample: the nearest thing to "the reference's genomic_overlaps timed beside"
+    that can travel to this box (the reference binary cannot: DESIGN.md section 6)."""
     import hashlib
     import subprocess
     import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import orc
+    cli_sample = n if cli_sample is None else cli_sample
     bins = os.path.join(PKG, "csrc")
     tmp = tempfile.mkdtemp(prefix="gtx_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
-    rp, qp, gp, op = [os.path.join(tmp, f) for f in ("refs.bed", "reads.bed", "reads.gtx", "out.txt")]
-    res = {}
+    rp, qp, gp, op, sp = [os.path.join(tmp, f) for f in ("refs.bed", "reads.bed", "reads.gtx", "out.txt", "sample.bed")]
+    made = [rp, qp, gp, op, sp]
+    res, cli = {}, None
     try:
         subprocess.run([os.path.join(bins, "gtx_packtool"), "synth", str(n), "7", qp], check=True)
         subprocess.run([os.path.join(bins, "gtx_packtool"), "synthrefs", str(m), "8", rp], check=True)
@@ -168,12 +177,115 @@ def measure_text_to_stdout(n, m):
         res["output_md5"] = digest["bed_text"]
         res["note"] = ("genomic_overlaps count -S -i, %d reads x %d regions, process wall time to exit with stdout to a file, best of 2; "
                        "host cores %d; never part of `value`" % (n, m, os.cpu_count()))
+
+        # ---- the CPU restatement's CLI on the same text (all of it by default: the restatement parses ~13 M lines/s on one core) ----
+        if cli_sample > 0 and os.path.exists(orc.CLI):
+            import mmap
+            ns = min(cli_sample, n)
+            with open(qp, "rb") as f:
+                mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+                size = len(mm)
+
+                def line_start(off):                                          # first line that begins at or after byte `off`
+                    if off <= 0:
+                        return 0
+                    k = mm.find(b"\n", off - 1)
+                    return size if k < 0 else k + 1
+
+                def name_at(off):
+                    return mm[off:mm.find(b"\t", off)]
+
+                end = size
+                if ns < n:                                                    # a prefix of ns lines (the file is in (chromosome, start) order)
+                    at, left = -1, ns
+                    while left > 0:
+                        at = mm.find(b"\n", at + 1); left -= 1
+                    end = at + 1
+                    with open(sp, "wb") as g:
+                        g.write(mm[:end])
+                    sample_path = sp
+                else:
+                    sample_path = qp
+                with open(op, "wb") as g:
+                    r = subprocess.run([os.path.join(bins, "genomic_overlaps"), "count", "-S", "-i", rp, sample_path], stdout=g, stderr=subprocess.PIPE)
+                if r.returncode != 0:
+                    sys.exit("text_cli: genomic_overlaps failed on the sample: " + r.stderr.decode()[-300:])
+                want = open(op, "rb").read()
+                t0 = time.perf_counter()
+                r = subprocess.run([orc.CLI, "count", "-S", "-i", rp, sample_path], capture_output=True)
+                one_s = time.perf_counter() - t0
+                if r.returncode != 0 or r.stdout != want:
+                    sys.exit("PARITY FAILURE: the CPU restatement's CLI and the product CLI disagree on the BED text (%d lines)" % ns)
+                cli = {"value": ns / one_s, "unit": "reads/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port", "seconds": one_s,
+                       "sample": "gtx_oracle count -S -i on %s of the BED text the text_to_stdout leg uses (%d regions), process wall time, "
+                                 "text parsing included; output md5 %s = the product CLI's on the same files"
+                                 % ("all %d lines" % ns if ns == n else "the first %d lines" % ns, m, hashlib.md5(want).hexdigest())}
+                # one process per chromosome shard (the reference's own sharding axis): the lines and the regions of a chromosome to a
+                # process each.  Both files are in strcmp order of the chromosome names, so a shard is a byte range (found by bisection
+                # on the line starts) and the shards' outputs, in the regions file's order, are the whole output.
+                names = []
+                with open(rp, "rb") as rf:
+                    rdata = rf.read()
+                pos = 0
+                while pos < len(rdata):
+                    c = rdata[pos:rdata.index(b"\t", pos)]
+                    names.append(c)
+                    lo, hi = pos, len(rdata)                                  # first line of another chromosome behind pos
+                    while lo < hi:
+                        mid = (lo + hi) // 2
+                        k = rdata.find(b"\n", mid)
+                        ls = len(rdata) if k < 0 else k + 1
+                        if ls >= len(rdata) or rdata[ls:rdata.index(b"\t", ls)] != c:
+                            hi = mid
+                        else:
+                            lo = mid + 1
+                    k = rdata.find(b"\n", lo)
+                    nxt = len(rdata) if k < 0 else k + 1
+                    fn = os.path.join(tmp, "r_%s.bed" % c.decode()); made.append(fn)
+                    with open(fn, "wb") as g:
+                        g.write(rdata[pos:nxt])
+                    pos = nxt
+                del rdata
+
+                def first_not_before(c):                                      # offset of the first line (< end) whose chromosome is >= c
+                    lo, hi = 0, end
+                    while lo < hi:
+                        mid = (lo + hi) // 2
+                        ls = min(line_start(mid), end)
+                        if ls >= end or name_at(ls) >= c:
+                            hi = mid
+                        else:
+                            lo = mid + 1
+                    return min(line_start(lo), end)
+
+                cuts = [first_not_before(c) for c in names] + [end]
+                for i, c in enumerate(names):
+                    fn = os.path.join(tmp, "q_%s.bed" % c.decode()); made.append(fn)
+                    lo, hi = cuts[i], max(cuts[i + 1], cuts[i])
+                    with open(fn, "wb") as g:
+                        if hi > lo and name_at(lo) == c:
+                            g.write(mm[lo:hi])
+                mm.close()
+
+            def one(c):
+                return subprocess.run([orc.CLI, "count", "-S", "-i", os.path.join(tmp, "r_%s.bed" % c.decode()), os.path.join(tmp, "q_%s.bed" % c.decode())],
+                                      capture_output=True)
+            workers = max(1, min(len(names), os.cpu_count() or 1))
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(workers) as ex:
+                outs = list(ex.map(one, names))
+            all_s = time.perf_counter() - t0
+            if any(o.returncode != 0 for o in outs) or b"".join(o.stdout for o in outs) != want:
+                sys.exit("PARITY FAILURE: the sharded run of the CPU restatement's CLI disagrees with the product CLI")
+            cli["all_cores"] = {"value": ns / all_s, "unit": "reads/s", "cores": workers, "host_cores": os.cpu_count(), "seconds": all_s,
+                                "note": "one gtx_oracle process per chromosome shard (%d shards: its lines of the text, its regions), outputs "
+                                        "concatenated in the regions file's chromosome order = the same bytes" % len(names)}
     finally:
-        for f in (rp, qp, gp, op):
+        for f in set(made):
             if os.path.exists(f):
                 os.remove(f)
         os.rmdir(tmp)
-    return res
+    return res, cli
 
 
 def bench_scans(args, eng, reads, n, rank, world, device, rehearse, total_reads, reads_per_rank, grp=None, locals_=(), per_chrom=None, owner=None):
@@ -778,7 +890,9 @@ def main():
     host_to_result = text_to_stdout = None
     if rank == 0 and world == 1 and not args.no_e2e:
         host_to_result = measure_host_to_result(eng, reads, n, hits, flags)
-        text_to_stdout = measure_text_to_stdout(n, len(refs))
+        text_to_stdout, text_cli = measure_text_to_stdout(n, len(refs))
+        if cpu is not None and text_cli is not None:
+            cpu["text_cli"] = text_cli
 
     if rank == 0:
         line = {

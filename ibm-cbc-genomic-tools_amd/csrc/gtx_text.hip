@@ -104,6 +104,7 @@ struct ParseArgs {
   int nChrom, strandAware, sortedRules, byStrand, weighted;
   long long maxLabel;
   int havePrev; unsigned prevNameOff, prevNameLen; int prevStrand; long long prevStart;   // the line before the block (its chromosome name in `names`' blob)
+  int prevLost;                // there is a line before the block, but its key did not travel (a chromosome name of 4096 bytes or more)
   int *tri; int *w; int *flag;
   unsigned *blkMinus;             // strand-aware runs: '-' lines per parse block (for the grouping pass), else null
 };
@@ -172,10 +173,12 @@ __global__ __launch_bounds__(kLines) void text_parse_kernel(ParseArgs a)
   __shared__ int tooLong;
   const unsigned j0 = blockIdx.x * kLines;
   const unsigned j1 = min(j0 + kLines, a.nLines);
+  // the caller's line count is not the block's: nl[] holds nothing to go by beyond the real count -- every parse block leaves before it
+  // reads a position (the flag voids the block, the host packer redoes it)
+  if (a.segTotal[0] != a.nLines) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.flag, 4); return; }
   // text of the block's lines: [t0, t1) (the newline of the last line included)
   const size_t t0 = j0 ? (size_t)a.nl[j0 - 1] + 1 : 0, t1 = (size_t)a.nl[j1 - 1] + 1;
   if (threadIdx.x == 0) tooLong = (t1 - t0 > (size_t)kLdsText - 32) ? 1 : 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && a.segTotal[0] != a.nLines) atomicOr(a.flag, 4);   // the caller's line count is not the block's
   __syncthreads();
   if (tooLong) { if (threadIdx.x == 0) atomicOr(a.flag, 2); return; }
   const size_t a0 = t0 & ~(size_t)15;                             // staged from the 16-byte line below t0: lds[k] = text[a0 + k]
@@ -205,10 +208,14 @@ __global__ __launch_bounds__(kLines) void text_parse_kernel(ParseArgs a)
       } else if (j > 0) {
         const size_t pb = j - 1 ? (size_t)a.nl[j - 2] + 1 : 0, pe = a.nl[j - 1];
         const unsigned char *g = (const unsigned char *)a.text + pb;
-        if (pe - pb > 4096 || !parse_line(g, 0u, (unsigned)(pe - pb), false, q2, q3, qn, qlen, qs, ql)) havePrev = false;
+        // (a line the parser refuses voids the block from its own thread; one that is merely too long to look at here leaves the
+        // order of this line undecided -- not a plain case: the host packer takes the block)
+        if (pe - pb > 4096) { havePrev = false; plain = false; }
+        else if (!parse_line(g, 0u, (unsigned)(pe - pb), false, q2, q3, qn, qlen, qs, ql)) havePrev = false;
         pn = g; pl = qlen; ps = qs; pstart = q2 + 1;
       } else {
         havePrev = a.havePrev != 0;
+        if (a.prevLost) plain = false;                            // the seam's key is not here to compare with: the host packer's block
         pn = (const unsigned char *)a.names + a.prevNameOff; pl = a.prevNameLen; ps = a.prevStrand; pstart = a.prevStart;
       }
       if (havePrev) {
@@ -296,7 +303,7 @@ hipError_t launch_tokenize(const TextDevice &d, const TextTables &t, const gtx_t
   a.segTotal = d.segCount + nSeg; a.table = (const ChromEntry *)t.table; a.tableMask = t.tableMask; a.names = t.names;
   a.nChrom = r.n_chrom; a.strandAware = r.strand_aware; a.sortedRules = r.sorted_rules; a.byStrand = r.sorted_by_strand;
   a.weighted = r.max_label_value > 1; a.maxLabel = r.max_label_value;
-  a.havePrev = r.have_prev && t.prevLen > 0; a.prevNameOff = t.prevOff; a.prevNameLen = t.prevLen; a.prevStrand = r.prev_strand; a.prevStart = r.prev_start;
+  a.havePrev = r.have_prev && t.prevLen > 0; a.prevLost = r.have_prev && t.prevLen == 0; a.prevNameOff = t.prevOff; a.prevNameLen = t.prevLen; a.prevStrand = r.prev_strand; a.prevStart = r.prev_start;
   a.tri = d.tri; a.w = d.w; a.flag = d.flag;
   const unsigned nBlocks = (nLines + kLines - 1) / kLines;
   a.blkMinus = nullptr;
