@@ -175,6 +175,67 @@ def measure_text_to_stdout(n, m, cli_sample=None):
         if digest["bed_text"] != digest["packed_gtx"]:
             sys.exit("PARITY FAILURE: the CLI's output differs between BED text and the packed region file")
         res["output_md5"] = digest["bed_text"]
+        # the inputs the reference's own examples use (examples/example01.tcsh:15 pipes its reads in; every shipped data file is .gz):
+        # the same text through a pipe, a gzip file of its first 20 M lines (inflate is one thread: that is its bound), and
+        # genomic_scans counts on the whole file -- all three tokenised on the device like the plain file
+        def timed(cmd, stdin_from=None, best_of=2):
+            best = None
+            for _ in range(best_of):
+                with open(op, "wb") as f:
+                    t0 = time.perf_counter()
+                    if stdin_from:
+                        cat = subprocess.Popen(["cat", stdin_from], stdout=subprocess.PIPE)
+                        r = subprocess.run(cmd, stdin=cat.stdout, stdout=f, stderr=subprocess.PIPE)
+                        cat.stdout.close(); cat.wait()
+                    else:
+                        r = subprocess.run(cmd, stdout=f, stderr=subprocess.PIPE)
+                    dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    sys.exit("text_to_stdout: %s failed: %s" % (cmd[0], r.stderr.decode()[-300:]))
+                best = dt if best is None else min(best, dt)
+            return best, hashlib.md5(open(op, "rb").read()).hexdigest()
+        ovl = [os.path.join(bins, "genomic_overlaps"), "count", "-S", "-i", rp]
+        dt, md = timed(ovl, stdin_from=qp)
+        if md != res["output_md5"]:
+            sys.exit("PARITY FAILURE: the CLI's output differs between a file and the same text on stdin")
+        res["stdin_pipe"] = {"seconds": dt, "reads_per_s": n / dt, "note": "cat reads.bed | genomic_overlaps count -S -i refs.bed"}
+        gz_lines = min(n, 20_000_000)
+        gzp, gzs = os.path.join(tmp, "part.bed.gz"), os.path.join(tmp, "part.bed")
+        made.extend([gzp, gzs])
+        with open(qp, "rb") as f, open(gzs, "wb") as g:
+            left = gz_lines
+            while left > 0:
+                buf = f.read(32 << 20)
+                if not buf:
+                    break
+                k = buf.count(b"\n")
+                if k > left:
+                    at = -1
+                    for _ in range(left):
+                        at = buf.index(b"\n", at + 1)
+                    buf, k = buf[:at + 1], left
+                g.write(buf); left -= k
+        subprocess.run("gzip -1 -c %s > %s" % (gzs, gzp), shell=True, check=True)
+        dt_plain, md_plain = timed(ovl + [gzs])
+        dt, md = timed(ovl + [gzp])
+        if md != md_plain:
+            sys.exit("PARITY FAILURE: the CLI's output differs between a file and its gzip")
+        t0 = time.perf_counter(); subprocess.run("gzip -dc %s > /dev/null" % gzp, shell=True, check=True); inflate = time.perf_counter() - t0
+        res["gz"] = {"seconds": dt, "reads_per_s": gz_lines / dt, "lines": gz_lines, "same_lines_uncompressed_seconds": dt_plain,
+                     "gzip_dc_alone_seconds": inflate, "gz_bytes": os.path.getsize(gzp),
+                     "note": "the first %d lines as .gz (gzip -1); bound: one inflate thread (gzip -dc of the same file alone beside it)" % gz_lines}
+        from gtx import synth as _synth
+        gnp = os.path.join(tmp, "genome.bed"); made.append(gnp)
+        with open(gnp, "w") as f:
+            for nm, ln in zip(_synth.CHROM_NAMES, _synth.CHROM_LEN):
+                f.write("%s\t0\t%d\n" % (nm, int(ln)))
+        scn = [os.path.join(bins, "genomic_scans"), "counts", "-i", "-g", gnp, "-w", "1000", "-d", "1000", "-min", "1"]
+        dt, md = timed(scn + [qp])
+        dt_g, md_g = timed(scn + [gp])
+        if md != md_g:
+            sys.exit("PARITY FAILURE: genomic_scans' output differs between BED text and the packed region file")
+        res["scans_counts"] = {"seconds": dt, "reads_per_s": n / dt, "packed_gtx_seconds": dt_g, "output_md5": md,
+                               "note": "genomic_scans counts -i -w 1000 -d 1000 -min 1 on the same %d reads (BASELINE config 4's geometry), from BED text and from .gtx" % n}
         res["note"] = ("genomic_overlaps count -S -i, %d reads x %d regions, process wall time to exit with stdout to a file, best of 2; "
                        "host cores %d; never part of `value`" % (n, m, os.cpu_count()))
 

@@ -656,10 +656,11 @@ static bool TextOnDevice(GenomicRegionSet *set, const PackOptions &opt, const Te
   if (!ts || (e && atoi(e) == 0)) return false;
   if (set->load_in_memory || set->format != "BED") return false;
   if (opt.guard || opt.collect_zero_length) return false;                 // (explode_blocks: a 12-column line sends its block back to the packer, which does it)
-  if (opt.mode != gtxhost::PACK_OVERLAPS_SORTED && opt.mode != gtxhost::PACK_OVERLAPS_UNSORTED) return false;
   if (!g_pool.buf[0] || !g_pool.buf[1] || !ts->usable()) return false;
-  const long left = set->StreamBytesLeft();                      // -1: not a regular uncompressed file
-  return left >= ((e && atoi(e) == 1) ? 1 : (32l << 20));
+  // a regular uncompressed file: worth it from 32 MB on.  A stream (stdin / a pipe, a .gz file, a FILE* of the caller's: -1) has no
+  // size to go by: it takes the device path, and pump_text hands a first block that turns out to be all there is to the host packer
+  const long left = set->StreamBytesLeft();
+  return left < 0 || left >= ((e && atoi(e) == 1) ? 1 : (32l << 20));
 }
 
 template <class Prep, class Sink>
@@ -675,14 +676,15 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
     for (int i = 0; i < opt.chroms->size(); i++) names[i] = opt.chroms->name(i).c_str();
     gtx_text_rules rules;
     rules.chrom_names = names.empty() ? NULL : names.data(); rules.n_chrom = opt.chroms->size();
-    rules.strand_aware = opt.strand_aware; rules.sorted_rules = opt.mode == gtxhost::PACK_OVERLAPS_SORTED; rules.sorted_by_strand = opt.sorted_by_strand;
+    rules.strand_aware = opt.strand_aware; rules.sorted_rules = opt.mode == gtxhost::PACK_OVERLAPS_SORTED || opt.mode == gtxhost::PACK_SCAN_SORTED; rules.sorted_by_strand = opt.sorted_by_strand;
     rules.max_label_value = opt.max_label_value;
     g_pool.used[0] = g_pool.used[1] = true;                      // (the buffers hold text now: a batch packed here takes heap memory)
     packer.UseTextBuffers((char *)g_pool.buf[0], (char *)g_pool.buf[1], kPoolBytes);
     PackedBatch batch;
     if (!packer.PackPrimedText(&batch, &err)) DiePack(err);
     if (!batch.empty()) sink(batch);
-    BedPacker::TextBlock blk[2]; int ticket[2] = {-1, -1}; bool host_only = false;
+    BedPacker::TextBlock blk[2]; int ticket[2] = {-1, -1}; bool host_only = false, first_block = true;
+    static const bool text_forced = getenv("GTX_TEXT_ON_DEVICE") && atoi(getenv("GTX_TEXT_ON_DEVICE")) == 1;
     long on_device = 0, redone = 0, host_blocks = 0;
     auto settle = [&](int k) {                                   // the verdict on the block in blk[k]
       if (ticket[k] < 0) return;
@@ -702,6 +704,8 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       if (!packer.NextTextBlock(&blk[cur])) break;
       BedPacker::TextBlock &b = blk[cur];
       if (!b.seam_ok) host_only = true;                          // a last line that could not be read: no seam key for the device
+      if (first_block && !text_forced && b.bytes < (32u << 20) && packer.SourceAtEnd()) host_only = true;   // a short stream: the host packer is done before the device has the text
+      first_block = false;
       if (host_only) {
         host_blocks++;
         batch.clear();
@@ -837,7 +841,6 @@ static bool TextLooksSorted(const char *text, size_t bytes)
 }
 
 // an error of a member context, reported through the group's channel (CheckGrp prints gtx_group_last_error)
-static void gtxi_note(gtx_group *, gtx_ctx *c) { fflush(stdout); fprintf(stderr, "\nError: [gtx] %s\n", gtx_last_error(c)); exit(1); }
 
 static bool LooksSortedVec(const std::vector<int32_t> &tri)
 {
@@ -1013,14 +1016,14 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   gtx_count_info info;
   // the query file's text tokenised on the device where that applies (one GPU, a plain BED file: TextOnDevice)
   TextSink text_sink;
-  text_sink.usable = [&] { return gtx_group_size(grp) == 1; };
-  text_sink.needs_host = [&](int ticket) { int redo = 0; gtx_ctx *c = gtx_group_ctx(grp, 0); if (gtx_text_result(c, ticket, &redo) != GTX_OK) { gtxi_note(grp, c); CheckGrp(grp, GTX_E_HIP); } return redo != 0; };
+  text_sink.usable = [&] { return gtx_group_size(grp) >= 1; };     // (several GPUs: the blocks go to the members in turn, gtx_group_count_add_text)
+  text_sink.needs_host = [&](int ticket) { int redo = 0; CheckGrp(grp, gtx_group_text_result(grp, ticket, &redo)); return redo != 0; };
   if (coverage) {
     // zero-length reads (sorted rules let them through) and zero-length regions contribute 0: the device leaves them out
     const uint32_t cflags = sorted ? (GTX_ZERO_LENGTH_OK | (match_gaps ? GTX_GAPS_FORMULA : 0u)) : 0u;
     text_sink.add = [&](const char *text, size_t bytes, int64_t lines, const gtx_text_rules &rules) {
-      int ticket = -1; gtx_ctx *c = gtx_group_ctx(grp, 0);
-      if (gtx_coverage_add_text(c, text, bytes, lines, &rules, cflags | (sorted ? GTX_READS_SORTED : 0u), &ticket) != GTX_OK) { gtxi_note(grp, c); CheckGrp(grp, GTX_E_HIP); }
+      int ticket = -1;
+      CheckGrp(grp, gtx_group_coverage_add_text(grp, text, bytes, lines, &rules, cflags | (sorted ? GTX_READS_SORTED : 0u), &ticket));
       return ticket;
     };
     DrainSet(QuerySet, opt, [&] { device_side(true); }, [&](const PackedBatch &b) {
@@ -1039,10 +1042,10 @@ unsigned long int *GenomicRegionSetOverlaps::Reduce(bool coverage, bool match_ga
   }
   const uint32_t mode_flags = sorted ? GTX_ZERO_LENGTH_OK : 0;
   text_sink.add = [&](const char *text, size_t bytes, int64_t lines, const gtx_text_rules &rules) {
-    int ticket = -1; gtx_ctx *c = gtx_group_ctx(grp, 0);
+    int ticket = -1;
     // (the sorted merge's input is in order, or the block comes back; the bin index takes any order: a look at the text decides the kernel)
     const uint32_t flags = mode_flags | ((sorted || TextLooksSorted(text, bytes)) ? GTX_READS_SORTED : 0);
-    if (gtx_count_add_text(c, text, bytes, lines, &rules, flags, &ticket) != GTX_OK) { gtxi_note(grp, c); CheckGrp(grp, GTX_E_HIP); }
+    CheckGrp(grp, gtx_group_count_add_text(grp, text, bytes, lines, &rules, flags, &ticket));
     return ticket;
   };
   DrainSet(QuerySet, opt, [&] { device_side(false); }, [&](const PackedBatch &b) {
@@ -1378,18 +1381,48 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
   opt.max_label_value = max_label_value;
   std::vector<int32_t> tri, w;
   bool bad_preprocess = false;                                     // raised at the first region that is processed, like the reference
-  DrainSet(R, opt, [] {}, [&](const PackedBatch &b) {
-    if ((sorted_rules && preprocess != '1') || (!sorted_rules && preprocess != '1' && preprocess != 'c')) { bad_preprocess = true; g_drain_stop = true; return; }
+  const bool preprocess_ok = sorted_rules ? preprocess == '1' : (preprocess == '1' || preprocess == 'c');
+  const char prep = (preprocess == 'c' && !sorted_rules) ? 'c' : '1';
+  const uint32_t rule_flags = sorted_rules ? GTX_ZERO_LENGTH_OK : 0u;
+  gtx_group *grp = NULL;
+  gtx_ctx *one = NULL;                                             // one GPU: the scan is fed as a stream (gtx_scan_begin .. gtx_scan_end)
+  auto device_side = [&] {
+    grp = Devices();
+    if (gtx_group_size(grp) != 1) return;
+    one = gtx_group_ctx(grp, 0);
+    if (gtx_scan_begin(one, class_len.data(), n_chrom * ns, (int32_t)win_step, (int32_t)win_size, prep, rule_flags, max_label_value > 1, class_off.data()) != GTX_OK) {
+      fflush(stdout); fprintf(stderr, "\nError: [gtx] %s\n", gtx_last_error(one)); exit(1);
+    }
+  };
+  auto check_one = [&](int rc) { if (rc != GTX_OK) { fflush(stdout); fprintf(stderr, "\nError: [gtx %d] %s\n", rc, gtx_last_error(one)); exit(1); } };
+  // the input's text tokenised on the device where that applies (one GPU, a streamed BED input: TextOnDevice)
+  TextSink text_sink;
+  text_sink.usable = [&] { return one != NULL; };
+  text_sink.needs_host = [&](int ticket) { int redo = 0; check_one(gtx_text_result(one, ticket, &redo)); return redo != 0; };
+  text_sink.add = [&](const char *text, size_t bytes, int64_t lines, const gtx_text_rules &rules) {
+    if (!preprocess_ok) { bad_preprocess = true; g_drain_stop = true; return -1; }
+    int ticket = -1;
+    check_one(gtx_scan_add_text(one, text, bytes, lines, &rules, (sorted_rules || TextLooksSorted(text, bytes)) ? 0u : GTX_READS_UNSORTED, &ticket));
+    return ticket;
+  };
+  DrainSet(R, opt, device_side, [&](const PackedBatch &b) {
+    if (!preprocess_ok) { bad_preprocess = true; g_drain_stop = true; return; }
     total_label_value += (long int)b.label_sum;
+    if (one) { check_one(gtx_scan_add(one, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), LooksSorted(b.tri) ? 0u : GTX_READS_UNSORTED)); return; }
     tri.insert(tri.end(), b.tri.begin(), b.tri.end());
     w.insert(w.end(), b.w.begin(), b.w.end());
-  });
+  }, &text_sink);
   if (bad_preprocess && sorted_rules) { fprintf(stderr, "Error: [SortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
   if (bad_preprocess) { fprintf(stderr, "Error: [UnsortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
-  gtx_group *grp = Devices();
-  const char prep = (preprocess == 'c' && !sorted_rules) ? 'c' : '1';
+  if (!grp) device_side();                                         // (an in-memory input: DrainSet has not run the hand-over's first step)
+  if (one) {
+    int64_t text_labels = 0;                                       // the lines the device took: their label values are summed there
+    check_one(gtx_scan_end(one, (uint64_t *)values.data(), &text_labels));
+    total_label_value += (long int)text_labels;
+    return;
+  }
   CheckGrp(grp, gtx_group_scan(grp, tri.data(), w.empty() ? NULL : w.data(), (int64_t)(tri.size() / 3), class_len.data(), n_chrom * ns,
-                               (int32_t)win_step, (int32_t)win_size, prep, (sorted_rules ? GTX_ZERO_LENGTH_OK : 0u) | (LooksSortedVec(tri) ? GTX_READS_SORTED : 0u),
+                               (int32_t)win_step, (int32_t)win_size, prep, rule_flags | (LooksSortedVec(tri) ? GTX_READS_SORTED : 0u),
                                (uint64_t *)values.data(), class_off.data()));
 }
 

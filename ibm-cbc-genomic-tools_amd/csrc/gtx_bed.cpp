@@ -165,11 +165,36 @@ char *LineSource::Next()
   }
 }
 
-// a regular text file only (fd_ >= 0): up to `cap` bytes of complete lines straight into dst (page-locked memory of the caller's).
-// Returns 0 at the end of the input and (size_t)-1 when not even one line fits (or the source is not a regular file).
+// Up to `cap` bytes of complete lines straight into dst (page-locked memory of the caller's): a regular text file by parallel preads, a
+// stream (stdin, a pipe, a .gz file through inflate, a FILE* of the caller's) by straight reads behind what the line reader had buffered;
+// what follows the last newline waits in buf_ for the next call.  Returns 0 at the end of the input and (size_t)-1 when not even one
+// line fits (nothing is lost: the bytes are back in buf_ for NextBlock).
 size_t LineSource::ReadTextInto(char *dst, size_t cap, long *first_line)
 {
-  if (fd_ < 0) return (size_t)-1;
+  if (fd_ < 0) {
+    *first_line = line_no_ + 1;
+    size_t n = end_ - pos_;
+    if (n > cap) return (size_t)-1;
+    if (n) memcpy(dst, buf_.data() + pos_, n);
+    pos_ = end_ = 0;
+    while (n < cap && !eof_) {
+      size_t got;
+      if (gz_) { const int g = gzread(gz_, dst + n, (unsigned)std::min<size_t>(cap - n, 1u << 30)); got = g > 0 ? (size_t)g : 0; }
+      else got = fread(dst + n, 1, cap - n, fp_);
+      if (got == 0) { eof_ = true; break; }
+      n += got;
+    }
+    if (n == 0) return 0;
+    const char *nl = (const char *)memrchr(dst, '\n', n);
+    const size_t keep = nl ? (size_t)(nl - dst) + 1 : 0;
+    if (keep == 0 && eof_) return 0;                       // only an unterminated tail is left: dropped, like the line reader does
+    const size_t back = keep ? n - keep : n;                // the tail behind the last newline (or everything: a line longer than the buffer)
+    if (back > buf_.size()) buf_.resize(back + (back >> 1));
+    if (back) memcpy(buf_.data(), dst + (n - back), back);
+    pos_ = 0; end_ = back;
+    return keep ? keep : (size_t)-1;
+  }
+
   *first_line = line_no_ + 1;
   if (!bulk_started_) {
     bulk_started_ = true;

@@ -42,7 +42,8 @@ class LineSource {
   // Same, but a regular text file is read with several pread() calls in parallel straight into
   // `block` (no intermediate buffer); *view = block.data().  .gz and stdin go through NextBlock.
   size_t NextBlockView(std::vector<char> &block, char **view, size_t target_bytes, long *first_line);
-  size_t ReadTextInto(char *dst, size_t cap, long *first_line);     // regular text files: complete lines straight into the caller's memory
+  size_t ReadTextInto(char *dst, size_t cap, long *first_line);     // complete lines straight into the caller's memory (files by parallel preads, streams by straight reads)
+  bool at_end() const { return fd_ >= 0 ? (bulk_started_ && file_pos_ >= file_len_) : eof_; }   // no complete line is left to read (a stream: known once a read has met the end)
   void AdvanceLines(long n) { line_no_ += n; }
   long regular_file_bytes() const { return fd_ >= 0 ? (long)file_len_ : -1; }   // -1: stdin, .gz, a FILE* of the caller's
 
@@ -224,6 +225,7 @@ class BedPacker {
   bool PackPrimedText(PackedBatch *out, PackError *err);
   void UseTextBuffers(char *b0, char *b1, size_t cap) { text_buf_[0] = b0; text_buf_[1] = b1; text_cap_ = cap; }   // NextTextBlock reads into these in turn
   bool NextTextBlock(TextBlock *b);
+  bool SourceAtEnd() const { return !src_ || exhausted_ || src_->at_end(); }
   bool PackTextBlock(const TextBlock &b, PackedBatch *out, PackError *err);   // the host's reading of that block (appended to *out)
  private:
   char *text_buf_[2] = {nullptr, nullptr}; size_t text_cap_ = 0;

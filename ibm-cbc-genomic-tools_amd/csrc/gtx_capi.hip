@@ -103,7 +103,7 @@ struct gtx_ctx {
   struct TextSlot {
     char *d_text = nullptr; size_t capText = 0; unsigned *d_seg = nullptr; size_t capSeg = 0;
     unsigned *d_nl = nullptr; int *d_tri = nullptr, *d_w = nullptr, *d_tri2 = nullptr, *d_w2 = nullptr; unsigned *d_blk = nullptr; size_t capLines = 0, capLines2 = 0;
-    int *d_flag = nullptr, *h_flag = nullptr; char *h_pin = nullptr; size_t capPin = 0; char *h_seam = nullptr;
+    int *d_flag = nullptr, *h_flag = nullptr; char *h_pin = nullptr; size_t capPin = 0; char *h_seam = nullptr; unsigned long long *d_sum = nullptr;
     hipEvent_t evParsed = nullptr, evConsumed = nullptr, evCopied = nullptr; bool busy = false;
   } text[2];
   long long textSeq = 0;
@@ -129,6 +129,9 @@ struct gtx_ctx {
 
   // streaming count (begin/add/end)
   bool streamOpen = false; int64_t streamSeen = 0; int32_t streamLast[2] = {0, 0};
+  // gtx_scan_begin .. gtx_scan_end: the open scan's geometry and what its batches have added so far
+  struct ScanOpen { bool open = false, weighted = false; gtx::ScanArgs a; std::vector<int32_t> classLen; int64_t extent = 0; char prep = '1'; uint32_t flags = 0;
+                    unsigned long long *d_labelSum = nullptr; } scan;
   int64_t seamUnsorted = INT64_MAX;    // first order violation found at a seam between batches (host-side check)
 
   int64_t batchReads = 8ll << 20;       // reads per device batch of the host-buffer entry points (96 MiB of triples: ~2 ms of PCIe)
@@ -243,7 +246,7 @@ void gtx_destroy(gtx_ctx *c)
   dfree(c->d_bktReads); dfree(c->d_bktWeights); dfree(c->d_bktDir); dfree(c->d_sampE); dfree(c->d_sampS); dfree(c->d_topE); dfree(c->d_topS); dfree(c->d_bkt); dfree(c->d_clsCell); dfree(c->d_cellTab); dfree(c->d_bktT); dfree(c->d_clsCellT); dfree(c->d_cellTabT); c->nBT = 0;
   dfree(c->d_placeCls); dfree(c->d_placeRank); dfree(c->d_placeClsT); dfree(c->d_placeRankT); dfree(c->d_shareTiles); dfree(c->d_shareRegions); dfree(c->d_shareOwned);
   dfree(c->d_bktCnt); dfree(c->d_bktS); dfree(c->d_clsCellS); dfree(c->d_cellTabS); dfree(c->d_scanParts); dfree(c->d_scanInfo); c->nBS = 0;
-  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info); dfree(c->d_chainFlags); free_alt_sets(c); dfree(c->d_info3);
+  dfree(c->d_histA); dfree(c->d_histB); dfree(c->d_partA); dfree(c->d_partB); dfree(c->d_prefA); dfree(c->d_prefB); dfree(c->d_info); dfree(c->d_chainFlags); free_alt_sets(c); dfree(c->d_info3); dfree(c->scan.d_labelSum);
   if (c->copyStream) (void)hipStreamSynchronize(c->copyStream);
   for (int k = 0; k < 2; k++) {
     dfree(c->d_stage[k]); dfree(c->d_stageW[k]);
@@ -254,7 +257,7 @@ void gtx_destroy(gtx_ctx *c)
   }
   if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
   for (auto &t : c->text) {
-    dfree(t.d_text); dfree(t.d_seg); dfree(t.d_nl); dfree(t.d_tri); dfree(t.d_w); dfree(t.d_tri2); dfree(t.d_w2); dfree(t.d_blk); dfree(t.d_flag);
+    dfree(t.d_text); dfree(t.d_seg); dfree(t.d_nl); dfree(t.d_tri); dfree(t.d_w); dfree(t.d_tri2); dfree(t.d_w2); dfree(t.d_blk); dfree(t.d_flag); dfree(t.d_sum);
     if (t.h_flag) (void)hipHostFree(t.h_flag);
     if (t.h_pin) (void)hipHostFree(t.h_pin);
     if (t.h_seam) (void)hipHostFree(t.h_seam);
@@ -1694,15 +1697,77 @@ int gtx_scan(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n
   return GTX_OK;
 }
 
+// ---- the same scan fed as a stream (genomic_scans on an input of any size: host batches, or text tokenised on the device) ----
+// The micro-window histogram accumulates over the batches (general kernels; batches in no order through the partition path), the
+// sliding sums follow at the end.  The all-at-once calls above stay what a caller with every read in hand uses: they can take the
+// owner-computes pass.
+int gtx_scan_begin(gtx_ctx *c, const int32_t *classLen, int32_t nClasses, int32_t step, int32_t size, char prep, uint32_t flags, int weighted,
+                   const int64_t *classOff)
+{
+  if (!c) return GTX_E_ARG;
+  if (prep != '1' && prep != 'c') return fail(c, GTX_E_ARG, "gtx_scan_begin: preprocess operator must be '1' or 'c'");
+  if (nClasses < 1 || !classLen || !classOff) return fail(c, GTX_E_ARG, "gtx_scan_begin: bad class table");
+  if (step <= 0 || size <= 0 || size % step) return fail(c, GTX_E_ARG, "gtx_scan_begin: window size must be a positive multiple of window step");
+  if (c->scan.open || c->streamOpen || c->covOpen) return fail(c, GTX_E_STATE, "gtx_scan_begin: a call is open");
+  HIPCHK(c, hipSetDevice(c->device));
+  int64_t extent = 0;
+  for (int i = 0; i < nClasses; i++) extent = std::max<int64_t>(extent, classOff[i] + gtx_scan_n_windows(classLen[i] < 0 ? 0 : classLen[i], step, size));
+  int rc = ensure_out(c, (size_t)extent); if (rc) return rc;
+  if (extent > 0) HIPCHK(c, hipMemsetAsync(c->d_out, 0, (size_t)extent * sizeof(u64), c->stream));
+  gtx_ctx::ScanOpen &s = c->scan;
+  rc = scan_prepare(c, classLen, nClasses, step, size, classOff, &s.a); if (rc) return rc;
+  s.a.center = prep == 'c'; s.a.sortedRule = (flags & GTX_ZERO_LENGTH_OK) ? 1 : 0;
+  s.weighted = weighted != 0; s.classLen.assign(classLen, classLen + nClasses); s.extent = extent; s.prep = prep; s.flags = flags;
+  if (c->scanTotalMicro > 0) HIPCHK(c, hipMemsetAsync(c->d_micro, 0, (size_t)c->scanTotalMicro * (s.weighted ? 8 : 4), c->stream));
+  if (!s.d_labelSum) HIPCHK(c, hipMalloc(&s.d_labelSum, sizeof(unsigned long long)));
+  HIPCHK(c, hipMemsetAsync(s.d_labelSum, 0, sizeof(unsigned long long), c->stream));
+  s.open = true;
+  return GTX_OK;
+}
+
+int gtx_scan_add(gtx_ctx *c, const int32_t *reads, const int32_t *weights, int64_t n, uint32_t flags)
+{
+  if (!c) return GTX_E_ARG;
+  if (!c->scan.open) return fail(c, GTX_E_STATE, "gtx_scan_add: gtx_scan_begin has not been called");
+  if (n < 0 || (n > 0 && !reads) || (c->scan.weighted && n > 0 && !weights) || (!c->scan.weighted && weights)) return fail(c, GTX_E_ARG, "gtx_scan_add: bad argument (weights as announced to gtx_scan_begin)");
+  HIPCHK(c, hipSetDevice(c->device));
+  gtx_ctx::ScanOpen &s = c->scan;
+  return stage_batches(c, reads, weights, n, [&](const void *dR, const int *dW, int64_t cnt, int64_t off) -> int {
+    const bool unsorted = (flags & GTX_READS_UNSORTED) || host_reads_look_unsorted(reads + 3 * off, cnt);
+    return scan_hist_any(c, dR, dW, cnt, s.a, s.classLen.data(), unsorted);
+  });
+}
+
+int gtx_scan_end(gtx_ctx *c, uint64_t *out, int64_t *labelSum)
+{
+  if (!c) return GTX_E_ARG;
+  if (!c->scan.open) return fail(c, GTX_E_STATE, "gtx_scan_end: gtx_scan_begin has not been called");
+  gtx_ctx::ScanOpen &s = c->scan;
+  s.open = false;
+  if (s.extent > 0 && !out) return fail(c, GTX_E_ARG, "gtx_scan_end: null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, gtx::launch_scan_windows(c->d_micro, s.weighted, s.a, c->scanTotalTiles, c->d_out, c->stream));
+  if (s.extent > 0) HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)s.extent * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  unsigned long long sum = 0;
+  HIPCHK(c, hipMemcpyAsync(&sum, s.d_labelSum, sizeof sum, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->copyStream));
+  if (labelSum) *labelSum = (int64_t)sum;
+  return GTX_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
 // region text tokenised on the device (gtx_text.hip)
 // ---------------------------------------------------------------------------------------------
-static int add_text(gtx_ctx *c, bool coverage, const char *text, size_t bytes, int64_t nLines, const gtx_text_rules *r, uint32_t flags, int *ticket)
+enum TextMode { TEXT_COUNT, TEXT_COVER, TEXT_SCAN };
+static int add_text(gtx_ctx *c, TextMode mode, const char *text, size_t bytes, int64_t nLines, const gtx_text_rules *r, uint32_t flags, int *ticket)
 {
-  const char *who = coverage ? "gtx_coverage_add_text" : "gtx_count_add_text";
-  if (coverage ? !c->covOpen : !c->streamOpen) return fail(c, GTX_E_STATE, "gtx_*_add_text: no open count / coverage call");
+  const bool coverage = mode == TEXT_COVER;
+  const char *who = mode == TEXT_SCAN ? "gtx_scan_add_text" : coverage ? "gtx_coverage_add_text" : "gtx_count_add_text";
+  if (mode == TEXT_SCAN ? !c->scan.open : coverage ? !c->covOpen : !c->streamOpen) return fail(c, GTX_E_STATE, "gtx_*_add_text: no open count / coverage / scan call");
+  if (mode == TEXT_SCAN && r && (r->max_label_value > 1) != c->scan.weighted) return fail(c, GTX_E_ARG, "gtx_scan_add_text: the rules' label weights do not match gtx_scan_begin's");
   if (!text || !r || !ticket || nLines < 0 || bytes >= (1ull << 32) - 4096 || nLines >= (1ll << 31) || r->n_chrom < 0 || (r->n_chrom > 0 && !r->chrom_names))
     { c->err = std::string(who) + ": bad argument"; return GTX_E_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
@@ -1713,6 +1778,7 @@ static int add_text(gtx_ctx *c, bool coverage, const char *text, size_t bytes, i
     HIPCHK(c, hipEventCreateWithFlags(&t.evParsed, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&t.evConsumed, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&t.evCopied, hipEventDisableTiming));
     HIPCHK(c, hipMalloc(&t.d_flag, sizeof(int))); HIPCHK(c, hipHostMalloc((void **)&t.h_flag, sizeof(int))); HIPCHK(c, hipHostMalloc((void **)&t.h_seam, 4096));
+    HIPCHK(c, hipMalloc(&t.d_sum, sizeof(unsigned long long))); HIPCHK(c, hipMemset(t.d_sum, 0, sizeof(unsigned long long)));
   }
   if (t.busy) { HIPCHK(c, hipEventSynchronize(t.evConsumed)); t.busy = false; }          // the block before last has been counted: its buffers are free
   c->textSeq++;
@@ -1771,13 +1837,21 @@ static int add_text(gtx_ctx *c, bool coverage, const char *text, size_t bytes, i
   gtxtext::TextDevice d; d.text = t.d_text; d.segCount = t.d_seg; d.nl = t.d_nl; d.tri = t.d_tri; d.w = t.d_w; d.flag = t.d_flag;
   d.tri2 = r->strand_aware ? t.d_tri2 : nullptr; d.w2 = r->strand_aware ? t.d_w2 : nullptr; d.blkMinus = r->strand_aware ? t.d_blk : nullptr;
   const int *triOut = r->strand_aware ? t.d_tri2 : t.d_tri;
-  HIPCHK(c, gtxtext::launch_tokenize(d, tabs, *r, bytes, (unsigned)nLines, c->stream));
+  d.labelSum = mode == TEXT_SCAN ? c->scan.d_labelSum : nullptr; d.blockSum = t.d_sum;
+  HIPCHK(c, gtxtext::launch_tokenize(d, tabs, *r, bytes, (unsigned)nLines, c->stream, mode == TEXT_SCAN ? (c->scan.a.sortedRule ? 2 : 1) : 0));
   HIPCHK(c, hipMemcpyAsync(t.h_flag, t.d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipEventRecord(t.evParsed, c->stream));
   // ... and counted where the triples are
   const int *dW = r->max_label_value > 1 ? (r->strand_aware ? t.d_w2 : t.d_w) : nullptr;
   const int64_t seen = c->streamSeen;
   int rc = GTX_OK;
+  if (mode == TEXT_SCAN) {
+    // (a block of a sorted stream is in order: the general kernels aggregate runs of equal micro-windows; any other block: the partition path)
+    rc = scan_hist_any(c, triOut, dW, nLines, c->scan.a, c->scan.classLen.data(), (flags & GTX_READS_UNSORTED) != 0); if (rc) return rc;
+    HIPCHK(c, hipEventRecord(t.evConsumed, c->stream));
+    t.busy = true;
+    return GTX_OK;
+  }
   if (coverage) {
     if (flags & GTX_GAPS_FORMULA) { rc = merge_prepare(c, flags, 2); if (rc) return rc; }
     rc = cover_launch(c, triOut, dW, nLines, seen, flags, (flags & GTX_READS_UNSORTED) != 0 || !(flags & GTX_READS_SORTED)); if (rc) return rc;
@@ -1798,9 +1872,11 @@ static int add_text(gtx_ctx *c, bool coverage, const char *text, size_t bytes, i
 
 extern "C" {
 int gtx_count_add_text(gtx_ctx *c, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket)
-{ return c ? add_text(c, false, text, bytes, n_lines, rules, flags, ticket) : GTX_E_ARG; }
+{ return c ? add_text(c, TEXT_COUNT, text, bytes, n_lines, rules, flags, ticket) : GTX_E_ARG; }
 int gtx_coverage_add_text(gtx_ctx *c, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket)
-{ return c ? add_text(c, true, text, bytes, n_lines, rules, flags, ticket) : GTX_E_ARG; }
+{ return c ? add_text(c, TEXT_COVER, text, bytes, n_lines, rules, flags, ticket) : GTX_E_ARG; }
+int gtx_scan_add_text(gtx_ctx *c, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket)
+{ return c ? add_text(c, TEXT_SCAN, text, bytes, n_lines, rules, flags, ticket) : GTX_E_ARG; }
 int gtx_text_result(gtx_ctx *c, int ticket, int *needs_host)
 {
   if (!c || !needs_host || (ticket & ~1)) return c ? fail(c, GTX_E_ARG, "gtx_text_result: bad argument") : GTX_E_ARG;

@@ -152,6 +152,8 @@ struct gtx_group {
   std::vector<int32_t> owner;              // class -> member
   std::vector<int64_t> memberReads;        // reads routed to each member in the open call
   bool countOpen = false, coverOpen = false;
+  bool fullVectors = false;                // the open count call has counted text blocks: reads of any class on any member -- the members' full vectors are summed
+  unsigned long long textTurn = 0;         // gtx_group_*_add_text: next member
   unsigned long long regionsTurn = 0;                 // gtx_group_count_add_regions: next member
   bool lastAsync = false;                             // the last device count call finalized on the exchange streams
   bool rehearse = false;                   // GTX_GROUP_REHEARSE=1
@@ -810,7 +812,7 @@ static int finish(gtx_group *g, bool coverage, uint64_t *out, gtx_count_info *in
   // count on a plain reference set: every member finalizes its own classes into its piece of the compact vector
   bool pairs = false;                                            // multi-interval regions: corrections go into a member's whole vector
   for (int i = 0; i < n; i++) pairs = pairs || gtxi_pairs_on(g->ctx[i]);
-  const bool pieces = !coverage && !(g->refFlags & GTX_REFS_KEEP_ZERO_LENGTH) && !pairs;
+  const bool pieces = !coverage && !(g->refFlags & GTX_REFS_KEEP_ZERO_LENGTH) && !pairs && !g->fullVectors;
   if (pieces) { int rc = ensure_plan(g); if (rc) return rc; }
   for (int i = 0; i < n; i++) GCHK_CTX(g, i, coverage ? gtxi_coverage_finish(g->ctx[i], &d[i]) : gtxi_count_finish(g->ctx[i], &d[i], pieces ? 1 : 0));
   GCHK_HIP(g, hipSetDevice(g->dev[0]));
@@ -849,7 +851,7 @@ int gtx_group_count_begin(gtx_group *g)
   if (!g) return GTX_E_ARG;
   NEED_ALL_LOCAL(g, "gtx_group_count_begin");
   { int rcw = wait_exchanges(g); if (rcw) return rcw; }            // (device calls still finalizing / exchanging: their output vector is about to be reused)
-  g->lastAsync = false;
+  g->lastAsync = false; g->fullVectors = false;
   for (size_t i = 0; i < g->ctx.size(); i++) GCHK_CTX(g, i, gtx_count_begin(g->ctx[i]));
   std::fill(g->memberReads.begin(), g->memberReads.end(), 0);
   g->countOpen = true;
@@ -866,6 +868,41 @@ int gtx_group_count_add(gtx_group *g, const int32_t *reads, const int32_t *weigh
     GCHK_CTX(g, m, gtx_count_add(g->ctx[m], r, w, cnt, flags));
     return GTX_OK;
   });
+}
+
+// Region text tokenised on the device (gtx_count_add_text) in a group: a block of the stream goes to the members in turn, whatever
+// the classes of its lines -- the read stream is split evenly, every member holds the whole reference set -- so the call ends with the
+// sum of the members' full vectors (ncclReduce) instead of pieces.  ticket = 2 x local member + the member's slot.
+int gtx_group_count_add_text(gtx_group *g, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket)
+{
+  if (!g || !ticket) return GTX_E_ARG;
+  if (!g->countOpen) return gfail(g, GTX_E_STATE, "gtx_group_count_add_text: gtx_group_count_begin has not been called");
+  const int m = (int)(g->textTurn++ % g->ctx.size());
+  int t = -1;
+  GCHK_CTX(g, m, gtx_count_add_text(g->ctx[m], text, bytes, n_lines, rules, flags & ~GTX_CHECK_SORTED, &t));
+  if (g->ctx.size() > 1) g->fullVectors = true;
+  g->memberReads[g->member(m)] += n_lines;
+  *ticket = 2 * m + t;
+  return GTX_OK;
+}
+
+int gtx_group_coverage_add_text(gtx_group *g, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket)
+{
+  if (!g || !ticket) return GTX_E_ARG;
+  if (!g->coverOpen) return gfail(g, GTX_E_STATE, "gtx_group_coverage_add_text: gtx_group_coverage_begin has not been called");
+  const int m = (int)(g->textTurn++ % g->ctx.size());
+  int t = -1;
+  GCHK_CTX(g, m, gtx_coverage_add_text(g->ctx[m], text, bytes, n_lines, rules, flags, &t));
+  g->memberReads[g->member(m)] += n_lines;
+  *ticket = 2 * m + t;
+  return GTX_OK;
+}
+
+int gtx_group_text_result(gtx_group *g, int ticket, int *needs_host)
+{
+  if (!g || !needs_host || ticket < 0 || (size_t)(ticket >> 1) >= g->ctx.size()) return g ? gfail(g, GTX_E_ARG, "gtx_group_text_result: bad argument") : GTX_E_ARG;
+  GCHK_CTX(g, ticket >> 1, gtx_text_result(g->ctx[ticket >> 1], ticket & 1, needs_host));
+  return GTX_OK;
 }
 
 int gtx_group_set_ref_blocks(gtx_group *g, const int64_t *first, const int32_t *blocks)

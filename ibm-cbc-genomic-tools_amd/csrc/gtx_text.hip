@@ -104,6 +104,7 @@ struct ParseArgs {
   int nChrom, strandAware, sortedRules, byStrand, weighted;
   long long maxLabel;
   int havePrev; unsigned prevNameOff, prevNameLen; int prevStrand; long long prevStart;   // the line before the block (its chromosome name in `names`' blob)
+  int scanRules; unsigned long long *blockSum;   // see launch_tokenize
   int prevLost;                // there is a line before the block, but its key did not travel (a chromosome name of 4096 bytes or more)
   int *tri; int *w; int *flag;
   unsigned *blkMinus;             // strand-aware runs: '-' lines per parse block (for the grouping pass), else null
@@ -171,6 +172,8 @@ __global__ __launch_bounds__(kLines) void text_parse_kernel(ParseArgs a)
 {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsText];
   __shared__ int tooLong;
+  __shared__ unsigned long long sumLabels;
+  if (threadIdx.x == 0) sumLabels = 0;
   const unsigned j0 = blockIdx.x * kLines;
   const unsigned j1 = min(j0 + kLines, a.nLines);
   // the caller's line count is not the block's: nl[] holds nothing to go by beyond the real count -- every parse block leaves before it
@@ -188,12 +191,15 @@ __global__ __launch_bounds__(kLines) void text_parse_kernel(ParseArgs a)
   }
   __syncthreads();
   const unsigned j = j0 + threadIdx.x;
-  if (j >= j1) return;
+  if (j >= j1) { if (a.blockSum) __syncthreads(); return; }       // (the barrier of the label sum below)
   const unsigned b = (unsigned)((j ? (size_t)a.nl[j - 1] + 1 : 0) - a0), e = (unsigned)((size_t)a.nl[j] - a0);
   long long v2, v3, label; int nTok, strand; unsigned tokLen;
   bool plain = parse_line((const unsigned char *)lds, b, e, a.weighted != 0, v2, v3, nTok, tokLen, strand, label);
   int cls = -1, start = 0, stop = 0, wv = 1;
+  long long lineLabel = 0;                                        // GetLabelValue of the line (genomic_intervals.cpp:1081-1085), whatever becomes of it
   if (plain) {
+    lineLabel = 1;
+    if (a.weighted) { const long long lv = nTok >= 4 ? label : 0; lineLabel = lv < a.maxLabel ? lv : a.maxLabel; }
     const long long S = v2 + 1, E = v3;                           // BED: start = atol(col2) + 1, stop = atol(col3)
     if (S >= INT_MAX - 1 || E >= INT_MAX - 1) plain = false;
     // the order check of the sorted merge (NextQuery :5889-5898 via IsBefore :396-401): key (chromosome, [strand,] start) against the line before
@@ -242,8 +248,9 @@ __global__ __launch_bounds__(kLines) void text_parse_kernel(ParseArgs a)
           if (same) { id = en.id; break; }
         }
       }
+      if (a.scanRules == 1 && (S > E || E <= 0)) id = -1;         // the unsorted scanner skips such an interval before it looks at the chromosome (:5039)
       if (id >= 0) {
-        if (!a.sortedRules && (E <= 0 || S > E)) plain = false;   // the unsorted algorithm's errors (:5740-5741): the host reports them
+        if (!a.scanRules && !a.sortedRules && (E <= 0 || S > E)) plain = false;   // the unsorted algorithm's errors (:5740-5741): the host reports them
         else {
           cls = id + ((a.strandAware && strand == '-') ? a.nChrom : 0);
           start = (int)S; stop = (int)E;
@@ -253,6 +260,11 @@ __global__ __launch_bounds__(kLines) void text_parse_kernel(ParseArgs a)
     }
   }
   if (!plain) atomicOr(a.flag, 1);
+  if (a.blockSum) {
+    if (plain && lineLabel != 0) atomicAdd(&sumLabels, (unsigned long long)lineLabel);
+    __syncthreads();
+    if (threadIdx.x == 0 && sumLabels != 0) atomicAdd(a.blockSum, sumLabels);
+  }
   a.tri[3 * (size_t)j] = cls; a.tri[3 * (size_t)j + 1] = start; a.tri[3 * (size_t)j + 2] = stop;
   if (a.weighted) a.w[j] = wv;
   if (a.blkMinus && cls >= a.nChrom) atomicAdd(&a.blkMinus[blockIdx.x], 1u);
@@ -286,13 +298,16 @@ __global__ __launch_bounds__(kLines) void strand_group_kernel(const int *__restr
 }
 
 // a block that is not plain is not counted at all: the host packer redoes it
-__global__ __launch_bounds__(256) void text_void_kernel(int *__restrict__ tri, unsigned nLines, const int *__restrict__ flag)
+__global__ __launch_bounds__(256) void text_void_kernel(int *__restrict__ tri, unsigned nLines, const int *__restrict__ flag,
+                                                        unsigned long long *blockSum, unsigned long long *labelSum)
 {
+  // (scans: the label values of a plain block's lines join the call's total; a block that goes back to the host brings its own)
+  if (blockSum && blockIdx.x == 0 && threadIdx.x == 0) { if (*flag == 0) atomicAdd(labelSum, *blockSum); *blockSum = 0; }
   if (*flag == 0) return;
   for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < nLines; j += (size_t)gridDim.x * 256) tri[3 * j] = -1;
 }
 
-hipError_t launch_tokenize(const TextDevice &d, const TextTables &t, const gtx_text_rules &r, size_t bytes, unsigned nLines, hipStream_t st)
+hipError_t launch_tokenize(const TextDevice &d, const TextTables &t, const gtx_text_rules &r, size_t bytes, unsigned nLines, hipStream_t st, int scanRules)
 {
   const unsigned nSeg = (unsigned)((bytes + kSeg - 1) / kSeg);
   nl_count_kernel<<<nSeg, 64, 0, st>>>(d.text, bytes, d.segCount);
@@ -305,6 +320,7 @@ hipError_t launch_tokenize(const TextDevice &d, const TextTables &t, const gtx_t
   a.weighted = r.max_label_value > 1; a.maxLabel = r.max_label_value;
   a.havePrev = r.have_prev && t.prevLen > 0; a.prevLost = r.have_prev && t.prevLen == 0; a.prevNameOff = t.prevOff; a.prevNameLen = t.prevLen; a.prevStrand = r.prev_strand; a.prevStart = r.prev_start;
   a.tri = d.tri; a.w = d.w; a.flag = d.flag;
+  a.scanRules = scanRules; a.blockSum = d.labelSum ? d.blockSum : nullptr;
   const unsigned nBlocks = (nLines + kLines - 1) / kLines;
   a.blkMinus = nullptr;
   if (r.strand_aware && d.tri2) {
@@ -313,7 +329,7 @@ hipError_t launch_tokenize(const TextDevice &d, const TextTables &t, const gtx_t
     if (e != hipSuccess) return e;
   }
   text_parse_kernel<<<nBlocks, kLines, 0, st>>>(a);
-  text_void_kernel<<<256, 256, 0, st>>>(d.tri, nLines, d.flag);
+  text_void_kernel<<<256, 256, 0, st>>>(d.tri, nLines, d.flag, d.labelSum ? d.blockSum : nullptr, d.labelSum);
   if (a.blkMinus) {
     nl_scan_kernel<<<1, 1024, 0, st>>>(d.blkMinus, nBlocks);
     strand_group_kernel<<<nBlocks, kLines, 0, st>>>(d.tri, a.weighted ? d.w : nullptr, nLines, r.n_chrom, d.blkMinus, nBlocks, d.tri2, a.weighted ? d.w2 : nullptr, d.flag);

@@ -35,6 +35,23 @@ class CountInfo(ctypes.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class TextRules(ctypes.Structure):
+    """gtx_text_rules (include/gtx.h): how the device reads a block of BED text"""
+    _fields_ = [("chrom_names", ctypes.POINTER(ctypes.c_char_p)), ("n_chrom", ctypes.c_int32),
+                ("strand_aware", ctypes.c_int32), ("sorted_rules", ctypes.c_int32), ("sorted_by_strand", ctypes.c_int32),
+                ("max_label_value", ctypes.c_int64),
+                ("have_prev", ctypes.c_int32), ("prev_chrom", ctypes.c_char_p), ("prev_strand", ctypes.c_int32), ("prev_start", ctypes.c_int64)]
+
+    @classmethod
+    def make(cls, names, strand_aware=False, sorted_rules=False, sorted_by_strand=False, max_label_value=1):
+        r = cls()
+        r._names = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])     # (kept alive with the object)
+        r.chrom_names = r._names; r.n_chrom = len(names)
+        r.strand_aware = int(strand_aware); r.sorted_rules = int(sorted_rules); r.sorted_by_strand = int(sorted_by_strand)
+        r.max_label_value = int(max_label_value); r.have_prev = 0; r.prev_chrom = None; r.prev_strand = ord("+"); r.prev_start = 0
+        return r
+
+
 # name -> (restype, argtypes); must list every symbol include/gtx.h declares
 ABI = {
     "gtx_version": (ctypes.c_int, []),
@@ -70,6 +87,14 @@ ABI = {
     "gtx_scan_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32,
                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_scan_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char, ctypes.c_uint32,
+                                      ctypes.c_int, ctypes.c_void_p]),
+    "gtx_scan_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]),
+    "gtx_scan_add_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "gtx_scan_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_group_count_add_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "gtx_group_coverage_add_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "gtx_group_text_result": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "gtx_group_create": (ctypes.c_void_p, [ctypes.c_int, ctypes.c_void_p]),
     "gtx_group_destroy": (None, [ctypes.c_void_p]),
     "gtx_group_size": (ctypes.c_int, [ctypes.c_void_p]),
@@ -281,6 +306,30 @@ class Engine:
         self._chk(self.lib.gtx_scan(self.ctx, _ptr(reads), _ptr(w), reads.shape[0], _ptr(cl), len(cl), int(win_step), int(win_size),
                                     preprocess.encode()[0:1], int(flags), _ptr(out), _ptr(off)))
         return out[:tot], off
+
+    def scan_stream(self, pieces, class_len, win_step, win_size, preprocess="1", weighted=False, flags=0):
+        """gtx_scan_begin .. gtx_scan_end over `pieces`: (reads, weights | None, flags) tuples for packed host batches, or (text bytes,
+        TextRules, flags) for blocks of BED text tokenised on the device.  Returns (windows, class offsets, label sum of the text blocks
+        the device took, tickets' needs_host verdicts)."""
+        cl = np.ascontiguousarray(class_len, dtype=np.int32)
+        off, tot = scan_layout(cl, win_step, win_size)
+        out = np.zeros(max(tot, 1), dtype=np.uint64)
+        self._chk(self.lib.gtx_scan_begin(self.ctx, _ptr(cl), len(cl), int(win_step), int(win_size), preprocess.encode()[0:1], int(flags), int(weighted), _ptr(off)))
+        verdicts = []
+        for a, b, fl in pieces:
+            if isinstance(a, (bytes, bytearray)):
+                t = ctypes.c_int(-1)
+                self._chk(self.lib.gtx_scan_add_text(self.ctx, a, len(a), a.count(b"\n"), ctypes.byref(b), int(fl), ctypes.byref(t)))
+                redo = ctypes.c_int(0)
+                self._chk(self.lib.gtx_text_result(self.ctx, t.value, ctypes.byref(redo)))
+                verdicts.append(redo.value)
+            else:
+                r = _triples(a)
+                w = None if b is None else np.ascontiguousarray(b, dtype=np.int32)
+                self._chk(self.lib.gtx_scan_add(self.ctx, _ptr(r), _ptr(w), r.shape[0], int(fl)))
+        labels = ctypes.c_int64(0)
+        self._chk(self.lib.gtx_scan_end(self.ctx, _ptr(out), ctypes.byref(labels)))
+        return out[:tot], off, int(labels.value), verdicts
 
     def scan_device(self, d_reads, n_reads, class_len, win_step, win_size, d_out, preprocess="1", d_weights=None, flags=0):
         cl = np.ascontiguousarray(class_len, dtype=np.int32)

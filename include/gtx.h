@@ -351,6 +351,26 @@ int gtx_count_add_text(gtx_ctx *ctx, const char *text, size_t bytes, int64_t n_l
 int gtx_coverage_add_text(gtx_ctx *ctx, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket);
 /* waits for the tokenizer of that block; *needs_host != 0: nothing of the block was counted, the caller packs and adds it */
 int gtx_text_result(gtx_ctx *ctx, int ticket, int *needs_host);
+/* The same in a group that holds all its members (between gtx_group_count_begin / gtx_group_coverage_begin and their _end): a block goes
+ * to the members in turn, whatever the classes of its lines -- the read stream split evenly over members that each hold the whole
+ * reference set (SURVEY 8(e)'s second partition) -- and a count call that took text blocks ends with the ncclReduce(sum) of the
+ * members' full vectors instead of pieces.  Blocks that come back (needs_host) are packed by the caller and go through gtx_group_*_add. */
+int gtx_group_count_add_text(gtx_group *g, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket);
+int gtx_group_coverage_add_text(gtx_group *g, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket);
+int gtx_group_text_result(gtx_group *g, int ticket, int *needs_host);
+
+/* genomic_scans counts fed as a stream (UnsortedGenomicRegionSetScanner ctor genomic_intervals.cpp:5019-5080, sorted scanner :4928-4957):
+ * gtx_scan_begin fixes the geometry (arguments as gtx_scan; flags: GTX_ZERO_LENGTH_OK = the sorted scanner's rule; weighted != 0: every
+ * batch brings label weights), gtx_scan_add adds packed reads from host memory (flags: GTX_READS_UNSORTED as a hint), gtx_scan_add_text a
+ * block of BED text tokenised on the device (rules as for the overlap calls; lines the device does not take come back through
+ * gtx_text_result and are packed by the caller), gtx_scan_end writes the windows (layout of gtx_scan) and, when label_sum is not NULL,
+ * the sum of the label values of all lines of the text blocks that did NOT come back (CountGenomicRegions, :6206-6214: peaks' read
+ * total).  The micro-window histogram accumulates over the batches; a caller with every read in hand uses gtx_scan / gtx_scan_device. */
+int gtx_scan_begin(gtx_ctx *ctx, const int32_t *class_len, int32_t n_classes, int32_t win_step, int32_t win_size, char preprocess,
+                   uint32_t flags, int weighted, const int64_t *class_offsets);
+int gtx_scan_add(gtx_ctx *ctx, const int32_t *read_triples, const int32_t *weights, int64_t n_reads, uint32_t flags);
+int gtx_scan_add_text(gtx_ctx *ctx, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket);
+int gtx_scan_end(gtx_ctx *ctx, uint64_t *windows_out, int64_t *label_sum);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 

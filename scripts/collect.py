@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Copy the outputs of scripts/r02_refresh.sh (gpurun_out/refresh_r02/) into profiles/r02_* and build the PMC summaries.
+"""Copy the outputs of scripts/refresh.sh <tag> (gpurun_out/refresh_<tag>/) into profiles/<tag>_* and build the PMC summaries.
 FETCH_SIZE is in KB and is doubled for gfx950 as MI355X_MICROARCH.md prescribes (128-B requests tallied at 64 B); WRITE_SIZE as is."""
 import collections, csv, glob, hashlib, json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
-src = R + "gpurun_out/refresh_r02/"
-rnd = "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+src = R + "gpurun_out/refresh_%s/" % rnd
 
 
 def newest(pattern):
@@ -19,17 +19,22 @@ def sha16(files=("gtx_kernels.hip", "gtx_kernels.h", "gtx_capi.hip")):
     return h.hexdigest()[:16]
 
 
-for a in ("bench_line", "bench_scans_line", "bench_perm_line", "bench_c5_line", "bench_line_under_rocprof"):
+for a in ("bench_line", "bench_scans_line", "bench_perm_line", "bench_c5_line", "bench_line_under_rocprof", "bench_rehearse4_line", "bench_selftest_line", "bench_fallback2_line"):
     if os.path.exists(src + a + ".json") and os.path.getsize(src + a + ".json"):
         shutil.copy(src + a + ".json", R + "profiles/%s_%s.json" % (rnd, a))
 for tag, name in (("stats", "bench"), ("stats_scans", "bench_scans"), ("stats_perm", "bench_perm"), ("stats_c5", "c5_bench"), ("stats_bucket", "bucket"), ("stats_covshuf", "cov_shuffled"),
-                  ("stats_cov", "coverage"), ("stats_scanfine", "scan_geometries")):
+                  ("stats_cov", "coverage"), ("stats_scanfine", "scan_geometries"), ("stats_share", "share_member"), ("stats_pairs", "pairs")):
     f = newest(src + tag + "/*/*kernel_stats.csv")
     if f:
         shutil.copy(f, R + "profiles/%s_%s_kernel_stats.csv" % (rnd, name))
-for log in ("bench_bucket.log", "bench_cov.log", "bench_scan.log", "bench_covshuf.log", "bench_scanshuf.log"):
+for t in ("share_timing.txt", "share_timing_1g.txt", "share_streams.txt", "membench_100m.txt", "membench_1g.txt", "ab_sched.txt"):
+    if os.path.exists(src + t):
+        shutil.copy(src + t, R + "profiles/%s_%s" % (rnd, t))
+if os.path.exists(src + "wave_trace.txt"):
+    open(R + "profiles/%s_wave_trace.txt" % rnd, "w").write("".join(l for l in open(src + "wave_trace.txt") if l.startswith(("{", "alive", "streaming"))))
+for log in ("bench_bucket.log", "bench_cov.log", "bench_scan.log", "bench_covshuf.log", "bench_scanshuf.log", "bench_pairs.log"):
     if os.path.exists(src + log):
-        keep = [l for l in open(src + log) if ("bucket path" in l or "coverage:" in l or "coverage, " in l or "scan -w" in l or "bit-equal" in l)]
+        keep = [l for l in open(src + log) if ("bucket path" in l or "coverage:" in l or "coverage, " in l or "scan -w" in l or "bit-equal" in l or "per call" in l or "gtx_set_ref_blocks" in l or "gtx_count_add_regions" in l)]
         open(R + "profiles/%s_%s.txt" % (rnd, log[:-4]), "w").write("".join(keep))
 
 
@@ -55,7 +60,7 @@ def pmc_json(path, kernel, match, fetch, write, extra, alg, note):
     if "FETCH_SIZE" not in c:
         print("no counters for", kernel); return
     fb = c["FETCH_SIZE"] * 1024 * 2; wb = c.get("WRITE_SIZE", 0.0) * 1024
-    d = {"kernel": kernel, "command": "scripts/r02_refresh.sh (rocprofv3 --kernel-trace --pmc <counter>, one counter set per run)",
+    d = {"kernel": kernel, "command": "scripts/refresh.sh %s pmc (rocprofv3 --kernel-trace --pmc <counter>, one counter set per run)" % rnd,
          "kernel_source_sha16": sha16(), "counters_mean_per_dispatch": c, "dispatches": n,
          "fetch_bytes_corrected": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
          "correction": "gfx950: FETCH_SIZE (KB) tallies 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE (KB) as is",

@@ -1,3 +1,3 @@
-for rep in 1 2; do for mx in 512 4096; do
-echo "chain max $mx: $(GTX_CHAIN_MAX_TILES=$mx python bench.py --steps 40 --warmup 5 --no-e2e --cpu-sample 0 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(d["ms_per_step"], d["roofline"]["kernel_ms"])')"
-done; done
+mkdir -p gpurun_out/r04
+python -m pytest tests/test_gpu_cli.py -x -q -k "text_on_device" > gpurun_out/r04/cli_default.txt 2>&1; tail -n 12 gpurun_out/r04/cli_default.txt
+GTX_TEXT_ON_DEVICE=1 python -m pytest tests/test_gpu_cli.py tests/test_gpu_group.py -x -q > gpurun_out/r04/cli_text_forced.txt 2>&1; tail -n 12 gpurun_out/r04/cli_text_forced.txt

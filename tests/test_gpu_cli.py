@@ -829,3 +829,85 @@ def test_text_on_device_odd_lines_go_back_to_the_host(text_beds, name):
             assert nums is not None and nums[1] >= 1, (args, nums)                    # the odd line's block did come back (odd under either algorithm's rules)
         if name in ("three_cols.bed", "label_text.bed", "no_final_newline.bed") and want[0] == 0:
             assert nums is not None and nums[1] == 0, (args, nums)                    # plain after all: a 3-column line, a label atol reads, a dropped tail
+
+
+def _run_text(tool, args, cwd, stdin=None, block_mb=1, extra_env=None):
+    env = dict(os.environ, GTX_TEXT_ON_DEVICE="1", GTX_TEXT_TRACE="1", GTX_PACK_BLOCK_MB=str(block_mb))
+    env.update(extra_env or {})
+    r = subprocess.run([TOOLS[tool]] + list(args), capture_output=True, cwd=cwd, env=env, input=stdin)
+    lines = r.stderr.decode().split("\n")
+    trace = [l for l in lines if l.startswith("[gtx text]")]
+    nums = [int(x) for x in __import__("re").findall(r": (\d+)", trace[0])] if trace else None
+    return r.returncode, r.stdout.decode(), "\n".join(l for l in lines if not l.startswith("[gtx text]")), nums
+
+
+@pytest.mark.parametrize("mode", [["count", "-S", "-i"], ["count", "-i", "--max-label-value", "5"], ["coverage", "-S", "-i"], ["density", "-i"]],
+                         ids=lambda m: " ".join(m))
+def test_text_on_device_from_a_pipe_and_from_gz(text_beds, mode):
+    """The inputs the reference's examples use (examples/example01.tcsh:15: `cat reads | genomic_overlaps density -v exons.bed`; every
+    shipped data file is .gz): stdin and a gzip file are read block by block like a regular file -- straight reads, or inflate, into
+    the page-locked buffers -- and tokenised on the device; output = the oracle CLI's on the plain file."""
+    import gzip
+    want = oracle(mode + ["refs.bed", "plain.bed"], cwd=text_beds)
+    text = (text_beds / "plain.bed").read_bytes()
+    rc, out, err, nums = _run_text("overlaps", mode + ["refs.bed"], text_beds, stdin=text)
+    assert (rc, out) == (want[0], want[1]), err
+    assert nums is not None and nums[0] >= 5 and nums[1] == 0 and nums[2] == 0, nums
+    gz = text_beds / "plain.bed.gz"
+    if not gz.exists():
+        gz.write_bytes(gzip.compress(text, 1))
+    rc, out, err, nums = _run_text("overlaps", mode + ["refs.bed", "plain.bed.gz"], text_beds)
+    assert (rc, out) == (want[0], want[1]), err
+    assert nums is not None and nums[0] >= 5 and nums[1] == 0 and nums[2] == 0, nums
+    # a pipe whose last line has no newline (dropped, core.cpp:243) and one with an odd line in the middle (that block back to the host)
+    rc, out, err, nums = _run_text("overlaps", mode + ["refs.bed"], text_beds, stdin=text[:-1])
+    want2 = oracle(mode + ["refs.bed", "no_final_newline.bed"], cwd=text_beds)
+    assert (rc, out) == (want2[0], want2[1]), err
+    rc, out, err, nums = _run_text("overlaps", mode + ["refs.bed"], text_beds, stdin=(text_beds / "spaces.bed").read_bytes())
+    want3 = oracle(mode + ["refs.bed", "spaces.bed"], cwd=text_beds)
+    assert (rc, out) == (want3[0], want3[1]) and nums[1] >= 1, (err, nums)
+
+
+SCAN_TEXT_RUNS = [["counts", "-i", "-w", "1000", "-d", "1000", "-min", "1"], ["counts", "-w", "500", "-d", "25", "-min", "2"],
+                  ["counts", "-S", "-i", "-w", "2000", "-d", "1000", "-min", "1"], ["counts", "-i", "-op", "c", "-w", "1000", "-d", "500", "-min", "1"],
+                  ["counts", "-i", "--max-label-value", "4", "-w", "1000", "-d", "1000", "-min", "1"]]
+
+
+@pytest.mark.parametrize("mode", SCAN_TEXT_RUNS, ids=lambda m: " ".join(m))
+def test_text_on_device_genomic_scans(text_beds, mode):
+    """genomic_scans counts fed as a stream (gtx_scan_begin .. gtx_scan_end), its input tokenised on the device: a plain file, a pipe,
+    and files with lines the scanners skip (start > stop, stop = 0, unknown chromosome) or the device hands back (spaces, \\r);
+    the sorted scanner's order error comes from the host packer with the reference's text."""
+    (text_beds / "genome.bed").write_text("chr1\t0\t2100000\nchr10\t0\t2100000\nchr2\t0\t1500000\nchrX\t0\t2100000\n")
+    g = ["-g", "genome.bed"]
+    for name in ("plain.bed", "inverted.bed", "zero_stop.bed", "unknown_chrom.bed", "spaces.bed", "crlf.bed", "disorder.bed"):
+        if "-S" in mode and name in ("unknown_chrom.bed",):
+            continue                                                         # (chr1_random lines break the order: covered by disorder.bed)
+        want = oracle(mode + g + [name], cwd=text_beds)
+        rc, out, err, nums = _run_text("scans", mode + g + [name], text_beds)
+        assert rc == want[0], (name, err, want[2])
+        if want[0] != 0:
+            # (the sorted scanner streams: the reference has printed the windows in front of the offending line by the time it exits;
+            # this build scans before it prints -- same exit code and message, no partial output: DESIGN.md, known limits)
+            assert err.strip() == want[2].strip(), name
+            continue
+        assert out == want[1], name
+        if name in ("plain.bed", "inverted.bed", "zero_stop.bed") and "-S" not in mode:
+            assert nums is not None and nums[0] >= 5 and nums[1] == 0, (name, nums)
+    want = oracle(mode + g + ["plain.bed"], cwd=text_beds)
+    rc, out, err, nums = _run_text("scans", mode + g, text_beds, stdin=(text_beds / "plain.bed").read_bytes())
+    assert (rc, out) == (want[0], want[1]) and nums[0] >= 5, (err, nums)
+
+
+def test_text_on_device_several_gpus(text_beds):
+    """--ngpu 3 (rehearsed on one device): the blocks of the query file go to the members in turn (gtx_group_count_add_text), whatever
+    their chromosomes, a block with an odd line comes back and is routed by class like any packed batch, and the call ends with the
+    sum of the members' full vectors"""
+    for mode in (["count", "-S", "-i"], ["count", "-i", "--max-label-value", "5"], ["coverage", "-i"]):
+        for name in ("plain.bed", "spaces.bed", "shuffled.bed"):
+            if "-S" in mode and name == "shuffled.bed":
+                continue
+            want = oracle(mode + ["refs.bed", name], cwd=text_beds)
+            rc, out, err, nums = _run_text("overlaps", [mode[0], "--ngpu", "3"] + mode[1:] + ["refs.bed", name], text_beds, extra_env={"GTX_GROUP_REHEARSE": "1"})
+            assert (rc, out) == (want[0], want[1]), (mode, name, err)
+            assert nums is not None and nums[0] >= 3, (mode, name, nums)

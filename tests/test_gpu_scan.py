@@ -237,3 +237,46 @@ def test_config4_100m_reads_both_geometries(engine, monkeypatch):
         nw = gtx.load().gtx_scan_n_windows(int(synth.CHROM_LEN[c]), step, size)
         np.testing.assert_array_equal(a[off[c]:off[c] + nw].cpu().numpy().view(np.uint64), want[woff[c]:woff[c] + nw])
     engine.set_stream(0)
+
+
+def _bed_text(reads, names, strands=None, labels=None):
+    """packed triples (1-based inclusive) -> BED6 lines"""
+    out = []
+    for i, (c, s, e) in enumerate(reads):
+        out.append("%s\t%d\t%d\t%s\t0\t%s\n" % (names[c % len(names)], s - 1, e, "r" if labels is None else str(labels[i]),
+                                              "+" if strands is None else strands[i]))
+    return "".join(out).encode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("step,size,prep", [(1000, 1000, "1"), (25, 500, "1"), (1000, 2000, "c")])
+def test_scan_fed_as_a_stream(step, size, prep):
+    """gtx_scan_begin .. gtx_scan_end (what genomic_scans uses on one GPU): packed host batches -- one of them shuffled -- and blocks of
+    BED text tokenised on the device must add up to the all-at-once scan and to the oracle's; a text block with a line the device
+    does not take (a space-separated one) comes back whole and leaves nothing behind."""
+    rng = np.random.default_rng(17)
+    e = gtx.Engine(0)
+    a = synth.genome_intervals(300_000, 31, 50, 51); b = synth.genome_intervals(200_000, 32, 50, 300)
+    c = synth.genome_intervals(40_000, 33, 50, 51); d = synth.genome_intervals(30_000, 34, 50, 51)
+    b = b[rng.permutation(len(b))]
+    c[5, 1], c[5, 2] = 700, 600                                             # start > stop: the unsorted scanner skips it
+    names = synth.CHROM_NAMES
+    rules = gtx.TextRules.make(names)
+    odd = _bed_text(d, names).replace(b"\t", b" ", 5)                       # its first line is space-separated: not the device's case
+    pieces = [(a, None, 0), (b, None, gtx.READS_UNSORTED), (_bed_text(c, names), rules, 0), (odd, rules, 0)]
+    win, off, labels, verdicts = e.scan_stream(pieces, synth.CHROM_LEN, step, size, preprocess=prep)
+    assert verdicts == [0, 1] and labels == len(c)
+    allr = np.concatenate([a, b, c])
+    want, _ = orc.scan(allr, synth.CHROM_LEN, step, size, preprocess=prep)
+    np.testing.assert_array_equal(win, want)
+    once, _ = e.scan(allr, synth.CHROM_LEN, step, size, preprocess=prep)
+    np.testing.assert_array_equal(once, want)
+    # label weights: min(max, atol(column 4)) summed over every line the device takes, windows weighted
+    wl = rng.integers(0, 9, size=len(c))
+    rules_w = gtx.TextRules.make(names, max_label_value=5)
+    wa = rng.integers(0, 6, size=len(a)).astype(np.int32)
+    win, off, labels, verdicts = e.scan_stream([(a, wa, 0), (_bed_text(c, names, labels=wl), rules_w, 0)], synth.CHROM_LEN, step, size, preprocess=prep, weighted=True)
+    assert verdicts == [0] and labels == int(np.minimum(wl, 5).sum())
+    want, _ = orc.scan(np.concatenate([a, c]), synth.CHROM_LEN, step, size, preprocess=prep, weights=np.concatenate([wa, np.minimum(wl, 5).astype(np.int32)]))
+    np.testing.assert_array_equal(win, want)
+    e.close()
