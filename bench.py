@@ -198,7 +198,9 @@ def measure_text_to_stdout(n, m, cli_sample=None):
         dt, md = timed(ovl, stdin_from=qp)
         if md != res["output_md5"]:
             sys.exit("PARITY FAILURE: the CLI's output differs between a file and the same text on stdin")
-        res["stdin_pipe"] = {"seconds": dt, "reads_per_s": n / dt, "note": "cat reads.bed | genomic_overlaps count -S -i refs.bed"}
+        t0 = time.perf_counter(); subprocess.run("cat %s | wc -l > /dev/null" % qp, shell=True, check=True); pipe_alone = time.perf_counter() - t0
+        res["stdin_pipe"] = {"seconds": dt, "reads_per_s": n / dt, "cat_into_wc_l_alone_seconds": pipe_alone,
+                             "note": "cat reads.bed | genomic_overlaps count -S -i refs.bed; bound: the pipe -- what it delivers to any reader that touches the bytes (`cat reads.bed | wc -l` beside it) plus the process's start-up"}
         gz_lines = min(n, 20_000_000)
         gzp, gzs = os.path.join(tmp, "part.bed.gz"), os.path.join(tmp, "part.bed")
         made.extend([gzp, gzs])

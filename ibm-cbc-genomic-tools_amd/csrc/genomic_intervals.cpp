@@ -1449,6 +1449,35 @@ long int GenomicRegionSetScanner::Next()
   return -1;
 }
 
+void GenomicRegionSetScanner::PrintRemaining(FILE *out_file, long int min_value)
+{
+  if (!computed) Compute(false);
+  const int ns = ignore_strand ? 1 : 2;
+  std::vector<char> buf; buf.reserve(8u << 20);
+  auto put_num = [&](long int v) {
+    char tmp[24]; int n = 0;
+    unsigned long int u = v < 0 ? 0ul - (unsigned long int)v : (unsigned long int)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) buf.push_back('-');
+    while (n) buf.push_back(tmp[--n]);
+  };
+  for (; cur_block < n_windows.size(); cur_block++, cur_win = 0) {
+    const std::string &chrom = chrom_names[cur_block / ns];
+    const char strand = (cur_block % ns) ? '-' : '+';
+    for (; cur_win < n_windows[cur_block]; cur_win++) {
+      const long int v = (long int)values[(size_t)(block_offset[cur_block] + cur_win)];
+      if (v == -1) { cur_win++; goto done; }                      // (a caller's loop takes Next() == -1 for the end, whatever made the value)
+      if (v < min_value) continue;
+      put_num(v); buf.push_back('\t');
+      buf.insert(buf.end(), chrom.begin(), chrom.end()); buf.push_back(' '); buf.push_back(strand); buf.push_back(' ');
+      put_num(win_step * cur_win + 1); buf.push_back(' '); put_num(win_step * cur_win + win_size); buf.push_back('\n');
+      if (buf.size() > (7u << 20)) { fwrite(buf.data(), 1, buf.size(), out_file); buf.clear(); }
+    }
+  }
+done:
+  if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), out_file);
+}
+
 void GenomicRegionSetScanner::PrintInterval(FILE *out_file)
 {
   const int ns = ignore_strand ? 1 : 2;

@@ -263,6 +263,10 @@ class GenomicRegionSetScanner
   // MI355X path: sum of GetLabelValue(max_label_value) over every region of the input, collected by the same pass that
   // fills the windows -- what the reference gets from a separate read of the file (CountGenomicRegions, :6206-6214)
   long int TotalLabelValue();
+  // MI355X path: every remaining window with a value >= min_value as "value\tchr strand start stop\n" -- what a caller's
+  // Next() / PrintInterval() loop prints (genomic_scans.cpp:421-428), formatted in bulk (three stdio calls per window are half a
+  // second for the three million windows of a genome at -w 1000)
+  void PrintRemaining(FILE *out_file, long int min_value);
 
   GenomicRegionSet *R;
   StringLIntMap *bounds;

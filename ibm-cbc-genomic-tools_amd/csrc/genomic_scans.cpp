@@ -232,6 +232,8 @@ int main(int argc, char *argv[])
       RefIndex = new GenomicRegionSetIndex(RefRegSet, "17,20,23,26");
     }
   }
+  if (RefRegSet == NULL) scanner->PrintRemaining(stdout, (long int)MIN_READS);   // (no -r filter: the same lines, formatted in bulk)
+  else
   for (long int v = REF_SORTED ? scanner->Next(RefRegSet) : scanner->Next(RefIndex); v != -1; v = REF_SORTED ? scanner->Next(RefRegSet) : scanner->Next(RefIndex)) {
     if (v >= MIN_READS) {
       printf("%ld\t", v);

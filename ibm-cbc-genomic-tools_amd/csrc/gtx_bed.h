@@ -51,6 +51,8 @@ class LineSource {
   LineSource() {}
   size_t Fill();                     // read more raw bytes into buf_; 0 at EOF
   FILE *fp_ = nullptr; gzFile gz_ = nullptr; bool is_stdin_ = false;
+  int raw_fd_ = -1;                  // the process's stdin: read by descriptor (no stdio buffer in between)
+  size_t ReadStream(char *dst, size_t want);   // up to `want` bytes of a stream into dst (0: the end)
   int fd_ = -1; size_t file_len_ = 0, file_pos_ = 0;          // regular text file: bulk path uses pread on fd_
   bool bulk_started_ = false;
   std::vector<char> buf_;            // raw bytes [pos_, end_) not yet handed out
