@@ -681,16 +681,19 @@ def bench_count_group(args, rank, world, local, device, rehearse, force_dist):
                        "imbalance": max(reads_per_rank) / (sum(reads_per_rank) / n_members),
                        "parallelism": "%s scaling through the product's gtx_group (libgtx.so): one process per GPU = one member each "
                                       "(gtx_group_create_rank), chromosomes dealt to the %d members by LPT packing of their read counts, reference "
-                                      "set replicated; per step gtx_group_count_device: streaming kernel + finalize of the member's own classes, "
-                                      "pieces of the compact vector to member 0" % (args.scaling, n_members),
+                                      "set replicated; per step gtx_group_count_device: streaming kernel + finalize of the member's own classes on one of "
+                                      "three streams in turn (the kernels of successive steps are not ordered behind each other), the member's regions to member 0" % (args.scaling, n_members),
                        "reduce": ("one-GPU rehearsal of the group code (not a measurement)" if rehearse else
-                                  "grouped ncclSend/ncclRecv of each member's piece of the uint64 count vector to member 0 over xGMI, on a stream of "
-                                  "its own under the next step's kernels; member 0 restores file order") +
+                                  "grouped ncclSend/ncclRecv of each member's runs of the uint64 count vector (a run per chromosome: the reference file is in "
+                                  "chromosome order) straight to their places in member 0's result vector over xGMI, on a stream of its own under the "
+                                  "next steps' kernels; member 0's own regions are written there by its finalize step") +
                                  (" [single-rank self-test: the piece goes out and back through RCCL]" if force_dist else ""),
                        "verified": "before the timed steps: result on member 0 == sum over the ranks of gtx_count_device on each rank's own reads"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
-                         "kernel": "count_walk_kernel (member 0's launch over its %d reads)" % n0, "kernel_ms": k_ms,
+                         "kernel": "count_walk_kernel (member 0's launch over its %d reads; timed with the kernels of the neighbouring steps running "
+                                   "beside it on the other two streams, i.e. sharing the chip's bandwidth: the per-step time is what counts here, "
+                                   "the kernel's own roofline is the N = 1 line's)" % n0, "kernel_ms": k_ms,
                          "kernel_samples": len(kernel_ms), "algorithmic_bytes": 12.0 * n0},
             "cpu_baseline": None,
         })

@@ -382,9 +382,9 @@ static int ensure_plan(gtx_group *g)
       g->runs[mem].push_back({j, g->perm[j], e - j}); nRuns++;
       j = e;
     }
-  // (GTX_GROUP_DIRECT=0 keeps the compact vector; the test hook that sends member 0's own piece through RCCL works on it too)
+  // (GTX_GROUP_DIRECT=0 keeps the compact vector)
   const bool directOff = getenv("GTX_GROUP_DIRECT") && atoi(getenv("GTX_GROUP_DIRECT")) == 0;      // (read when a plan is made)
-  g->direct = !directOff && !g->selfExchange && nRuns <= 64 * (size_t)g->nm;
+  g->direct = !directOff && nRuns <= 64 * (size_t)g->nm;
   std::vector<uint8_t> owned(std::max<size_t>(g->owner.size(), 1));
   for (size_t li = 0; li < g->ctx.size(); li++) {
     const int mem = g->member((int)li);
@@ -463,6 +463,16 @@ static int gather_runs(gtx_group *g, const std::vector<void *> &piece, unsigned 
     return GTX_OK;
   }
   if (g->comm.empty()) return GTX_OK;
+  const bool self = g->selfExchange && l0 >= 0 && g->segOff[1] > g->segOff[0];
+  if (self) {                                              // test hook: member 0's own runs leave and come back through RCCL, like another member's
+    const int64_t len0 = g->segOff[1] - g->segOff[0];
+    GCHK_HIP(g, hipSetDevice(g->dev[l0]));
+    if ((size_t)len0 > g->capSelfTmp) { if (g->d_selfTmp) (void)hipFree(g->d_selfTmp); g->d_selfTmp = nullptr; GCHK_HIP(g, hipMalloc(&g->d_selfTmp, sizeof(uint64_t) * (size_t)len0)); g->capSelfTmp = (size_t)len0; }
+    for (const gtx_group::Run &run : g->runs[0]) {
+      GCHK_HIP(g, hipMemcpyAsync(g->d_selfTmp + (run.compact - g->segOff[0]), d_hits + run.file, sizeof(uint64_t) * (size_t)run.len, hipMemcpyDeviceToDevice, st[l0]));
+      GCHK_HIP(g, hipMemsetAsync(d_hits + run.file, 0xff, sizeof(uint64_t) * (size_t)run.len, st[l0]));
+    }
+  }
   GCHK_NCCL(g, g->rccl.GroupStart());
   ncclResult_t r = ncclSuccess;
   for (size_t li = 0; li < g->ctx.size() && r == ncclSuccess; li++) {
@@ -473,12 +483,19 @@ static int gather_runs(gtx_group *g, const std::vector<void *> &piece, unsigned 
       r = g->rccl.Send((const unsigned long long *)piece[li] + (run.compact - g->segOff[mem]), (size_t)run.len, ncclUint64, 0, g->comm[li], st[li]);
     }
   }
-  if (l0 >= 0)
+  if (l0 >= 0) {
     for (int mem = 1; mem < g->nm && r == ncclSuccess; mem++)
       for (const gtx_group::Run &run : g->runs[mem]) {
         if (r != ncclSuccess) break;
         r = g->rccl.Recv(d_hits + run.file, (size_t)run.len, ncclUint64, mem, g->comm[l0], st[l0]);
       }
+    if (self)
+      for (const gtx_group::Run &run : g->runs[0]) {
+        if (r != ncclSuccess) break;
+        r = g->rccl.Send(g->d_selfTmp + (run.compact - g->segOff[0]), (size_t)run.len, ncclUint64, 0, g->comm[l0], st[l0]);
+        if (r == ncclSuccess) r = g->rccl.Recv(d_hits + run.file, (size_t)run.len, ncclUint64, 0, g->comm[l0], st[l0]);
+      }
+  }
   if (r != ncclSuccess) { g->rccl.GroupEnd(); g->err = std::string("ncclSend/ncclRecv: ") + g->rccl.GetErrorString(r); return GTX_E_HIP; }
   GCHK_NCCL(g, g->rccl.GroupEnd());
   return GTX_OK;
@@ -559,7 +576,7 @@ int gtx_group_count_device(gtx_group *g, const void *const *d_reads, const void 
     // rehearsal), and on member 0 the reordering of the compact vector.  Otherwise (member 0 in direct mode; a rank without a
     // communicator: the measurement mode GTX_GROUP_NO_EXCHANGE) the exchange stream stays out of it.
     const bool sends = mem != 0 && (!g->comm.empty() || g->rehearse);
-    onXs[li] = direct ? sends : (mem == 0 || sends);
+    onXs[li] = direct ? (sends || (mem == 0 && g->selfExchange && !g->comm.empty())) : (mem == 0 || sends);
     // Reads in stream order: kernel and finalize step go to one of the group's streams of this member in turn, histogram set with
     // the stream (GTX_GROUP_PIPELINE=0: always the first stream -- every call behind the one before, for A/B runs).  The stream
     // waits for the caller's stream as it stands now (the reads are resident behind it) and for the exchange that last read the

@@ -304,11 +304,12 @@ def test_no_class_count_given_spreads_the_members():
     g.close()
 
 
-def _through_rccl(make_group):
+def _through_rccl(make_group, class_order=False):
     import torch
     g = make_group()
     refs = synth.genome_intervals(30_000, 101, 50, 2000)
-    refs = refs[np.random.default_rng(2).permutation(len(refs))]
+    if not class_order:                                           # (file order != class order: the compact vector; class order: run by run into the caller's vector)
+        refs = refs[np.random.default_rng(2).permutation(len(refs))]
     reads = synth.genome_intervals(400_000, 102, 50, 51)
     g.set_refs(refs, synth.n_classes())
     dev = torch.from_numpy(reads).cuda()
@@ -332,6 +333,9 @@ def test_pieces_travel_through_ncclsend_ncclrecv():
         uid = gtx.Group.unique_id()
         assert len(uid) == gtx.GROUP_ID_BYTES
         _through_rccl(lambda: gtx.Group(rank=0, world=1, device=0, unique_id=uid))
+        # a reference file in class order: the member's 24 runs leave and come back one by one, each to its place in the caller's vector
+        _through_rccl(lambda: gtx.Group([0]), class_order=True)
+        _through_rccl(lambda: gtx.Group(rank=0, world=1, device=0, unique_id=gtx.Group.unique_id()), class_order=True)
     finally:
         del os.environ["GTX_GROUP_SELF_EXCHANGE"]
 
