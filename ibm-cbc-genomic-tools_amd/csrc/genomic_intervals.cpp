@@ -663,8 +663,11 @@ static bool TextOnDevice(GenomicRegionSet *set, const PackOptions &opt, const Te
   return left < 0 || left >= ((e && atoi(e) == 1) ? 1 : (32l << 20));
 }
 
+// on_error (may be empty): called with the packer's error instead of dying with it, after the batch in hand -- which, under
+// PackOptions::keep_prefix_on_error, holds the regions of the lines in front of the offending one -- has gone to `sink`; nothing more is packed
 template <class Prep, class Sink>
-static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sink, const TextSink *text_sink = NULL)
+static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sink, const TextSink *text_sink = NULL,
+                     const std::function<void(const PackError &)> &on_error = std::function<void(const PackError &)>())
 {
   g_drain_stop = false;
   const size_t batch_reads = kBatchReads;
@@ -681,8 +684,9 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
     g_pool.used[0] = g_pool.used[1] = true;                      // (the buffers hold text now: a batch packed here takes heap memory)
     packer.UseTextBuffers((char *)g_pool.buf[0], (char *)g_pool.buf[1], kPoolBytes);
     PackedBatch batch;
-    if (!packer.PackPrimedText(&batch, &err)) DiePack(err);
+    if (!packer.PackPrimedText(&batch, &err) && !on_error) DiePack(err);
     if (!batch.empty()) sink(batch);
+    if (err.set) { on_error(err); g_drain_stop = true; g_pool.used[0] = g_pool.used[1] = false; return; }
     BedPacker::TextBlock blk[2]; int ticket[2] = {-1, -1}; bool host_only = false, first_block = true;
     static const bool text_forced = getenv("GTX_TEXT_ON_DEVICE") && atoi(getenv("GTX_TEXT_ON_DEVICE")) == 1;
     long on_device = 0, redone = 0, host_blocks = 0;
@@ -694,9 +698,10 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       redone++;
       batch.clear();
       const bool ok = packer.PackTextBlock(blk[k], &batch, &err);
-      if (err.set) DiePack(err);
+      if (err.set && !on_error) DiePack(err);
       (void)ok;
       if (!batch.empty()) sink(batch);
+      if (err.set) { on_error(err); g_drain_stop = true; }
     };
     for (int cur = 0;; cur ^= 1) {
       settle(cur);                                               // (its buffer is about to be read over)
@@ -710,12 +715,14 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
         host_blocks++;
         batch.clear();
         packer.PackTextBlock(b, &batch, &err);
-        if (err.set) { settle(cur ^ 1); DiePack(err); }
+        if (err.set && !on_error) { settle(cur ^ 1); DiePack(err); }
         if (!batch.empty()) sink(batch);
+        if (err.set) { on_error(err); g_drain_stop = true; break; }
         continue;
       }
       rules.have_prev = b.have_prev; rules.prev_chrom = b.prev_chrom.c_str(); rules.prev_strand = b.prev_strand; rules.prev_start = b.prev_start;
       ticket[cur] = text_sink->add(b.text, b.bytes, b.n_lines, rules);
+      if (on_error) settle(cur);                                 // (a caller that goes on after an error wants nothing behind the offending line counted: one block at a time)
     }
     settle(0); settle(1);
     if (getenv("GTX_TEXT_TRACE")) fprintf(stderr, "[gtx text] blocks tokenised on the device: %ld, sent back to the host packer: %ld, packed on the host from the start: %ld\n", on_device, redone, host_blocks);
@@ -728,12 +735,13 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       PackedBatch &batch = two[cur];
       bool more = packer.NextBatch(&batch, batch_reads, &err);
       if (g_drain_stop) break;
-      if (err.set) DiePack(err);
+      if (err.set && !on_error) DiePack(err);
       if (!batch.empty()) {
         const auto t0 = std::chrono::steady_clock::now();
         sink(batch); cur ^= 1;
         if (getenv("GTX_PACK_TRACE")) fprintf(stderr, "[sink] %zu reads handed over in %.1f ms\n", batch.tri.size() / 3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       }
+      if (err.set) { on_error(err); break; }
       if (!more) break;
     }
   };
@@ -1343,6 +1351,7 @@ GenomicRegionSetScanner::GenomicRegionSetScanner(GenomicRegionSet *R, StringLInt
   if (win_step <= 0 || win_size % win_step != 0) { std::cerr << "Error: window size must be a multiple of window step in 'GenomicRegionSetScanner'!\n"; exit(1); }
   n_win_combine = win_size / win_step;
   cur_block = 0; cur_win = 0; computed = false; total_label_value = 0;
+  halt_set = false; halt_block = 0; halt_win = 0; halt_line = 0; halt_no_prefix = false;
 }
 
 GenomicRegionSetScanner::~GenomicRegionSetScanner() {}
@@ -1379,6 +1388,10 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
   opt.mode = sorted_rules ? gtxhost::PACK_SCAN_SORTED : gtxhost::PACK_SCAN_UNSORTED;
   opt.chroms = &chroms; opt.strand_aware = !ignore_strand; opt.sorted_by_strand = !ignore_strand;
   opt.max_label_value = max_label_value;
+  opt.keep_prefix_on_error = sorted_rules;
+  PackError input_error;                                           // sorted rules: met where the reference's walk meets it (below), not here
+  std::function<void(const PackError &)> on_error;
+  if (sorted_rules) on_error = [&](const PackError &e) { input_error = e; };
   std::vector<int32_t> tri, w;
   bool bad_preprocess = false;                                     // raised at the first region that is processed, like the reference
   const bool preprocess_ok = sorted_rules ? preprocess == '1' : (preprocess == '1' || preprocess == 'c');
@@ -1411,7 +1424,33 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
     if (one) { check_one(gtx_scan_add(one, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), LooksSorted(b.tri) ? 0u : GTX_READS_UNSORTED)); return; }
     tri.insert(tri.end(), b.tri.begin(), b.tri.end());
     w.insert(w.end(), b.w.begin(), b.w.end());
-  }, &text_sink);
+  }, &text_sink, on_error);
+  if (input_error.set && !bad_preprocess) {
+    // Where does the reference's walk fetch the offending line?  When it consumes the region in front of it (R->Next, :4944 / :4936):
+    // inside that region's block at the micro-window its start falls into -- the windows whose last micro-window lies before that
+    // one are out by then --, or, for a region no block takes (a chromosome without bounds, a start behind the last micro-window),
+    // by the skip loop at the head of the first block behind it (:4934); a region behind every block is never consumed, and neither
+    // is the line behind it met.  No region in front of the line: the constructor's first read meets it (:4882).
+    const long int comb = win_size / win_step;
+    halt_set = true; halt_block = 0; halt_win = 0;
+    halt_line = input_error.line; halt_no_prefix = input_error.no_prefix; halt_msg = input_error.msg;
+    if (input_error.have_last) {
+      const size_t ci = (size_t)(std::lower_bound(chrom_names.begin(), chrom_names.end(), input_error.last_chrom) - chrom_names.begin());
+      const bool known = ci < chrom_names.size() && chrom_names[ci] == input_error.last_chrom;
+      size_t at_head_of = ci * (size_t)ns;                         // unknown chromosome: skipped at the head of the first block of a later one
+      if (known) {
+        const size_t B = ci * (size_t)ns + ((!ignore_strand && input_error.last_strand == '-') ? 1 : 0);
+        const long int n_mw = std::max<long int>(0, (*bounds)[chrom_names[ci]]) / win_step;
+        const long int k = input_error.last_start <= 0 ? 1 : (input_error.last_start + win_step - 1) / win_step;
+        if (k <= n_mw) { halt_block = B; halt_win = std::max<long int>(0, std::min<long int>(k - comb, n_windows[B])); at_head_of = (size_t)-1; }
+        else at_head_of = B + 1;
+      }
+      if (at_head_of != (size_t)-1) {
+        if (at_head_of < n_windows.size()) { halt_block = at_head_of; halt_win = 0; }
+        else halt_set = false;                                     // never consumed: the walk ends without meeting the line
+      }
+    }
+  }
   if (bad_preprocess && sorted_rules) { fprintf(stderr, "Error: [SortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
   if (bad_preprocess) { fprintf(stderr, "Error: [UnsortedGenomicRegionSetScanner] preprocess operator '%c' not supported!\n", preprocess); exit(1); }
   if (!grp) device_side();                                         // (an in-memory input: DrainSet has not run the hand-over's first step)
@@ -1439,13 +1478,22 @@ unsigned long int CalcBoundSize(StringLIntMap *bounds)
   return y;
 }
 
+void GenomicRegionSetScanner::RaiseHalt()
+{
+  PackError e; e.set = true; e.line = halt_line; e.no_prefix = halt_no_prefix; e.msg = halt_msg;
+  fflush(stdout);
+  DiePack(e);
+}
+
 long int GenomicRegionSetScanner::Next()
 {
   if (!computed) Compute(false);
   while (cur_block < n_windows.size()) {
+    if (halt_set && (cur_block > halt_block || (cur_block == halt_block && cur_win >= halt_win))) RaiseHalt();
     if (cur_win < n_windows[cur_block]) { cur_win++; return (long int)values[(size_t)(block_offset[cur_block] + cur_win - 1)]; }
     cur_block++; cur_win = 0;
   }
+  if (halt_set) RaiseHalt();
   return -1;
 }
 
@@ -1465,6 +1513,7 @@ void GenomicRegionSetScanner::PrintRemaining(FILE *out_file, long int min_value)
     const std::string &chrom = chrom_names[cur_block / ns];
     const char strand = (cur_block % ns) ? '-' : '+';
     for (; cur_win < n_windows[cur_block]; cur_win++) {
+      if (halt_set && (cur_block > halt_block || (cur_block == halt_block && cur_win >= halt_win))) goto done;
       const long int v = (long int)values[(size_t)(block_offset[cur_block] + cur_win)];
       if (v == -1) { cur_win++; goto done; }                      // (a caller's loop takes Next() == -1 for the end, whatever made the value)
       if (v < min_value) continue;
@@ -1476,6 +1525,7 @@ void GenomicRegionSetScanner::PrintRemaining(FILE *out_file, long int min_value)
   }
 done:
   if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), out_file);
+  if (halt_set && (cur_block >= n_windows.size() || cur_block > halt_block || (cur_block == halt_block && cur_win >= halt_win))) { fflush(out_file); RaiseHalt(); }
 }
 
 void GenomicRegionSetScanner::PrintInterval(FILE *out_file)

@@ -284,6 +284,11 @@ class GenomicRegionSetScanner
   long int cur_win;                                               // 1-based inside the block
   bool computed;
   long int total_label_value;
+  // the sorted scanner streams: an error in its input is met when the region in front of the offending line is consumed, with the
+  // windows before that point already handed out (genomic_intervals.cpp:4928-4957).  Compute() scans the regions in front of the
+  // line and notes where the walk stops: all windows of the blocks before halt_block, halt_win windows of that block, then the error.
+  bool halt_set; size_t halt_block; long int halt_win; long int halt_line; bool halt_no_prefix; std::string halt_msg;
+  void RaiseHalt();
 };
 
 class SortedGenomicRegionSetScanner : public GenomicRegionSetScanner

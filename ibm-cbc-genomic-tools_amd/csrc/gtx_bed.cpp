@@ -907,7 +907,36 @@ bool BedPacker::PackPieces(void *pieces_ptr, long first_line, PackedBatch *out, 
         SortsBefore(p.first_chrom.c_str(), p.first_strand, p.first_start, prev_chrom_.c_str(), prev_strand_, prev_start_, opt_.sorted_by_strand)) {
       if (!p.err.set || p.err.line > p.first_region_line) { p.err = PackError(); SetErr(&p.err, p.first_region_line, NotSortedMsg(opt_)); }
     }
-    if (p.err.set) { *err = p.err; if (direct) { out->tri.resize(base_tri); out->w.resize(base_w); } return false; }
+    if (p.err.set) {
+      *err = p.err;
+      if (!opt_.keep_prefix_on_error) { if (direct) { out->tri.resize(base_tri); out->w.resize(base_w); } return false; }
+      // the regions in front of the offending line stay: the pieces before this one, and what this piece had parsed when it met the
+      // line (nothing of it when the line is its first region: the order error of a seam)
+      const bool own = p.any && p.err.line > p.first_region_line;     // (p.any: a region of this piece came before the error)
+      if (own) { have_prev_ = true; prev_chrom_ = p.prev_chrom ? std::string(p.prev_chrom, p.prev_chrom_len) : p.last_chrom; prev_strand_ = p.last_strand; prev_start_ = p.last_start; }
+      err->have_last = have_prev_; err->last_chrom = prev_chrom_; err->last_strand = prev_strand_; err->last_start = prev_start_;
+      const int keep = own ? t + 1 : t;
+      if (direct) {
+        size_t wpos = 0;
+        for (int q = 0; q < keep; q++) {
+          if (pieces[q].nd && out->tri.data() + base_tri + 3 * wpos != pieces[q].dtri) {
+            memmove(out->tri.data() + base_tri + 3 * wpos, pieces[q].dtri, pieces[q].nd * 3 * sizeof(int32_t));
+            if (weighted) memmove(out->w.data() + base_w + wpos, pieces[q].dw, pieces[q].nd * sizeof(int32_t));
+          }
+          wpos += pieces[q].nd;
+        }
+        out->tri.resize(base_tri + 3 * wpos);
+        if (weighted) out->w.resize(base_w + wpos);
+      } else {
+        for (int pass = 0; pass < 2; pass++)
+          for (int q = 0; q < keep; q++) {
+            const std::vector<int32_t> &tr = pass ? pieces[q].tri_minus : pieces[q].tri, &ww = pass ? pieces[q].w_minus : pieces[q].w;
+            out->tri.insert(out->tri.end(), tr.begin(), tr.end()); out->w.insert(out->w.end(), ww.begin(), ww.end());
+          }
+      }
+      for (int q = 0; q < keep; q++) out->label_sum += pieces[q].label_sum;
+      return false;
+    }
     if (sorted_mode && p.any) { have_prev_ = true; prev_chrom_ = p.last_chrom; prev_strand_ = p.last_strand; prev_start_ = p.last_start; }
   }
   if (direct) {

@@ -151,6 +151,8 @@ struct PackOptions {
                                      // intervals goes out on its own list (PackedBatch::m_*), after the same checks as any other region
   int threads = 0;                   // 0 = hardware concurrency
   IndexGuard *guard = nullptr;       // PACK_OVERLAPS_SORTED with an out-of-order index set (forces one thread)
+  bool keep_prefix_on_error = false; // an error leaves the regions of the lines in front of it in the batch (the sorted scanner streams: what it
+                                     // has counted by then is on its way out, genomic_intervals.cpp:4928-4957) and names the last of them in PackError
 };
 
 struct PackError {
@@ -158,6 +160,8 @@ struct PackError {
   long line = 0;                     // file line number of the offending line
   bool no_prefix = false;            // message is printed as is (no "Error: Line N: " in front)
   std::string msg;                   // what the reference prints after "Error: Line N: "
+  // keep_prefix_on_error: the last region in front of the offending line (order key), if there is one
+  bool have_last = false; std::string last_chrom; char last_strand = '+'; long last_start = 0;
 };
 
 // Where the big batch arrays live.  By default ordinary heap memory; the GPU-side host code installs a pool of page-locked

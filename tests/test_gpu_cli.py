@@ -886,13 +886,12 @@ def test_text_on_device_genomic_scans(text_beds, mode):
         want = oracle(mode + g + [name], cwd=text_beds)
         rc, out, err, nums = _run_text("scans", mode + g + [name], text_beds)
         assert rc == want[0], (name, err, want[2])
-        if want[0] != 0:
-            # (the sorted scanner streams: the reference has printed the windows in front of the offending line by the time it exits;
-            # this build scans before it prints -- same exit code and message, no partial output: DESIGN.md, known limits)
-            assert err.strip() == want[2].strip(), name
-            continue
+        # (the sorted scanner streams: by the time it meets an offending line the reference has printed the windows in front of the
+        # region before that line -- the same bytes here, then the same message and exit code)
         assert out == want[1], name
-        if name in ("plain.bed", "inverted.bed", "zero_stop.bed") and "-S" not in mode:
+        if want[0] != 0:
+            assert err.strip() == want[2].strip(), name
+        elif name in ("plain.bed", "inverted.bed", "zero_stop.bed") and "-S" not in mode:
             assert nums is not None and nums[0] >= 5 and nums[1] == 0, (name, nums)
     want = oracle(mode + g + ["plain.bed"], cwd=text_beds)
     rc, out, err, nums = _run_text("scans", mode + g, text_beds, stdin=(text_beds / "plain.bed").read_bytes())
@@ -911,3 +910,33 @@ def test_text_on_device_several_gpus(text_beds):
             rc, out, err, nums = _run_text("overlaps", [mode[0], "--ngpu", "3"] + mode[1:] + ["refs.bed", name], text_beds, extra_env={"GTX_GROUP_REHEARSE": "1"})
             assert (rc, out) == (want[0], want[1]), (mode, name, err)
             assert nums is not None and nums[0] >= 3, (mode, name, nums)
+
+
+SORTED_SCAN_ERRORS = [
+    ("late_disorder", lambda v: v.__setitem__(150_000, "chr1\t1999999\t2000100\tlate\t0\t+")),             # out of order in the middle of chr10
+    ("first_line_bad", lambda v: v.__setitem__(0, "chr1\t100\t200\tx\t0\tq")),                              # the constructor's first read meets it: nothing printed
+    ("second_line_bad", lambda v: v.__setitem__(1, "chr1\t100")),                                            # met when the first region is consumed
+    ("bad_strand_late", lambda v: v.__setitem__(199_990, "\t".join(v[199_990].split("\t")[:5] + ["x"]))),     # on chrX, near the end
+    ("behind_the_bounds", lambda v: v.extend(["chrX\t2100500\t2100600\tedge\t0\t+", "chrX\t5\t10\tback\t0\t+"])),   # the region before the bad line starts behind chrX's last micro-window: the head of no later block consumes it
+    ("unknown_chrom_then_bad", lambda v: (v.__setitem__(100_000, "chr1_zzz\t5\t10\tu\t0\t+"), v.__setitem__(100_001, "chr2\t1\t2\tb\t0\tq"))),   # the region before the bad line has no bounds: the skip loop at the head of chr2's block consumes it
+]
+
+
+@pytest.mark.parametrize("name,edit", SORTED_SCAN_ERRORS, ids=[n for n, _ in SORTED_SCAN_ERRORS])
+def test_sorted_scanner_meets_errors_where_the_reference_does(text_beds, name, edit):
+    """genomic_scans counts -S streams in the reference: an error of the input is met when the region in FRONT of the offending line is
+    consumed, with the windows before that point already printed -- or never, when that region lies behind every block.  Output up to
+    the error, the message and the exit code must be the oracle CLI's, from the host packer and from the device tokenizer alike, with
+    and without strands, at two geometries."""
+    (text_beds / "genome.bed").write_text("chr1\t0\t2100000\nchr10\t0\t2100000\nchr2\t0\t1500000\nchrX\t0\t2100000\n")
+    v = (text_beds / "plain.bed").read_text().splitlines()
+    edit(v)
+    (text_beds / ("sse_%s.bed" % name)).write_text("\n".join(v) + "\n")
+    for mode in (["counts", "-S", "-i", "-w", "1000", "-d", "1000", "-min", "0"], ["counts", "-S", "-i", "-w", "2000", "-d", "500", "-min", "1"]):
+        args = mode + ["-g", "genome.bed", "sse_%s.bed" % name]
+        want = oracle(args, cwd=text_beds)
+        for dev in ("0", "1"):
+            rc, out, err, nums = _run_text("scans", args, text_beds, extra_env={"GTX_TEXT_ON_DEVICE": dev})
+            assert rc == want[0], (name, mode, dev, err, want[2])
+            assert out == want[1], (name, mode, dev, len(out), len(want[1]))
+            assert err.strip() == want[2].strip(), (name, mode, dev)
