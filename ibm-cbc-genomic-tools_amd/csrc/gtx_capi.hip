@@ -524,10 +524,15 @@ extern "C" int gtx_debug_trace_read(unsigned long long *out, long long nWaves)
 }
 #endif
 
-static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int64_t indexBase = 0, const gtx_ctx::HistSet *set = nullptr, bool share = false)
+// hist32: the call is ONE launch of the streaming kernel over unweighted reads (a *_device call): 32-bit histogram slots
+// (CountArgs::hist32); the caller hands the same flag to launch_finalize
+static gtx::CountArgs count_args(gtx_ctx *c, uint32_t flags, int64_t nReads, int64_t indexBase = 0, const gtx_ctx::HistSet *set = nullptr, bool share = false,
+                                 bool hist32 = false)
 {
   gtx::CountArgs a;
   a.indexBase = indexBase;
+  { static const bool off = (getenv("GTX_HIST32") && atoi(getenv("GTX_HIST32")) == 0) || (getenv("GTX_PF") && atoi(getenv("GTX_PF")));
+    a.hist32 = hist32 && !off && nReads < (1ll << 32) && c->prefetch >= 4; }
   a.owned = (share || set) && c->shareOn ? c->d_shareOwned : nullptr;
   a.sortedE = c->d_sortedE; a.sortedS = c->d_sortedS; a.segStart = c->d_segStart;
   a.histA = c->d_histA; a.histB = c->d_histB; a.partA = c->d_partA; a.partB = c->d_partB; a.info = c->d_info + c->infoCur;
@@ -705,7 +710,7 @@ static int count_begin(gtx_ctx *c)
 }
 
 // share: the context is a group member -- finalize its classes only, d_hits receives its regions in the group's compact order
-static int count_end(gtx_ctx *c, void *d_hits, bool share = false, bool scatter = false)
+static int count_end(gtx_ctx *c, void *d_hits, bool share = false, bool scatter = false, bool hist32 = false)
 {
   gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions, scatter};
   if (++c->chainEpoch == 0) {                       // (after 2^32 calls: the flags start over)
@@ -714,7 +719,7 @@ static int count_end(gtx_ctx *c, void *d_hits, bool share = false, bool scatter 
   }
   HIPCHK(c, gtx::launch_finalize(c->d_histA, c->d_histB, c->histLen, c->d_partA, c->d_partB, c->tileSumsValid, c->d_prefA, c->d_prefB,
                                  c->d_posE, c->d_posS, c->d_classBase, c->nRefs, (u64 *)d_hits, c->d_info + (c->infoCur ^ 1), c->stream,
-                                 share ? &fs : nullptr, c->d_chainFlags, c->chainEpoch, c->d_info + c->infoCur, &c->chainDraws));
+                                 share ? &fs : nullptr, c->d_chainFlags, c->chainEpoch, c->d_info + c->infoCur, &c->chainDraws, hist32));
   { int rc = merge_end(c, d_hits); if (rc) return rc; }
   c->histDirty = false;
   c->infoCur ^= 1;                                // the block just used stays readable until the call after next
@@ -734,12 +739,17 @@ int gtx_count_device(gtx_ctx *c, const void *d_reads, const void *d_weights, int
   // GTX_CHECK_SORTED is answered by the streaming kernel (exact for any order; only it looks at the order of the reads)
   const bool streaming = (flags & (GTX_READS_SORTED | GTX_CHECK_SORTED)) != 0;
   if (!streaming) c->tileSumsValid = false;
-  if (streaming) HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, count_args(c, flags, n), true, c->stream));
+  bool h32 = false;
+  if (streaming) {
+    const gtx::CountArgs a = count_args(c, flags, n, 0, nullptr, false, d_weights == nullptr);
+    h32 = a.hist32 != 0 && n > 0;
+    HIPCHK(c, gtx::launch_count(d_reads, d_weights, n, a, true, c->stream));
+  }
   else { rc = launch_unsorted(c, d_reads, d_weights, n, count_args(c, flags, n)); if (rc) return rc; }
   rc = merge_batch(c, d_reads, d_weights, n); if (rc) return rc;
   rc = pairs_batch(c, d_reads, d_weights, n); if (rc) return rc;
   if (c->profThis) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  rc = count_end(c, d_hits); if (rc) return rc;
+  rc = count_end(c, d_hits, false, false, h32); if (rc) return rc;
   if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], c->stream)); c->profCalls++; }
   return GTX_OK;
 }
@@ -1990,7 +2000,7 @@ int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d
   if (c->profThis) { c->ev = c->evRing[c->profCalls % gtx_ctx::kProfSlots]; HIPCHK(c, hipEventRecord(c->ev[1], run)); }
   const bool keepDefault = c->tileSumsValid;
   c->tileSumsValid = true;
-  gtx::CountArgs a = count_args(c, flags, n, 0, &h);               // (clears c->tileSumsValid when the kernel leaves the tile sums to the finalize step)
+  gtx::CountArgs a = count_args(c, flags, n, 0, &h, false, d_weights == nullptr);   // (clears c->tileSumsValid when the kernel leaves the tile sums to the finalize step)
   a.info = info;
   const bool sumsValid = c->tileSumsValid;
   c->tileSumsValid = keepDefault;
@@ -2001,7 +2011,7 @@ int gtxi_count_device_share_async(gtx_ctx *c, const void *d_reads, const void *d
   gtx::FinalizeShare fs = {c->d_shareTiles, c->nShareTiles, c->d_shareRegions, c->nShareRegions, direct_out != nullptr};
   if (++h.epoch == 0) { HIPCHK(c, hipMemsetAsync(h.flags, 0, sizeof(unsigned) * 8 * (nTiles + 2), run)); h.epoch = 1; h.draws = 0; }
   HIPCHK(c, gtx::launch_finalize(h.histA, h.histB, c->histLen, h.partA, h.partB, sumsValid, h.prefA, h.prefB, c->d_posE, c->d_posS, c->d_classBase,
-                                 c->nRefs, dst, infoNext, run, &fs, h.flags, h.epoch, info, &h.draws));
+                                 c->nRefs, dst, infoNext, run, &fs, h.flags, h.epoch, info, &h.draws, a.hist32 != 0 && n > 0));
   if (c->profThis) { if (c->profEvery <= 1) HIPCHK(c, hipEventRecord(c->ev[3], run)); c->profCalls++; }
   c->lastShareInfo = info;
   *d_piece = dst; *pieceLen = c->nShareRegions;

@@ -80,6 +80,8 @@ struct CountArgs {
   PlaceTable place;
   SpanSchedule sched;
   int flip;                      // streaming kernel: meet all boundaries of a window at once (dense references)
+  int hist32;                    // streaming kernel (unweighted, R = 4): histA / histB are read and written as unsigned[] -- the caller's finalize step too
+                                 //   (launch_finalize(..., hist32)).  For calls of fewer than 2^32 reads in ONE launch: no slot or prefix can pass that
   long long indexBase;           // position of reads[0] in the caller's stream: added to the indices reported in `info`
   // sorted-merge semantics (zeroLenOk): inverted reads (start > end + 1) are not degenerate there -- the merge matches them
   // by its two comparisons like any other read (genomic_intervals.cpp:1225-1236).  The rank difference does not hold for
@@ -205,7 +207,8 @@ hipError_t launch_finalize(unsigned long long *histA, unsigned long long *histB,
                            unsigned long long *prefA, unsigned long long *prefB,
                            const int *posE, const int *posS, const int *classBase, long long m,
                            unsigned long long *hits, DevInfo *nextInfo, hipStream_t st, const FinalizeShare *share = nullptr,
-                           unsigned *chainFlags = nullptr, unsigned epoch = 0, DevInfo *info = nullptr, unsigned long long *chainDraws = nullptr);
+                           unsigned *chainFlags = nullptr, unsigned epoch = 0, DevInfo *info = nullptr, unsigned long long *chainDraws = nullptr,
+                           bool hist32 = false);
 // chainFlags (may be null): 8 x (tiles + 2) words (two 64-bit words per tile and histogram; the word behind each histogram's is the kernel's ticket counter), zero when
 // made, never written by the caller; epoch: a value no earlier call on these flags used (and not 0); info: the call's block (DevInfo::fault); chainDraws: the host's count of
 // the tickets drawn from these flags so far (0 when they are made; the launcher advances it).  With them a call whose tile sums are not valid and whose tiles are few

@@ -112,13 +112,17 @@ __device__ __forceinline__ i64 wave_sum(i64 v)
 // ---------------------------------------------------------------------------------------------
 struct Seg { int start, end, cls; };            // class segment [start,end) of both boundary arrays
 
-template <bool WEIGHTED, bool STRICT, bool SUMKEY = false>
+// H32: the histogram's slots are 32-bit (an unweighted count of fewer than 2^32 reads: no slot, and no prefix over the slots, can pass
+// the number of reads -- half the bytes for the flushes here and for the finalize step to scan, clear and gather from)
+template <bool WEIGHTED, bool STRICT, bool SUMKEY = false, bool H32 = false>
 struct Win {
+  static_assert(!H32 || (!WEIGHTED && !SUMKEY), "32-bit slots are for unweighted counts");
+  typedef typename std::conditional<H32, unsigned, u64>::type hist_t;
   // SUMKEY (coverage): besides the weight of the keys that fall into a slot, the sum of weight x key
   // is kept in a second histogram (hist2 / part2 / acc2 / pend2)
   typedef typename std::conditional<WEIGHTED || SUMKEY, i64, unsigned>::type acc_t;
   const int *arr;       // sorted boundaries of all classes
-  u64 *hist;            // rank histogram, index = rank + class id
+  hist_t *hist;         // rank histogram, index = rank + class id
   u64 *part;            // per-tile (kTile slots) sums of hist, kept up to date for the finalize scan (nullptr: not kept)
   u64 *hist2, *part2;   // SUMKEY only
   i64 acc2, pend2;      // SUMKEY only
@@ -154,7 +158,7 @@ struct Win {
   {
     const i64 idx0 = (i64)b - 1 + sg.cls;                    // wave-uniform: histogram index of lane 0
     const i64 idx = idx0 + lane;
-    if (a != 0) atomicAdd(&hist[idx], (u64)(i64)a);
+    if (a != 0) atomicAdd(&hist[idx], (hist_t)(i64)a);
     if (!part) return;                                       // few tiles: the finalize step rebuilds their sums (see count_args)
     if constexpr (sizeof(acc_t) == 4) {
       // a wave streams at most 128 x 64 reads, so the lane sums fit 32 bits: one DPP scan, and the tile border
@@ -272,7 +276,7 @@ struct Win {
       int lo = sg.start, hi = sg.end;
       while (lo < hi) { int mid = (int)(((i64)lo + hi) >> 1); if (before(arr[mid], key)) lo = mid + 1; else hi = mid; }
       const i64 idx = (i64)lo + sg.cls;
-      atomicAdd(&hist[idx], (u64)w);
+      atomicAdd(&hist[idx], (hist_t)w);
       if (SUMKEY) atomicAdd(&hist2[idx], (u64)(w * key));
       tile = (int)(idx >> kTileShift);
     }
@@ -342,10 +346,10 @@ __device__ __forceinline__ Tri load_tri(const char *p)
 }
 
 // per-wave running state of the streaming kernel (all wave-uniform except the windows inside A, B)
-template <bool WEIGHTED>
+template <bool WEIGHTED, bool H32 = false>
 struct WaveState {
-  Win<WEIGHTED, false> A;                       // ends array, keyed by read start
-  Win<WEIGHTED, true> B;                        // starts array, keyed by read end
+  Win<WEIGHTED, false, false, H32> A;           // ends array, keyed by read start
+  Win<WEIGHTED, true, false, H32> B;            // starts array, keyed by read end
   bool validA, validB;
   Seg sg;
   int nNoClass, nDegen;
@@ -358,8 +362,8 @@ struct WaveState {
 // lane (class change inside a chunk, interleaved classes, keys scattered over many windows) adds
 // itself with two binary searches.  Reads of an unknown class or with start > end are only counted
 // into gtx_count_info.
-template <bool WEIGHTED>
-__device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED> &st, const CountArgs &a, const Tri &t, int w, u64 active, i64 firstIndex, int lane)
+template <bool WEIGHTED, bool H32>
+__device__ __forceinline__ void walk_chunk(WaveState<WEIGHTED, H32> &st, const CountArgs &a, const Tri &t, int w, u64 active, i64 firstIndex, int lane)
 {
   if (a.checkSorted) {
     int cc = t.c >> a.sortClassShift;
@@ -735,7 +739,7 @@ __device__ __forceinline__ void rank_pair(const Seg &sg, const WA &A, const int 
 // flight only between issuing a step's loads and their arrival -- about 60 % of the time; a wave's rate is bytes in flight /
 // latency, and the launch is short of resident waves to cover for that (8 per SIMD is the hardware's limit, a second register
 // set would cost three of them).
-template <bool WEIGHTED, int R, bool FLIP, bool PF = false>
+template <bool WEIGHTED, int R, bool FLIP, bool PF = false, bool H32 = false>
 __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, const CountArgs &a)
 {
   static_assert(!PF || (R == 4 && !WEIGHTED), "the LDS prefetch is built for steps of 4 x 64 unweighted reads");
@@ -762,8 +766,9 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
   const int nSteps = (nMine + 64 * R - 1) / (64 * R);
   const int nFull = nMine / (64 * R);                          // steps with all R x 64 reads present
 
-  WaveState<WEIGHTED> st;
-  st.A.arr = a.sortedE; st.A.hist = a.histA; st.A.part = a.partA; st.B.arr = a.sortedS; st.B.hist = a.histB; st.B.part = a.partB;
+  WaveState<WEIGHTED, H32> st;
+  typedef typename Win<WEIGHTED, false, false, H32>::hist_t hist_t;
+  st.A.arr = a.sortedE; st.A.hist = (hist_t *)a.histA; st.A.part = a.partA; st.B.arr = a.sortedS; st.B.hist = (hist_t *)a.histB; st.B.part = a.partB;
   st.A.acc = st.B.acc = 0; st.A.pend = st.B.pend = 0; st.A.j = st.B.j = 0; st.A.base = st.B.base = 0;
   st.A.W = st.A.Wn = st.B.W = st.B.Wn = kHi; st.A.prevW = st.B.prevW = kLo; st.A.curW = st.B.curW = kHi;
   st.validA = st.validB = false;
@@ -950,7 +955,7 @@ __device__ __forceinline__ void count_walk_body(const Tri *__restrict__ reads, c
 #pragma unroll
       for (int q = 1; q < R; ++q) if (r == q) { tt = t[q]; ww = w[q]; }
       const u64 active = left >= 64 ? ~0ull : ((1ull << left) - 1);
-      walk_chunk<WEIGHTED>(st, a, tt, ww, active, first + at + 64 * r, lane);
+      walk_chunk<WEIGHTED, H32>(st, a, tt, ww, active, first + at + 64 * r, lane);
     }
     ++s; have = false;
   }
@@ -979,6 +984,15 @@ template <bool WEIGHTED, int R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void count_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
 {
   count_walk_body<WEIGHTED, R, false>(reads, weights, n, a);
+}
+// the same with 32-bit histogram slots (CountArgs::hist32: an unweighted call of fewer than 2^32 reads on resident reads)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void count_walk_kernel_h32(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
+{
+  count_walk_body<false, 4, false, false, true>(reads, weights, n, a);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void count_walk_kernel_flip_h32(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
+{
+  count_walk_body<false, 4, true, false, true>(reads, weights, n, a);
 }
 // experiment (GTX_PF=1): the next step prefetched through LDS
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void count_walk_kernel_pf(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
@@ -1459,6 +1473,16 @@ __global__ __launch_bounds__(1024) void count_search_kernel(const Tri *__restric
 //                          and zeroes the tile sums
 // (tile_sums_kernel rebuilds the tile sums for the search kernel, which does not maintain them.)
 // ---------------------------------------------------------------------------------------------
+// four consecutive histogram slots of a thread (32-byte aligned for 64-bit slots, 16-byte for 32-bit ones: i0 is a multiple of 4)
+template <class T> __device__ __forceinline__ void load4(const T *p, u64 (&v)[4]);
+template <> __device__ __forceinline__ void load4<u64>(const u64 *p, u64 (&v)[4])
+{ const ulonglong2 x = *(const ulonglong2 *)p, y = *(const ulonglong2 *)(p + 2); v[0] = x.x; v[1] = x.y; v[2] = y.x; v[3] = y.y; }
+template <> __device__ __forceinline__ void load4<unsigned>(const unsigned *p, u64 (&v)[4])
+{ const uint4 x = *(const uint4 *)p; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+template <class T> __device__ __forceinline__ void store4(T *p, u64 a, u64 b, u64 c, u64 d);
+template <> __device__ __forceinline__ void store4<u64>(u64 *p, u64 a, u64 b, u64 c, u64 d) { *(ulonglong2 *)p = make_ulonglong2(a, b); *(ulonglong2 *)(p + 2) = make_ulonglong2(c, d); }
+template <> __device__ __forceinline__ void store4<unsigned>(unsigned *p, u64 a, u64 b, u64 c, u64 d) { *(uint4 *)p = make_uint4((unsigned)a, (unsigned)b, (unsigned)c, (unsigned)d); }
+
 __device__ __forceinline__ u64 block_sum(u64 v, u64 *lds)
 {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1473,47 +1497,44 @@ __device__ __forceinline__ u64 block_sum(u64 v, u64 *lds)
 }
 
 // tileList (may be null): the tiles to work on -- a member of a group only has counts in the tiles of the classes it owns
-__global__ __launch_bounds__(256) void tile_sums_kernel(const u64 *__restrict__ ha, const u64 *__restrict__ hb, i64 len,
+// (T: the histograms' slot type; the tile sums are 64-bit either way)
+template <class T>
+__global__ __launch_bounds__(256) void tile_sums_kernel(const T *__restrict__ ha, const T *__restrict__ hb, i64 len,
                                                         u64 *__restrict__ pa, u64 *__restrict__ pb, const int *__restrict__ tileList)
 {
-  // grid (tiles, 2): blockIdx.y picks the histogram; thread t owns 4 consecutive slots (two 16-byte loads)
+  // grid (tiles, 2): blockIdx.y picks the histogram; thread t owns 4 consecutive slots
   __shared__ u64 lds[4];
-  const u64 *__restrict__ h = blockIdx.y ? hb : ha;
+  const T *__restrict__ h = blockIdx.y ? hb : ha;
   const int tileIdx = tileList ? tileList[blockIdx.x] : (int)blockIdx.x;
   const i64 i0 = (i64)tileIdx * kTile + (i64)threadIdx.x * 4;
   u64 s = 0;
-  if (i0 + 4 <= len) {
-    const ulonglong2 x = *(const ulonglong2 *)(h + i0), y = *(const ulonglong2 *)(h + i0 + 2);
-    s = x.x + x.y + y.x + y.y;
-  } else {
-    for (int k = 0; k < 4; k++) if (i0 + k < len) s += h[i0 + k];
-  }
+  if (i0 + 4 <= len) { u64 v[4]; load4<T>(h + i0, v); s = v[0] + v[1] + v[2] + v[3]; }
+  else for (int k = 0; k < 4; k++) if (i0 + k < len) s += h[i0 + k];
   s = block_sum(s, lds);
   if (threadIdx.x == 0) (blockIdx.y ? pb : pa)[tileIdx] = s;
 }
 
 // grid (tiles, 2): blockIdx.y picks the histogram (A or B) -- twice the blocks, half the work per block
-__global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha, u64 *__restrict__ hb, i64 len,
+template <class T>
+__global__ __launch_bounds__(256) void finalize_scan_kernel(T *__restrict__ ha, T *__restrict__ hb, i64 len,
                                                             const u64 *__restrict__ ta, const u64 *__restrict__ tb,
-                                                            u64 *__restrict__ pa, u64 *__restrict__ pb, const int *__restrict__ tileList)
+                                                            T *__restrict__ pa, T *__restrict__ pb, const int *__restrict__ tileList)
 {
   __shared__ u64 lds[4];
   __shared__ u64 wsum[4];
-  u64 *__restrict__ h = blockIdx.y ? hb : ha;
+  T *__restrict__ h = blockIdx.y ? hb : ha;
   const u64 *__restrict__ ts = blockIdx.y ? tb : ta;
-  u64 *__restrict__ p = blockIdx.y ? pb : pa;
+  T *__restrict__ p = blockIdx.y ? pb : pa;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int tile = tileList ? tileList[blockIdx.x] : (int)blockIdx.x;   // (tiles not in the list hold no counts: their sums are 0)
-  // thread t owns 4 consecutive slots (two 16-byte loads); issued first, used last
+  // thread t owns 4 consecutive slots; issued first, used last
   const i64 i0 = (i64)tile * kTile + (i64)threadIdx.x * 4;
-  const bool full = i0 + 4 <= len;                   // (32-byte aligned: the histograms come from hipMalloc, i0 is a multiple of 4)
+  const bool full = i0 + 4 <= len;                   // (the histograms come from hipMalloc, i0 is a multiple of 4)
   u64 v[4];
-  if (full) {
-    const ulonglong2 x = *(const ulonglong2 *)(h + i0), y = *(const ulonglong2 *)(h + i0 + 2);
-    v[0] = x.x; v[1] = x.y; v[2] = y.x; v[3] = y.y;
-  } else {
+  if (full) load4<T>(h + i0, v);
+  else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = i0 + k < len ? h[i0 + k] : 0;
+    for (int k = 0; k < 4; k++) v[k] = i0 + k < len ? (u64)h[i0 + k] : 0;
   }
   // offset of this tile: sum of the tile sums below it
   u64 o = 0;
@@ -1525,15 +1546,11 @@ __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha
   __syncthreads();
   o += x - v[3];
   for (int k = 0; k < wv; k++) o += wsum[k];
-  if (full) {
-    *(ulonglong2 *)(p + i0) = make_ulonglong2(v[0] + o, v[1] + o);
-    *(ulonglong2 *)(p + i0 + 2) = make_ulonglong2(v[2] + o, v[3] + o);
-    *(ulonglong2 *)(h + i0) = make_ulonglong2(0, 0);
-    *(ulonglong2 *)(h + i0 + 2) = make_ulonglong2(0, 0);
-  } else {
+  if (full) { store4<T>(p + i0, v[0] + o, v[1] + o, v[2] + o, v[3] + o); store4<T>(h + i0, 0, 0, 0, 0); }
+  else {
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      if (i0 + k < len) { p[i0 + k] = v[k] + o; h[i0 + k] = 0; }
+      if (i0 + k < len) { p[i0 + k] = (T)(v[k] + o); h[i0 + k] = 0; }
   }
 }
 
@@ -1548,9 +1565,10 @@ __global__ __launch_bounds__(256) void finalize_scan_kernel(u64 *__restrict__ ha
 // kChainSpinMax times gives up, raises DevInfo::fault (the call's result is then refused by gtx_last_info) and finishes with what it has.
 static constexpr unsigned kChainSpinMax = 1u << 22;           // polls of one word (~1 us each under load): seconds
 static constexpr int kChainMaxTiles = 512;
-__global__ __launch_bounds__(256) void finalize_scan_chained_kernel(u64 *__restrict__ ha, u64 *__restrict__ hb, i64 len,
+template <class T>
+__global__ __launch_bounds__(256) void finalize_scan_chained_kernel(T *__restrict__ ha, T *__restrict__ hb, i64 len,
                                                                     u64 *fa, u64 *fb, u64 *ctlA, u64 *ctlB, u64 base, unsigned epoch, int nRun,
-                                                                    u64 *__restrict__ pa, u64 *__restrict__ pb, const int *__restrict__ tileList,
+                                                                    T *__restrict__ pa, T *__restrict__ pb, const int *__restrict__ tileList,
                                                                     DevInfo *info)
 {
   __shared__ u64 lds[4];
@@ -1560,20 +1578,18 @@ __global__ __launch_bounds__(256) void finalize_scan_chained_kernel(u64 *__restr
   if (threadIdx.x == 0) tk = atomicAdd(second ? ctlB : ctlA, 1ull) - base;
   __syncthreads();
   if (tk >= (u64)nRun) { if (threadIdx.x == 0) atomicAdd((u64 *)&info->fault, 1ull); return; }   // (the host's count of draws is off: touch nothing)
-  u64 *__restrict__ h = second ? hb : ha;
+  T *__restrict__ h = second ? hb : ha;
   u64 *fl = second ? fb : fa;
-  u64 *__restrict__ p = second ? pb : pa;
+  T *__restrict__ p = second ? pb : pa;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int pos = (int)tk, tile = tileList ? tileList[pos] : pos;
   const i64 i0 = (i64)tile * kTile + (i64)threadIdx.x * 4;
   const bool full = i0 + 4 <= len;
   u64 v[4];
-  if (full) {
-    const ulonglong2 x = *(const ulonglong2 *)(h + i0), y = *(const ulonglong2 *)(h + i0 + 2);
-    v[0] = x.x; v[1] = x.y; v[2] = y.x; v[3] = y.y;
-  } else {
+  if (full) load4<T>(h + i0, v);
+  else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = i0 + k < len ? h[i0 + k] : 0;
+    for (int k = 0; k < 4; k++) v[k] = i0 + k < len ? (u64)h[i0 + k] : 0;
   }
   v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
   const u64 x = wave_scan_add64(v[3]);             // inclusive scan of the thread totals across the wave (DPP)
@@ -1597,19 +1613,17 @@ __global__ __launch_bounds__(256) void finalize_scan_chained_kernel(u64 *__restr
   o = block_sum(o, lds);
   o += x - v[3];
   for (int k = 0; k < wv; k++) o += wsum[k];
-  if (full) {
-    *(ulonglong2 *)(p + i0) = make_ulonglong2(v[0] + o, v[1] + o);
-    *(ulonglong2 *)(p + i0 + 2) = make_ulonglong2(v[2] + o, v[3] + o);
-    *(ulonglong2 *)(h + i0) = make_ulonglong2(0, 0);
-    *(ulonglong2 *)(h + i0 + 2) = make_ulonglong2(0, 0);
-  } else {
+  if (full) { store4<T>(p + i0, v[0] + o, v[1] + o, v[2] + o, v[3] + o); store4<T>(h + i0, 0, 0, 0, 0); }
+  else {
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      if (i0 + k < len) { p[i0 + k] = v[k] + o; h[i0 + k] = 0; }
+      if (i0 + k < len) { p[i0 + k] = (T)(v[k] + o); h[i0 + k] = 0; }
   }
 }
 
-__global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict__ pa, const u64 *__restrict__ pb,
+// (T = unsigned: the differences are taken modulo 2^32 -- every prefix and every count is below the number of reads, which is)
+template <class T>
+__global__ __launch_bounds__(256) void gather_hits_kernel(const T *__restrict__ pa, const T *__restrict__ pb,
                                                           const int *__restrict__ posE, const int *__restrict__ posS,
                                                           const int *__restrict__ classBase, i64 m, u64 *__restrict__ hits,
                                                           u64 *__restrict__ ta, u64 *__restrict__ tb, int nTiles, DevInfo *nextInfo,
@@ -1627,8 +1641,8 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const u64 *__restrict_
   u64 h = 0;
   if (pe >= 0) {
     int cb = classBase[k];                       // slot just below the class's first slot, -1 if none
-    u64 ba = cb >= 0 ? pa[cb] : 0, bb = cb >= 0 ? pb[cb] : 0;
-    h = (pa[pe] - ba) - (pb[posS[k]] - bb);
+    T ba = cb >= 0 ? pa[cb] : 0, bb = cb >= 0 ? pb[cb] : 0;
+    h = (u64)(T)((T)(pa[pe] - ba) - (T)(pb[posS[k]] - bb));
   }
   hits[outIdx] = h;
 }
@@ -1938,7 +1952,9 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
     else if (a.prefetch <= 1) count_walk_kernel<false, 1><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.prefetch == 2) count_walk_kernel<false, 2><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.prefetch == 3) count_walk_kernel<false, 3><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (a.flip && a.hist32) count_walk_kernel_flip_h32<<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (a.flip) count_walk_kernel_flip<<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+    else if (a.hist32) count_walk_kernel_h32<<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else if (getenv("GTX_PF") && atoi(getenv("GTX_PF"))) count_walk_kernel_pf<<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
     else count_walk_kernel<false, 4><<<grid, bs, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   } else {
@@ -1963,13 +1979,14 @@ hipError_t launch_count(const void *reads, const void *weights, i64 n, const Cou
 hipError_t launch_tile_sums(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, hipStream_t st)
 {
   const int nb = scan_tiles(histLen);
-  if (nb > 0) tile_sums_kernel<<<dim3(nb, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, nullptr);
+  if (nb > 0) tile_sums_kernel<u64><<<dim3(nb, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, nullptr);
   return hipGetLastError();
 }
 
-hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, bool tileSumsValid, u64 *prefA, u64 *prefB,
-                           const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, DevInfo *nextInfo, hipStream_t st,
-                           const FinalizeShare *share, unsigned *chainFlags, unsigned epoch, DevInfo *info, unsigned long long *chainDraws)
+template <class T>
+static hipError_t launch_finalize_t(T *histA, T *histB, i64 histLen, u64 *tileA, u64 *tileB, bool tileSumsValid, T *prefA, T *prefB,
+                                    const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, DevInfo *nextInfo, hipStream_t st,
+                                    const FinalizeShare *share, unsigned *chainFlags, unsigned epoch, DevInfo *info, unsigned long long *chainDraws)
 {
   const int nb = scan_tiles(histLen);
   const int nbRun = share ? share->nTiles : nb;                // a group member: the tiles of its classes, its regions (compact)
@@ -1978,20 +1995,31 @@ hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 
   if (nbRun > 0) {
     static const int chainMax = getenv("GTX_CHAIN_MAX_TILES") ? atoi(getenv("GTX_CHAIN_MAX_TILES")) : kChainMaxTiles;
     if (!tileSumsValid && chainFlags && chained && info && chainDraws && nbRun <= chainMax) {
-      finalize_scan_chained_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, (u64 *)chainFlags, (u64 *)chainFlags + 2 * (nb + 2), (u64 *)chainFlags + 2 * nb,
-                                                                   (u64 *)chainFlags + 2 * (nb + 2) + 2 * nb, *chainDraws, epoch, nbRun, prefA, prefB, tl, info);
+      finalize_scan_chained_kernel<T><<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, (u64 *)chainFlags, (u64 *)chainFlags + 2 * (nb + 2), (u64 *)chainFlags + 2 * nb,
+                                                                      (u64 *)chainFlags + 2 * (nb + 2) + 2 * nb, *chainDraws, epoch, nbRun, prefA, prefB, tl, info);
       *chainDraws += (unsigned long long)nbRun;
     }
     else {
-      if (!tileSumsValid) tile_sums_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, tl);
-      finalize_scan_kernel<<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB, tl);
+      if (!tileSumsValid) tile_sums_kernel<T><<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, tl);
+      finalize_scan_kernel<T><<<dim3(nbRun, 2), 256, 0, st>>>(histA, histB, histLen, tileA, tileB, prefA, prefB, tl);
     }
   }
   const i64 mm = share ? share->nRegions : m;
   const i64 work = (mm > nb ? mm : nb) > 0 ? (mm > nb ? mm : nb) : 1;
-  gather_hits_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(prefA, prefB, posE, posS, classBase, mm, hits, tileA, tileB, nb, nextInfo,
-                                                                     share ? share->regionList : nullptr, share && share->scatter ? 1 : 0);
+  gather_hits_kernel<T><<<(unsigned)((work + 255) / 256), 256, 0, st>>>(prefA, prefB, posE, posS, classBase, mm, hits, tileA, tileB, nb, nextInfo,
+                                                                        share ? share->regionList : nullptr, share && share->scatter ? 1 : 0);
   return hipGetLastError();
+}
+
+hipError_t launch_finalize(u64 *histA, u64 *histB, i64 histLen, u64 *tileA, u64 *tileB, bool tileSumsValid, u64 *prefA, u64 *prefB,
+                           const int *posE, const int *posS, const int *classBase, i64 m, u64 *hits, DevInfo *nextInfo, hipStream_t st,
+                           const FinalizeShare *share, unsigned *chainFlags, unsigned epoch, DevInfo *info, unsigned long long *chainDraws, bool hist32)
+{
+  // hist32: the call's streaming kernel counted into 32-bit slots (CountArgs::hist32): the same buffers, read as unsigned[]
+  if (hist32) return launch_finalize_t<unsigned>((unsigned *)histA, (unsigned *)histB, histLen, tileA, tileB, tileSumsValid, (unsigned *)prefA, (unsigned *)prefB,
+                                                 posE, posS, classBase, m, hits, nextInfo, st, share, chainFlags, epoch, info, chainDraws);
+  return launch_finalize_t<u64>(histA, histB, histLen, tileA, tileB, tileSumsValid, prefA, prefB, posE, posS, classBase, m, hits, nextInfo, st, share, chainFlags, epoch,
+                                info, chainDraws);
 }
 
 hipError_t launch_coverage(const void *reads, const void *weights, i64 n, const CoverArgs &a, hipStream_t st)
@@ -2008,7 +2036,7 @@ hipError_t launch_coverage_finalize(const CoverArgs &a, i64 histLen, const Cover
 {
   const int nb = scan_tiles(histLen);
   for (int q = 0; q < 4 && nb > 0; q += 2)
-    finalize_scan_kernel<<<dim3(nb, 2), 256, 0, st>>>(a.hist[q], a.hist[q + 1], histLen, a.part[q], a.part[q + 1], g.pref[q], g.pref[q + 1], nullptr);
+    finalize_scan_kernel<u64><<<dim3(nb, 2), 256, 0, st>>>(a.hist[q], a.hist[q + 1], histLen, a.part[q], a.part[q + 1], g.pref[q], g.pref[q + 1], nullptr);
   const i64 work = (m > nb ? m : nb) > 0 ? (m > nb ? m : nb) : 1;
   gather_coverage_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(g, m, cov, nb, nextInfo);
   return hipGetLastError();

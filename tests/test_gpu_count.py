@@ -590,3 +590,46 @@ def test_placeholder_regions_never_match(engine):
         engine.set_refs(refs, 1, fl)
         hits, _ = engine.count(reads, None, gtx.READS_SORTED | (gtx.ZERO_LENGTH_OK if fl else 0))
         assert hits.tolist() == [2, 0, 2, 0]
+
+
+@pytest.mark.gpu
+def test_slot_widths_take_turns_on_one_context(engine):
+    """An unweighted *_device call of one launch counts into 32-bit histogram slots (its finalize step reads the same buffers as
+    unsigned[]); weighted calls, reads in no order, host-buffer streams and coverage keep 64-bit slots.  The two views share the
+    buffers and each leaves its own cleared: any sequence of calls on one context must give every call's own result -- including
+    a dense reference set (the all-boundaries-at-once kernel), the order check, reads of no class and a batch small enough to keep
+    the tile sums in the streaming kernel."""
+    import torch
+    rng = np.random.default_rng(41)
+    for m, n in ((30_000, 1_500_000), (400_000, 600_000), (5_000, 90_000)):          # sparse, dense (flip), small batch
+        refs = synth.genome_intervals(m, 3 + m, 50, 2000)
+        reads = synth.genome_intervals(n, 4 + m, 50, 300)
+        reads[7, 0] = 999                                                        # no such class
+        w = rng.integers(-3, 9, size=n).astype(np.int32)
+        engine.set_refs(refs, synth.n_classes())
+        d_r, d_w = torch.from_numpy(reads).cuda(), torch.from_numpy(w).cuda()
+        shuf = reads[rng.permutation(n)]
+        d_s = torch.from_numpy(np.ascontiguousarray(shuf)).cuda()
+        hits = torch.zeros(m, dtype=torch.int64, device="cuda")
+        keep = np.ones(n, dtype=bool); keep[7] = False
+        want = orc.count(refs, reads[keep], algo=orc.SORTED_MERGE)
+        want_w = orc.count(refs, reads[keep], w[keep], algo=orc.SORTED_MERGE)
+        def got():
+            engine.sync()
+            return hits.cpu().numpy().view(np.uint64)
+        for step in ("u32", "u64w", "u32", "shuffled", "u32check", "host", "cover", "u32", "u64w"):
+            hits.fill_(-1)
+            if step == "u32":
+                engine.count_device(d_r.data_ptr(), n, hits.data_ptr()); np.testing.assert_array_equal(got(), want)
+                assert engine.last_info()["n_no_class"] == 1
+            elif step == "u32check":
+                engine.count_device(d_r.data_ptr(), n, hits.data_ptr(), flags=gtx.READS_SORTED | gtx.CHECK_SORTED); np.testing.assert_array_equal(got(), want)
+                assert engine.last_info()["first_unsorted"] == 8                     # (the read of no class sits out of order: the one behind it is reported)
+            elif step == "u64w":
+                engine.count_device(d_r.data_ptr(), n, hits.data_ptr(), d_weights=d_w.data_ptr()); np.testing.assert_array_equal(got(), want_w)
+            elif step == "shuffled":
+                engine.count_device(d_s.data_ptr(), n, hits.data_ptr(), flags=0); np.testing.assert_array_equal(got(), want)
+            elif step == "host":
+                h, _ = engine.count(reads, None); np.testing.assert_array_equal(h, want)
+            else:
+                c, _ = engine.coverage(reads[keep][:200_000]); np.testing.assert_array_equal(c, orc.coverage(refs, reads[keep][:200_000], algo=orc.SORTED_MERGE))
