@@ -672,6 +672,9 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
   g_drain_stop = false;
   const size_t batch_reads = kBatchReads;
   PackedBatch two[2]; PackError err;
+  // (a scanner's batch without a single region for the windows still carries the label values of its lines)
+  const bool scan_mode = opt.mode == gtxhost::PACK_SCAN_SORTED || opt.mode == gtxhost::PACK_SCAN_UNSORTED;
+  auto worth = [&](const PackedBatch &b) { return !b.empty() || (scan_mode && b.label_sum != 0); };
   auto pump_text = [&](BedPacker &packer) {
     // blocks of complete lines straight into the two page-locked buffers, tokenised and counted on the device; what is not plain is
     // packed here.  Two blocks in flight: block i's verdict is collected before block i+2 is read over it.
@@ -685,7 +688,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
     packer.UseTextBuffers((char *)g_pool.buf[0], (char *)g_pool.buf[1], kPoolBytes);
     PackedBatch batch;
     if (!packer.PackPrimedText(&batch, &err) && !on_error) DiePack(err);
-    if (!batch.empty()) sink(batch);
+    if (worth(batch)) sink(batch);
     if (err.set) { on_error(err); g_drain_stop = true; g_pool.used[0] = g_pool.used[1] = false; return; }
     BedPacker::TextBlock blk[2]; int ticket[2] = {-1, -1}; bool host_only = false, first_block = true;
     static const bool text_forced = getenv("GTX_TEXT_ON_DEVICE") && atoi(getenv("GTX_TEXT_ON_DEVICE")) == 1;
@@ -700,7 +703,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       const bool ok = packer.PackTextBlock(blk[k], &batch, &err);
       if (err.set && !on_error) DiePack(err);
       (void)ok;
-      if (!batch.empty()) sink(batch);
+      if (worth(batch)) sink(batch);
       if (err.set) { on_error(err); g_drain_stop = true; }
     };
     for (int cur = 0;; cur ^= 1) {
@@ -716,7 +719,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
         batch.clear();
         packer.PackTextBlock(b, &batch, &err);
         if (err.set && !on_error) { settle(cur ^ 1); DiePack(err); }
-        if (!batch.empty()) sink(batch);
+        if (worth(batch)) sink(batch);
         if (err.set) { on_error(err); g_drain_stop = true; break; }
         continue;
       }
@@ -736,7 +739,7 @@ static void DrainSet(GenomicRegionSet *set, PackOptions opt, Prep prep, Sink sin
       bool more = packer.NextBatch(&batch, batch_reads, &err);
       if (g_drain_stop) break;
       if (err.set && !on_error) DiePack(err);
-      if (!batch.empty()) {
+      if (worth(batch)) {
         const auto t0 = std::chrono::steady_clock::now();
         sink(batch); cur ^= 1;
         if (getenv("GTX_PACK_TRACE")) fprintf(stderr, "[sink] %zu reads handed over in %.1f ms\n", batch.tri.size() / 3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -1421,6 +1424,7 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
   DrainSet(R, opt, device_side, [&](const PackedBatch &b) {
     if (!preprocess_ok) { bad_preprocess = true; g_drain_stop = true; return; }
     total_label_value += (long int)b.label_sum;
+    if (b.tri.empty()) return;
     if (one) { check_one(gtx_scan_add(one, b.tri.data(), b.w.empty() ? NULL : b.w.data(), (int64_t)(b.tri.size() / 3), LooksSorted(b.tri) ? 0u : GTX_READS_UNSORTED)); return; }
     tri.insert(tri.end(), b.tri.begin(), b.tri.end());
     w.insert(w.end(), b.w.begin(), b.w.end());
@@ -1469,6 +1473,20 @@ long int GenomicRegionSetScanner::TotalLabelValue()
 {
   if (!computed) Compute(false);
   return total_label_value;
+}
+
+// genomic_intervals.cpp:6206-6214: every region of the file, by the unsorted reader's rules (no order check; a line it cannot read
+// ends the run), its label value capped.  The scanners deliver this sum with their windows (TotalLabelValue); this pass is for the
+// caller that needs it although a sorted scanner stopped at an input error.
+long int CountGenomicRegions(char *reg_file, long int max_label_value)
+{
+  GenomicRegionSet set(reg_file, 10000, false, false, true);
+  ChromTable none; none.Freeze();
+  PackOptions opt;
+  opt.mode = gtxhost::PACK_SCAN_UNSORTED; opt.chroms = &none; opt.max_label_value = max_label_value;
+  long int n = 0;
+  DrainSet(&set, opt, [] {}, [&](const PackedBatch &b) { n += (long int)b.label_sum; });
+  return n;
 }
 
 unsigned long int CalcBoundSize(StringLIntMap *bounds)

@@ -263,6 +263,8 @@ class GenomicRegionSetScanner
   // MI355X path: sum of GetLabelValue(max_label_value) over every region of the input, collected by the same pass that
   // fills the windows -- what the reference gets from a separate read of the file (CountGenomicRegions, :6206-6214)
   long int TotalLabelValue();
+  // an input error is waiting for the Next() call that meets it (sorted scanners): TotalLabelValue() then covers the lines in front of it only
+  bool InputErrorPending() { if (!computed) Compute(false); return halt_set; }
   // MI355X path: every remaining window with a value >= min_value as "value\tchr strand start stop\n" -- what a caller's
   // Next() / PrintInterval() loop prints (genomic_scans.cpp:421-428), formatted in bulk (three stdio calls per window are half a
   // second for the three million windows of a genome at -w 1000)
@@ -321,6 +323,7 @@ void GtxSetDevices(int n_gpus);                                // MI355X path: G
 void GtxMark(const char *what);                                  // GTX_TIMING=1: wall-clock mark on stderr (not in the reference)
 void GtxFinish(int code);                                        // flush and leave without the teardown (see genomic_intervals.cpp)
 
+long int CountGenomicRegions(char *reg_file, long int max_label_value);   // a host pass over the file by the unsorted reader's rules (genomic_intervals.cpp:6206-6214)
 unsigned long int CalcBoundSize(StringLIntMap *bounds);          // sum of the chromosome lengths (genomic_intervals.cpp:6021-6026)
 
 // chromosome -> length from a genome region file (genomic_intervals.cpp:5997-6015)

@@ -74,7 +74,8 @@ static int RunPeaks(char *signal_reg_file, char *control_reg_file, char *uniq_re
   };
   GenomicRegionSet SignalRegSet(signal_reg_file, BUFFER_SIZE, P_VERBOSE, false, true);
   GenomicRegionSetScanner *signal_scanner = make(&SignalRegSet);
-  const long n_signal_reads = signal_scanner->TotalLabelValue();               // the whole signal scan runs here, on the GPU
+  long n_signal_reads = signal_scanner->TotalLabelValue();                     // the whole signal scan runs here, on the GPU
+  if (signal_scanner->InputErrorPending()) n_signal_reads = CountGenomicRegions(signal_reg_file, P_MAX_LABEL_VALUE);   // (the reference's own pass, :245)
   const double p_signal = (double)n_signal_reads / effective_genome_size;
   GenomicRegionSet *ControlRegSet = NULL;
   GenomicRegionSetScanner *control_scanner = NULL;
@@ -84,6 +85,7 @@ static int RunPeaks(char *signal_reg_file, char *control_reg_file, char *uniq_re
     ControlRegSet = new GenomicRegionSet(control_reg_file, BUFFER_SIZE, P_VERBOSE, false, true);
     control_scanner = make(ControlRegSet);
     n_control_reads = control_scanner->TotalLabelValue();
+    if (control_scanner->InputErrorPending()) n_control_reads = CountGenomicRegions(control_reg_file, P_MAX_LABEL_VALUE);
     p_control = (double)n_control_reads / effective_genome_size;
   }
   const double p_ratio = p_signal / p_control;

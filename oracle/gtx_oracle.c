@@ -639,6 +639,7 @@ static int scan_unsorted(orc_chroms *chroms, orc_source *src, const orc_bounds *
  * sort check of GenomicRegionSet::Next(sorted_by_strand,...) (:3873-3882).  Only -op 1 is
  * restated: 'c' is rejected by the reference here (:4944) and 'p' advances twice (:4940,:4945). */
 typedef void (*orc_emit_fn)(void *ctx, long value, int bidx, char strand, long start, long stop);
+static int g_scan_err_at_open;                 /* the error came from the constructor's first read (:4882), not from a Next() */
 
 typedef struct { orc_chroms *chroms; orc_source *src; orc_region cur; int have; int by_strand; int err; } orc_pull;
 
@@ -665,6 +666,7 @@ static int scan_sorted(orc_chroms *chroms, orc_source *src, const orc_bounds *b,
   orc_pull p; memset(&p, 0, sizeof p); p.chroms = chroms; p.src = src; p.by_strand = !ignore_strand;
   pull_next(&p);                                                                   /* r = R->Get() :4884 */
   int rc = p.err ? -1 : 0;
+  g_scan_err_at_open = p.err;
   for (int bi = 0; bi < b->n && !rc; bi++) {
     for (char strand = '+'; strand != ' ' && !rc; strand = (strand == '+' && !ignore_strand) ? '-' : ' ') {
       for (long j = 0; j < comb; j++) ring[j] = 0;
@@ -958,12 +960,20 @@ static long count_regions(orc_chroms *ch, const char *file, long mlv)
   return n;
 }
 
-static void scan_file(orc_chroms *ch, const orc_bounds *b, const char *file, int sorted, long dist, long win, long mlv, int ign, win_list *out)
+/* `late` (sorted scanners only): an error that one of the scanner's Next() calls meets does not end the run here -- its message
+ * is kept in late[] and the windows returned before it in *out, for the caller to raise it at the call that meets it */
+static void scan_file(orc_chroms *ch, const orc_bounds *b, const char *file, int sorted, long dist, long win, long mlv, int ign, win_list *out, char *late)
 {
   memset(out, 0, sizeof *out);
+  if (late) late[0] = 0;
   orc_reader rd; if (reader_open(&rd, file)) die();
   orc_source src; memset(&src, 0, sizeof src); src.chroms = ch; src.rd = &rd;
-  if (sorted) { if (scan_sorted(ch, &src, b, dist, win, mlv, ign, '1', collect_emit, out)) die(); }
+  if (sorted) {
+    if (scan_sorted(ch, &src, b, dist, win, mlv, ign, '1', collect_emit, out)) {
+      if (!late || g_scan_err_at_open) die();
+      snprintf(late, sizeof g_err, "%s", g_err); g_failed = 0; g_err[0] = 0;
+    }
+  }
   else {
     uint64_t **v;
     if (scan_unsorted(ch, &src, b, dist, win, mlv, ign, 'c', &v)) die();
@@ -1018,16 +1028,21 @@ static int run_peaks(orc_chroms *ch, const orc_bounds *b, const char *signal, co
   fprintf(stderr, "* Effective genome size = %lu\n", eff);
   long n_signal = count_regions(ch, signal, mlv);
   double p_signal = (double)n_signal / eff;
-  win_list S, C; scan_file(ch, b, signal, sorted, dist, win, mlv, ign, &S);
+  /* the scanners advance in lockstep (:302-303, signal first): an input error of a sorted scanner surfaces at the Next() call that
+   * reads the offending line, behind the three lines below; the other scanner's may come first */
+  static char s_late[sizeof g_err], c_late[sizeof g_err];
+  win_list S, C; scan_file(ch, b, signal, sorted, dist, win, mlv, ign, &S, s_late);
   long n_control = count_regions(ch, control, mlv);
   double p_control = (double)n_control / eff;
-  scan_file(ch, b, control, sorted, dist, win, mlv, ign, &C);
+  scan_file(ch, b, control, sorted, dist, win, mlv, ign, &C, c_late);
   double p_ratio = p_signal / p_control;
   fprintf(stderr, "* Signal input file = %s (reads = %lu; background probability = %.2e)\n", signal, n_signal, p_signal);
   fprintf(stderr, "* Control input file = %s (reads = %lu; background probability = %.2e)\n", control, n_control, p_control);
   fprintf(stderr, "* Signal/Control background probability = %f\n", p_ratio);
   long cap = 1024, n = 0; double *p1 = xmalloc(sizeof(double) * cap), *p2 = xmalloc(sizeof(double) * cap); long *idx = xmalloc(sizeof(long) * cap);
-  for (long t = 0; t < S.n; t++) {
+  for (long t = 0; ; t++) {
+    if (t == S.n) { if (s_late[0]) { snprintf(g_err, sizeof g_err, "%s", s_late); die(); } break; }
+    if (t == C.n && c_late[0]) { snprintf(g_err, sizeof g_err, "%s", c_late); die(); }
     long v1 = S.w[t].value, v2 = C.w[t].value, v0 = win;
     if (v1 > v0) v1 = v0;
     if (v2 > v0) v2 = v0;

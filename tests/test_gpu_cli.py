@@ -320,7 +320,10 @@ PEAK_RUNS = [
     (["peaks", "-S", "-g", "genome.bed", "-min", "6", "peaks_signal_strand.bed", "peaks_control_strand.bed"]),
     (["peaks", "-i", "--max-label-value", "3", "-g", "genome.bed", "-min", "12", "peaks_signal.bed", "peaks_control.bed"]),
     (["peaks", "-i", "-M", "bogus", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
-    (["peaks", "-S", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),                            # not sorted by strand -> error
+    # not sorted by strand: the scanners advance in lockstep, the error that is met first ends the run (here the control's, line 4,
+    # 85 windows into chr1 '-'; the signal's line 5 would be met at window 190) -- behind the report lines with the whole files' counts
+    (["peaks", "-S", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed"]),
+    (["peaks", "-S", "-g", "genome.bed", "peaks_control.bed", "peaks_signal.bed"]),
 ]
 
 
@@ -332,9 +335,8 @@ def test_peaks_cli_equals_oracle_cli(beds, args):
     got = product("scans", args, cwd=beds)
     assert got[0] == want[0]
     assert got[1] == want[1]
-    assert got[2].strip().splitlines()[-1:] == want[2].strip().splitlines()[-1:]
+    assert got[2] == want[2]                           # the "* Effective genome size ..." report lines, the error if any
     if want[0] == 0:
-        assert got[2] == want[2]                       # the "* Effective genome size ..." report lines
         if "bogus" not in args:
             assert len(got[1].splitlines()) >= 10      # the planted clusters are found
 
