@@ -1386,6 +1386,7 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
   }
   values.assign((size_t)std::max<long long>(total, 1), 0);
   if (n_chrom == 0) return;
+  if (sorted_rules && preprocess == 'p') { ComputeMappable(class_len, class_off); return; }
 
   PackOptions opt;
   opt.mode = sorted_rules ? gtxhost::PACK_SCAN_SORTED : gtxhost::PACK_SCAN_UNSORTED;
@@ -1469,6 +1470,86 @@ void GenomicRegionSetScanner::Compute(bool sorted_rules)
                                (uint64_t *)values.data(), class_off.data()));
 }
 
+// The sorted scanner's operator 'p' (genomic_intervals.cpp:4939-4942; what `genomic_scans peaks` scans its mappability track with): a
+// micro-window receives the part of a region that lies at or below its stop -- and the walk behind it is what the reference wrote, not
+// what one would expect: after a region that ends inside the micro-window it moves on twice (:4940, then :4945: the region behind it
+// is never looked at), after one that reaches beyond the micro-window once, with the region's start set to stop + 1 by then (:4941):
+// the rest of that region is dropped and the order check of the pull (:3879) sees the moved start.  Which region is looked at
+// depends on every region before it, so this is a host-side walk over the set's own iterators (a mappability track is a secondary
+// input, read once); what it yields is (block, micro-window, amount), and those go to the device as weighted point reads: the
+// micro-window histogram and the window sums are the scan kernels' as for any other input.  An input error is met where the walk
+// meets it (halt_*), like the sorted scanner's other errors.  One case the reference leaves undefined: the first of the two pulls
+// meeting the end of the stream (its second pull deletes the last region again); the walk ends there here.
+void GenomicRegionSetScanner::ComputeMappable(const std::vector<int32_t> &class_len, const std::vector<int64_t> &class_off)
+{
+  const int n_chrom = (int)chrom_names.size(), ns = ignore_strand ? 1 : 2;
+  const bool by_strand = !ignore_strand;
+  std::vector<int32_t> tri, w;
+  auto emit = [&](int cls, long int mw, long int amount) {
+    const int32_t pos = (int32_t)((mw - 1) * win_step + 1);          // a position of that micro-window
+    while (amount != 0) {                                              // (a weight is 32 bits; an amount beyond that goes in pieces)
+      const long int piece = std::max<long int>(INT_MIN + 1, std::min<long int>(INT_MAX, amount));
+      tri.push_back(cls); tri.push_back(pos); tri.push_back(pos); w.push_back((int32_t)piece);
+      amount -= piece;
+    }
+  };
+  LoadError err;
+  size_t at_block = 0; long int at_mw = 0;                             // where the walk is: what the halt position is read off
+  tls_load_error = &err;
+  try {
+    GenomicRegion *r = R->Get();
+    for (int c = 0; c < n_chrom && r; c++)
+      for (int s = 0; s < ns && r; s++) {
+        const char *chrom = chrom_names[(size_t)c].c_str();
+        const char strand = s ? '-' : '+';
+        at_block = (size_t)(c * ns + s); at_mw = 0;
+        for (;;) {                                                     // the regions that sort before this block (:4934)
+          if (!r) break;
+          const int t = strcmp(chrom, r->I.front()->CHROMOSOME);
+          if (!(t > 0 || (t == 0 && strand > r->I.front()->STRAND))) break;
+          r = R->Next(by_strand, false);
+        }
+        const long int n_mw = (long int)class_len[(size_t)(s * n_chrom + c)] / win_step;
+        while (r && strcmp(r->I.front()->CHROMOSOME, chrom) == 0 && (ignore_strand || r->I.front()->STRAND == strand)) {
+          GenomicInterval *i = r->I.front();
+          const long int first = i->START <= 0 ? 1 : (i->START + win_step - 1) / win_step;   // the first micro-window whose stop reaches the start
+          if (std::max(first, at_mw) > n_mw) break;                    // (left for the skip loop of the next block)
+          at_mw = std::max<long int>(std::max(first, at_mw), 1);
+          if (r->I.size() != 1) r->PrintError("single-interval regions expected for this operation!\n");
+          const long int stop = at_mw * win_step;
+          if (i->STOP <= stop) {
+            emit(s * n_chrom + c, at_mw, i->STOP - i->START + 1);
+            r = R->Next(by_strand, false);
+            if (!r) break;
+          } else {
+            emit(s * n_chrom + c, at_mw, stop - i->START + 1);
+            i->START = stop + 1;
+          }
+          r = R->Next(by_strand, false);
+        }
+      }
+  } catch (const LoadAbort &) {}
+  tls_load_error = NULL;
+  if (err.set) {
+    const long int comb = win_size / win_step;
+    halt_set = true; halt_line = err.line; halt_msg = err.msg; halt_no_prefix = !err.with_prefix;
+    halt_block = at_block; halt_win = std::max<long int>(0, std::min<long int>(at_mw - comb, n_windows[at_block]));
+  }
+  gtx_group *grp = Devices();
+  const int64_t n = (int64_t)w.size();
+  const uint32_t order = LooksSortedVec(tri) ? 0u : GTX_READS_UNSORTED;
+  if (gtx_group_size(grp) == 1) {
+    gtx_ctx *one = gtx_group_ctx(grp, 0);
+    auto check = [&](int rc) { if (rc != GTX_OK) { fflush(stdout); fprintf(stderr, "\nError: [gtx %d] %s\n", rc, gtx_last_error(one)); exit(1); } };
+    check(gtx_scan_begin(one, class_len.data(), n_chrom * ns, (int32_t)win_step, (int32_t)win_size, '1', GTX_ZERO_LENGTH_OK, 1, class_off.data()));
+    if (n) check(gtx_scan_add(one, tri.data(), w.data(), n, order));
+    check(gtx_scan_end(one, (uint64_t *)values.data(), NULL));
+    return;
+  }
+  CheckGrp(grp, gtx_group_scan(grp, tri.data(), w.data(), n, class_len.data(), n_chrom * ns, (int32_t)win_step, (int32_t)win_size, '1',
+                               GTX_ZERO_LENGTH_OK | (order ? 0u : GTX_READS_SORTED), (uint64_t *)values.data(), class_off.data()));
+}
+
 long int GenomicRegionSetScanner::TotalLabelValue()
 {
   if (!computed) Compute(false);
@@ -1486,6 +1567,15 @@ long int CountGenomicRegions(char *reg_file, long int max_label_value)
   opt.mode = gtxhost::PACK_SCAN_UNSORTED; opt.chroms = &none; opt.max_label_value = max_label_value;
   long int n = 0;
   DrainSet(&set, opt, [] {}, [&](const PackedBatch &b) { n += (long int)b.label_sum; });
+  return n;
+}
+
+// genomic_intervals.cpp:6032-6040: the sizes of the regions' intervals, summed over the file by the plain reader
+unsigned long int CalcRegSize(char *reg_file)
+{
+  GenomicRegionSet set(reg_file, 100000, false, false, true);
+  unsigned long int n = 0;
+  for (GenomicRegion *r = set.Get(); r != NULL; r = set.Next()) n += (unsigned long int)r->GetSize(true);
   return n;
 }
 

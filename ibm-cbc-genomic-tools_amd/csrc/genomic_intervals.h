@@ -278,6 +278,7 @@ class GenomicRegionSetScanner
 
  protected:
   void Compute(bool sorted_rules);                                // runs the GPU scan over the whole input
+  void ComputeMappable(const std::vector<int32_t> &class_len, const std::vector<int64_t> &class_off);   // ... for the sorted scanner's operator 'p'
   std::vector<std::string> chrom_names;                           // bounds in std::map (strcmp) order
   std::vector<long int> n_windows;                                // per (chromosome, strand) block, iteration order
   std::vector<long long> block_offset;
@@ -324,6 +325,7 @@ void GtxMark(const char *what);                                  // GTX_TIMING=1
 void GtxFinish(int code);                                        // flush and leave without the teardown (see genomic_intervals.cpp)
 
 long int CountGenomicRegions(char *reg_file, long int max_label_value);   // a host pass over the file by the unsorted reader's rules (genomic_intervals.cpp:6206-6214)
+unsigned long int CalcRegSize(char *reg_file);                   // sum of the sizes of a file's regions, gaps left out (genomic_intervals.cpp:6032-6040)
 unsigned long int CalcBoundSize(StringLIntMap *bounds);          // sum of the chromosome lengths (genomic_intervals.cpp:6021-6026)
 
 // chromosome -> length from a genome region file (genomic_intervals.cpp:5997-6015)

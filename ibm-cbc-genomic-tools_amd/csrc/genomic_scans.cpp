@@ -2,9 +2,9 @@
 // (reference driver: gtools/genomic_scans.cpp:73-150 options, :399-436 RunCounts, :209-380 PeakFinder, :449-470).
 // Sliding-window read counts over the chromosomes of a genome file; the histogram + window sums
 // run on the GPU behind the reference's GenomicRegionSetScanner classes.  `peaks` scans a signal and a control
-// read set the same way and tests every window on the host (tail probabilities: gtx_stats.h, GSL is not linked;
-// the third input file -- a mappability track scanned with the 'p' operator -- is outside the path).  `peaks` (GSL tail
-// probabilities) is outside this path; the -r reference filter is a host-side test per reported window.
+// read set the same way -- and, when given, a mappability track with the sorted scanner's operator 'p' -- and tests every
+// window on the host (tail probabilities: gtx_stats.h, GSL is not linked); the -r reference filter of `counts` is a
+// host-side test per reported window.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -62,10 +62,9 @@ static double ComputeQValues(const std::vector<double> &pval, const std::vector<
 
 static int RunPeaks(char *signal_reg_file, char *control_reg_file, char *uniq_reg_file)
 {
-  if (uniq_reg_file != NULL) { fprintf(stderr, "Error: the GENOME-UNIQ-REG-FILE input (operator 'p') is outside the MI355X path of this build!\n"); return 1; }
-  const char preprocess = P_SORTED ? '1' : 'c';
+  const char preprocess = (P_SORTED || uniq_reg_file != NULL) ? '1' : 'c';       // (genomic_scans.cpp:236-237)
   StringLIntMap *bounds = ReadBounds((char *)P_GENOME_REG_FILE, false);
-  const unsigned long effective_genome_size = CalcBoundSize(bounds);
+  const unsigned long effective_genome_size = uniq_reg_file == NULL ? CalcBoundSize(bounds) : CalcRegSize(uniq_reg_file);
   fprintf(stderr, "* Effective genome size = %lu\n", effective_genome_size);
 
   auto make = [&](GenomicRegionSet *set) -> GenomicRegionSetScanner * {
@@ -93,6 +92,10 @@ static int RunPeaks(char *signal_reg_file, char *control_reg_file, char *uniq_re
   fprintf(stderr, "* Control input file = %s (reads = %lu; background probability = %.2e)\n", control_reg_file, n_control_reads, p_control);
   fprintf(stderr, "* Signal/Control background probability = %f\n", p_ratio);
 
+  // the mappability track: always the sorted scanner, operator 'p', label values not used (genomic_scans.cpp:265-267)
+  GenomicRegionSet *UniqRegSet = uniq_reg_file == NULL ? NULL : new GenomicRegionSet(uniq_reg_file, BUFFER_SIZE, P_VERBOSE, false, true);
+  GenomicRegionSetScanner *uniq_scanner = uniq_reg_file == NULL ? NULL : new SortedGenomicRegionSetScanner(UniqRegSet, bounds, P_WIN_DIST, P_WIN_SIZE, 1, P_IGNORE_STRAND, 'p');
+
   // without a control the reference draws one Poisson number per window from its clock-seeded generator (:299);
   // here from a generator seeded the same way unless GTX_SEED fixes it
   std::mt19937_64 rng(getenv("GTX_SEED") ? strtoull(getenv("GTX_SEED"), NULL, 10) : (unsigned long long)(getpid() + time(NULL)));
@@ -104,7 +107,7 @@ static int RunPeaks(char *signal_reg_file, char *control_reg_file, char *uniq_re
   long int v1, v2, v0;
   while ((v1 = signal_scanner->Next()) != -1) {
     v2 = control_scanner ? control_scanner->Next() : background(rng);
-    v0 = P_WIN_SIZE;
+    v0 = uniq_scanner == NULL ? P_WIN_SIZE : uniq_scanner->Next();
     v1 = std::min(v1, v0);
     v2 = std::min(v2, v0);
     if (P_NORM) { if (p_ratio < 1.0) v2 = (long int)floor((float)v2 * p_ratio); else v1 = (long int)floor((float)v1 / p_ratio); }
@@ -154,7 +157,7 @@ static int RunPeaks(char *signal_reg_file, char *control_reg_file, char *uniq_re
     delete interval_list[k];
   }
   GtxFinish(0);
-  delete signal_scanner; delete control_scanner; delete ControlRegSet; delete bounds;
+  delete signal_scanner; delete control_scanner; delete ControlRegSet; delete uniq_scanner; delete UniqRegSet; delete bounds;
   return 0;
 }
 

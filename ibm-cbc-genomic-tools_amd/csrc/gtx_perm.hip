@@ -212,6 +212,63 @@ __global__ void perm_list_kernel(int32_t *__restrict__ out, PermGeom g, u64 seed
 // ---------------------------------------------------------------------------------------------
 struct StatConsts { double Vsum, VsumZ, Vsum2, VtotalSum; i64 nRows; i64 tAll; int under; };
 
+// ---- the distribution functions of -a for ratio / t / corr (gsl_cdf_ugaussian_Q, gsl_cdf_tdist_Q at permutation_test.cpp:307, :338, :450,
+// :542; GSL is not linked).  Defined in include/gtx_perm.h: Q(x) = erfc(x / sqrt 2) / 2; Student's t with nu degrees of freedom:
+// Q(t) = I_x(nu/2, 1/2) / 2 for t >= 0 with x = nu / (nu + t^2), the regularised incomplete beta function by its continued fraction
+// (modified Lentz) on the side where it converges fast.  The tests hold a CPU evaluation of the same statements beside it (device
+// and host differ in the last bits of log / exp / lgamma / erfc only).
+__device__ inline double beta_cf(double a, double b, double x)
+{
+  const double tiny = 1e-300;
+  const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+  double c = 1.0, d = 1.0 - qab * x / qap;
+  if (fabs(d) < tiny) d = tiny;
+  d = 1.0 / d;
+  double h = d;
+  for (int m = 1; m <= 100000; m++) {
+    const double m2 = 2.0 * m;
+    double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+    d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+    c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+    d = 1.0 / d; h *= d * c;
+    aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+    d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+    c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+    d = 1.0 / d;
+    const double del = d * c;
+    h *= del;
+    if (fabs(del - 1.0) <= 2.220446049250313e-16) break;
+  }
+  return h;
+}
+__device__ inline double ibeta_reg(double a, double b, double x, double y)      // I_x(a, b), y = 1 - x from the caller
+{
+  if (!(x > 0.0)) return 0.0;
+  if (!(y > 0.0)) return 1.0;
+  const double lx = x < 0.5 ? log(x) : log1p(-y), ly = y < 0.5 ? log(y) : log1p(-x);
+  const double pre = exp(lgamma(a + b) - lgamma(a) - lgamma(b) + a * lx + b * ly);
+  if (x < (a + 1.0) / (a + b + 2.0)) return pre * beta_cf(a, b, x) / a;
+  return 1.0 - pre * beta_cf(b, a, y) / b;
+}
+__device__ inline double tdist_Q(double t, double nu)
+{
+  if (t != t || !(nu > 0.0)) return __builtin_nan("");
+  if (isinf(t)) return t > 0 ? 0.0 : 1.0;
+  const double t2 = t * t, den = nu + t2;
+  const double tail = 0.5 * ibeta_reg(0.5 * nu, 0.5, nu / den, t2 / den);
+  return t >= 0 ? tail : 1.0 - tail;
+}
+__device__ inline double gauss_Q(double x) { return 0.5 * erfc(x / 1.41421356237309504880); }
+// `(long int)floor(..)` of :306 / :337 and `df < 0 ? 1.0 : tdist_Q(Y, df)`: a NaN or an out-of-range quotient converts to LONG_MIN on
+// x86-64, i.e. takes the 1.0 branch
+__device__ inline double welch_tail(double y, double s0, i64 n0, double s1, i64 n1)
+{
+  const double a = s0 + s1;
+  const double dfd = floor(a * a / (s0 * s0 / (double)(n0 - 1) + s1 * s1 / (double)(n1 - 1)));
+  if (!(dfd >= 0.0) || dfd >= 9223372036854775808.0) return 1.0;
+  return tdist_Q(y, (double)(i64)dfd);
+}
+
 template <int STAT, bool TOTALS> struct Acc;
 
 // (kWords: the leading 8-byte words that make up the running state -- what travels between the row-range launches)
@@ -220,6 +277,7 @@ template <bool TOTALS> struct Acc<GTX_STAT_SUM, TOTALS> {                      /
   double y = 0, yt = 0;
   __device__ void add(float v, float vt) { y += v; if (TOTALS) yt += vt; }
   __device__ double finish(i64 nc, const StatConsts &k) const { double r = TOTALS ? y / yt : y / nc; return k.under ? -r : r; }
+  __device__ double approx(i64, const StatConsts &) const { return __builtin_nan(""); }      // ("not implemented yet" there: refused by the host)
 };
 
 template <int STAT, bool TOTALS> struct AccCount {                              // :341-413
@@ -230,6 +288,7 @@ template <int STAT, bool TOTALS> struct AccCount {                              
   {
     return STAT == GTX_STAT_N ? (double)kk : STAT == GTX_STAT_SENS ? (double)kk / nc : (double)kk / k.tAll;
   }
+  __device__ double approx(i64, const StatConsts &) const { return __builtin_nan(""); }      // (`n`: by table, MODE_RANK)
 };
 template <bool TOTALS> struct Acc<GTX_STAT_N, TOTALS> : AccCount<GTX_STAT_N, TOTALS> {};
 template <bool TOTALS> struct Acc<GTX_STAT_SENS, TOTALS> : AccCount<GTX_STAT_SENS, TOTALS> {};
@@ -249,6 +308,18 @@ template <int STAT> struct AccMoments {                                         
     const double y = (mean[1] - mean[0]) / sqrt(var[1] / n[1] + var[0] / n[0]);
     return k.under ? -y : y;
   }
+  __device__ double approx(i64 nc, const StatConsts &k) const                      // Calc*Statistic(approx = true): :305-308, :447-451
+  {
+    const double y = finish(nc, k);
+    if (STAT == GTX_STAT_RATIO) {
+      const double m = k.Vsum / k.nRows, v = k.Vsum2 / k.nRows;
+      return gauss_Q((m * y - m) / sqrt(v * (y * y) + v));
+    }
+    const i64 n1 = nc, n0 = k.nRows - nc;
+    double mean0 = (k.Vsum - m1) / n0, mean1 = m1 / n1;
+    const double var0 = (k.Vsum2 - v1) / n0 - mean0 * mean0, var1 = v1 / n1 - mean1 * mean1;
+    return welch_tail(y, var0 / n0, n0, var1 / n1, n1);
+  }
 };
 template <> struct Acc<GTX_STAT_RATIO, false> : AccMoments<GTX_STAT_RATIO> {};
 template <> struct Acc<GTX_STAT_T, false> : AccMoments<GTX_STAT_T> {};
@@ -263,6 +334,7 @@ template <> struct Acc<GTX_STAT_RATIO, true> {                                  
     const double mean0 = s0 / t0, mean1 = s1 / t1;
     return k.under ? mean0 / mean1 : mean1 / mean0;
   }
+  __device__ double approx(i64, const StatConsts &) const { return __builtin_nan(""); }      // ("not implemented yet" there, :475)
 };
 
 template <> struct Acc<GTX_STAT_T, true> {                                       // :309-329
@@ -283,6 +355,14 @@ template <> struct Acc<GTX_STAT_T, true> {                                      
     const double y = (mean[1] - mean[0]) / sqrt(varZ[1] / n[1] + varZ[0] / n[0]);
     return k.under ? -y : y;
   }
+  __device__ double approx(i64 nc, const StatConsts &k) const                      // :336-339
+  {
+    const double y = finish(nc, k);
+    const i64 n1 = nc, n0 = k.nRows - nc;
+    const double a0 = (k.VsumZ - z1) / n0, a1 = z1 / n1;
+    const double varZ0 = (k.Vsum2 - q1) / n0 - a0 * a0, varZ1 = q1 / n1 - a1 * a1;
+    return welch_tail(y, varZ0 / n0, n0, varZ1 / n1, n1);
+  }
 };
 
 template <bool TOTALS> struct Acc<GTX_STAT_CORR, TOTALS> {                       // :527-545, core.cpp:1535-1558
@@ -300,6 +380,11 @@ template <bool TOTALS> struct Acc<GTX_STAT_CORR, TOTALS> {                      
     y = fabs(y);
     return k.under ? 1.0 - y : y;
   }
+  __device__ double approx(i64 nc, const StatConsts &k) const                      // :542 (n is the list's length there, not VectorCorr's pair count)
+  {
+    const double y = finish(nc, k);
+    return tdist_Q(y * sqrt((double)(nc - 2) / (1 - y * y)), (double)(nc - 2));
+  }
 };
 
 enum { MODE_STAT = 0, MODE_GE = 1, MODE_RANK = 2 };
@@ -310,6 +395,7 @@ struct StatArgs {
   const float *Vp, *Vtp;          // slab(s) in the tile layout above, or (MODE_STAT) the plain value vectors
   i64 nCols, nPerm;               // permutations in this batch
   StatConsts k;
+  int approx;                     // MODE_STAT / MODE_RANK of ratio, t, corr: the statistic's approximate p-value (Acc::approx) instead of the statistic
   const double *Yobs;             // MODE_GE
   double *Yout;                   // MODE_STAT
   u64 *counts;
@@ -408,14 +494,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void perm_stat_kernel(StatArgs
   const i64 nc = a.colPtr[c + 1] - a.colPtr[c];
   if constexpr (MODE == MODE_RANK) {
     // approximate p-value by table, then its lower bound among the sorted observed ones
-    const double val = a.tab[a.tabPtr[c] + acc.kk];
+    double val;
+    if constexpr (STAT == GTX_STAT_N) val = a.tab[a.tabPtr[c] + acc.kk];
+    else val = acc.approx(nc, a.k);
     i64 lo = 0, hi = a.nCols;
     while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (a.sortedY[mid] < val) lo = mid + 1; else hi = mid; }
     if (valid && lo < a.nCols) atomicAdd(&a.counts[lo], 1ull);
   } else {
-    const double y = acc.finish(nc, a.k);
-    if constexpr (MODE == MODE_STAT) { if (j == 0) a.Yout[c] = y; }
+    if constexpr (MODE == MODE_STAT) { if (j == 0) a.Yout[c] = a.approx ? acc.approx(nc, a.k) : acc.finish(nc, a.k); }
     else {
+      const double y = acc.finish(nc, a.k);
       const u64 m = __ballot(valid && y >= a.Yobs[c]);
       if (lane == 0 && m) atomicAdd(&a.counts[c], (u64)__popcll(m));
     }
@@ -429,7 +517,8 @@ hipError_t launch_stat_mode(int mode, const StatArgs &a, unsigned grid, hipStrea
                          else perm_stat_kernel<STAT, TOTALS, HASVT, M, false><<<grid, 64 * kWavesPerBlock, 0, st>>>(a); } while (0)
   if (mode == MODE_STAT) GTX_STAT(MODE_STAT);
   else if (mode == MODE_GE) GTX_STAT(MODE_GE);
-  else if constexpr (STAT == GTX_STAT_N) GTX_STAT(MODE_RANK);
+  else if constexpr (STAT == GTX_STAT_N || STAT == GTX_STAT_T || STAT == GTX_STAT_CORR || (STAT == GTX_STAT_RATIO && !TOTALS)) GTX_STAT(MODE_RANK);
+  else return hipErrorInvalidValue;
 #undef GTX_STAT
   return hipGetLastError();
 }
@@ -537,6 +626,7 @@ int gtx_perm_set_table(gtx_perm *p, int64_t n_rows, int64_t n_cols, const int64_
   PCHK(p, hipSetDevice(p->device));
   p->nRows = -1;
   dfree(p->d_V); dfree(p->d_Vt); dfree(p->d_colPtr); dfree(p->d_rows); dfree(p->d_rows16); dfree(p->d_Y); dfree(p->d_counts);
+  dfree(p->d_tab); dfree(p->d_tabPtr); dfree(p->d_sortedY); p->capTab = 0;     // (sized by the table's categories)
   PCHK(p, hipMalloc(&p->d_V, sizeof(float) * n_rows));
   PCHK(p, hipMemcpy(p->d_V, V, sizeof(float) * n_rows, hipMemcpyHostToDevice));
   p->hasVt = Vtotal != nullptr;
@@ -593,6 +683,27 @@ int gtx_perm_statistic(gtx_perm *p, int stat, int under, double *Y)
   a.Vp = p->d_V; a.Vtp = p->d_Vt; a.nPerm = 1; a.Yout = p->d_Y; a.nParts = 1; a.part = 0;
   PCHK(p, launch_stat(stat, MODE_STAT, p->useTotals, p->hasVt, a, p->stream));
   PCHK(p, hipMemcpyAsync(Y, p->d_Y, sizeof(double) * p->nCols, hipMemcpyDeviceToHost, p->stream));
+  PCHK(p, hipStreamSynchronize(p->stream));
+  return GTX_OK;
+}
+
+static int check_approx(gtx_perm *p, int stat)
+{
+  if (int rc = check_stat(p, stat)) return rc;
+  if (stat == GTX_STAT_T || stat == GTX_STAT_CORR || (stat == GTX_STAT_RATIO && !p->useTotals)) return GTX_OK;
+  return pfail(p, GTX_E_ARG, "no distribution for this statistic (permutation_test.cpp:364, :387, :475, :502, :514: \"not implemented yet\"; `n` goes by table: gtx_perm_count_rank)");
+}
+
+int gtx_perm_statistic_approx(gtx_perm *p, int stat, int under, double *P)
+{
+  if (!p || !P) return GTX_E_ARG;
+  if (int rc = check_approx(p, stat)) return rc;
+  if (p->nCols == 0) return GTX_OK;
+  PCHK(p, hipSetDevice(p->device));
+  StatArgs a = base_args(p, under);
+  a.Vp = p->d_V; a.Vtp = p->d_Vt; a.nPerm = 1; a.Yout = p->d_Y; a.nParts = 1; a.part = 0; a.approx = 1;
+  PCHK(p, launch_stat(stat, MODE_STAT, p->useTotals, p->hasVt, a, p->stream));
+  PCHK(p, hipMemcpyAsync(P, p->d_Y, sizeof(double) * p->nCols, hipMemcpyDeviceToHost, p->stream));
   PCHK(p, hipStreamSynchronize(p->stream));
   return GTX_OK;
 }
@@ -746,6 +857,29 @@ int gtx_perm_count_rank(gtx_perm *p, int under, const int64_t *tab_ptr, const do
   StatArgs a = base_args(p, under);
   a.counts = p->d_counts; a.tabPtr = p->d_tabPtr; a.tab = p->d_tab; a.sortedY = p->d_sortedY;
   if (int rc = run_batches(p, GTX_STAT_N, MODE_RANK, a, false, seed, first_perm, n_perm)) return rc;
+  PCHK(p, hipMemcpyAsync(counts, p->d_counts, sizeof(u64) * p->nCols, hipMemcpyDeviceToHost, p->stream));
+  PCHK(p, hipStreamSynchronize(p->stream));
+  return GTX_OK;
+}
+
+int gtx_perm_count_rank_approx(gtx_perm *p, int stat, int under, const double *sortedY, uint64_t seed, int64_t first_perm, int64_t n_perm,
+                               uint64_t *counts)
+{
+  if (!p || !counts || !sortedY) return GTX_E_ARG;
+  if (int rc = check_approx(p, stat)) return rc;
+  if (first_perm < 0 || n_perm < 0) return pfail(p, GTX_E_ARG, "gtx_perm_count_rank_approx: negative permutation range");
+  for (i64 c = 0; c < p->nCols; c++) counts[c] = 0;
+  if (p->nCols == 0 || n_perm == 0) return GTX_OK;
+  PCHK(p, hipSetDevice(p->device));
+  if (!p->d_sortedY) {
+    dfree(p->d_tab); dfree(p->d_tabPtr); p->capTab = 0;
+    PCHK(p, hipMalloc(&p->d_sortedY, sizeof(double) * (p->nCols + 1)));
+  }
+  PCHK(p, hipMemcpyAsync(p->d_sortedY, sortedY, sizeof(double) * p->nCols, hipMemcpyHostToDevice, p->stream));
+  PCHK(p, hipMemsetAsync(p->d_counts, 0, sizeof(u64) * p->nCols, p->stream));
+  StatArgs a = base_args(p, under);
+  a.counts = p->d_counts; a.sortedY = p->d_sortedY; a.approx = 1;
+  if (int rc = run_batches(p, stat, MODE_RANK, a, stat_reads_totals(p, stat), seed, first_perm, n_perm)) return rc;
   PCHK(p, hipMemcpyAsync(counts, p->d_counts, sizeof(u64) * p->nCols, hipMemcpyDeviceToHost, p->stream));
   PCHK(p, hipStreamSynchronize(p->stream));
   return GTX_OK;

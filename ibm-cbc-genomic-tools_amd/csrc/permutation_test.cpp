@@ -7,10 +7,10 @@
 // RunApproxPermutations are one call each into the C ABI.  There is no CPU implementation of those
 // here: without a GPU the tool stops with an error.
 //
-// Outside this build: -a for the statistics whose approximation needs GSL distribution functions
-// (ratio, t, corr; for sum/sens/spec the reference itself says "not implemented yet").  `-S n -a`,
-// the form the reference's own example uses (examples/example06.tcsh), is supported: its
-// hypergeometric tail is a host-side table by (category size, k).
+// -a (p-values from a distribution, FDR from permutations of those): `-S n`, the form the reference's own example uses
+// (examples/example06.tcsh), goes by a host-side table of the hypergeometric tail by (category size, k); ratio (without totals),
+// t and corr evaluate their normal / Student tails on the device for every (category, permutation) -- the tails are defined in
+// include/gtx_perm.h (GSL is not linked); for sum / sens / spec / ratio with totals the reference itself says "not implemented yet".
 //
 // The seed of the permutations is getpid()+time(NULL) as in the reference (:557) unless the
 // environment variable GTX_PERM_SEED gives one; GTX_DEVICE picks the GPU.
@@ -82,7 +82,8 @@ class StringSets
   double *CalcStatistic(int stat);                                              // Calc*Statistic(approx = false)
   double *CalcHyperGeomApprox(const double *k_observed);                        // CalcHyperGeomStatistic(approx = true)
   double *RunPermutations(double *Y, long int n_permutations, int stat);
-  double *RunApproxPermutations(double *Y, long int n_permutations);           // -S n only
+  double *CalcApprox(int stat, const double *observed);                         // Calc*Statistic(approx = true)
+  double *RunApproxPermutations(double *Y, long int n_permutations, int stat);
   void PrintGOGenes(long int c) { for (int64_t z = col_ptr[c]; z < col_ptr[c + 1]; z++) printf("%s ", ROW_LABELS[rows[z]].c_str()); }
 
   long int n_rows, n_cols, n_values;
@@ -281,11 +282,23 @@ double *StringSets::RunPermutations(double *Y, long int n_permutations, int stat
   return pval;
 }
 
-double *StringSets::RunApproxPermutations(double *Y, long int n_permutations)
+double *StringSets::CalcApprox(int stat, const double *observed)
 {
-  BuildHyperTable();
+  if (stat == GTX_STAT_N) return CalcHyperGeomApprox(observed);
+  double *P = new double[n_cols + 1];
+  int rc = gtx_perm_statistic_approx(dev, stat, UNDER, P);
+  if (rc != GTX_OK) Die(rc, "gtx_perm_statistic_approx");
+  return P;
+}
+
+double *StringSets::RunApproxPermutations(double *Y, long int n_permutations, int stat)
+{
   std::vector<uint64_t> hist(n_cols + 1, 0);
-  int rc = gtx_perm_count_rank(dev, UNDER, tab_ptr.data(), tab.data(), Y, seed, 0, n_permutations, hist.data());
+  int rc;
+  if (stat == GTX_STAT_N) {
+    BuildHyperTable();
+    rc = gtx_perm_count_rank(dev, UNDER, tab_ptr.data(), tab.data(), Y, seed, 0, n_permutations, hist.data());
+  } else rc = gtx_perm_count_rank_approx(dev, stat, UNDER, Y, seed, 0, n_permutations, hist.data());
   if (rc != GTX_OK) Die(rc, "gtx_perm_count_rank");
   // :630-636 (counts are int there)
   std::vector<int> counts(n_cols + 1, 0);
@@ -347,15 +360,15 @@ int main(int argc, char *argv[])
   const int stat = StatId(STATISTIC);
   StringSets INPUT(MATRIX_FILE, VECTOR_FILE);
   if (stat < 0) { fprintf(stderr, "Error: unknown statistic '%s'!\n", STATISTIC); return 1; }
-  if (APPROX && stat != GTX_STAT_N) {
-    if (stat == GTX_STAT_SUM || stat == GTX_STAT_SENS || stat == GTX_STAT_SPEC) fprintf(stderr, "Error: not implemented yet!\n");   // the reference's own answer
-    else fprintf(stderr, "Error: -a with -S %s needs GSL distribution functions and is outside the MI355X path of this build!\n", STATISTIC);
+  // -a where the reference has no distribution (:364, :387, :475, :502, :514: raised in the first category's turn)
+  if (APPROX && INPUT.n_cols > 0 && (stat == GTX_STAT_SUM || stat == GTX_STAT_SENS || stat == GTX_STAT_SPEC || (stat == GTX_STAT_RATIO && INPUT.use_totals))) {
+    fprintf(stderr, "Error: not implemented yet!\n");
     return 1;
   }
 
   const long n_cols = INPUT.n_cols;
   double *VAL = INPUT.CalcStatistic(stat);
-  double *PVAL = APPROX ? INPUT.CalcHyperGeomApprox(VAL) : INPUT.RunPermutations(VAL, N_PERMUTATIONS, stat);
+  double *PVAL = APPROX ? INPUT.CalcApprox(stat, VAL) : INPUT.RunPermutations(VAL, N_PERMUTATIONS, stat);
 
   std::vector<int> R(n_cols);
   for (long c = 0; c < n_cols; c++) R[c] = (int)c;
@@ -365,7 +378,7 @@ int main(int argc, char *argv[])
 
   double *FDR;
   if (n_cols == 0) FDR = new double[1];
-  else if (APPROX) FDR = INPUT.RunApproxPermutations(SORTED.data(), N_PERMUTATIONS);
+  else if (APPROX) FDR = INPUT.RunApproxPermutations(SORTED.data(), N_PERMUTATIONS, stat);
   else {
     FDR = new double[n_cols];
     for (long k = 1, c = 0; c < n_cols; c++, k++) FDR[c] = SORTED[c] * n_cols / k;

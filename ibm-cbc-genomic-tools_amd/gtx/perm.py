@@ -22,6 +22,8 @@ ABI = {
     "gtx_perm_statistic": (_int, [_vp, _int, _int, _vp]),
     "gtx_perm_count_ge": (_int, [_vp, _int, _int, _vp, _u64, _i64, _i64, _vp]),
     "gtx_perm_count_rank": (_int, [_vp, _int, _vp, _vp, _vp, _u64, _i64, _i64, _vp]),
+    "gtx_perm_statistic_approx": (_int, [_vp, _int, _int, _vp]),
+    "gtx_perm_count_rank_approx": (_int, [_vp, _int, _int, _vp, _u64, _i64, _i64, _vp]),
     "gtx_perm_permutation": (_int, [_vp, _u64, _i64, _vp]),
     "gtx_perm_last_ms": (_int, [_vp, _vp, _vp]),
 }
@@ -142,6 +144,18 @@ class PermEngine:
         counts = np.empty(self.table.n_cols, dtype=np.uint64)
         self._check(self._lib.gtx_perm_count_rank(self._h, int(under), tab_ptr.ctypes.data, tab.ctypes.data, sorted_y.ctypes.data, int(seed),
                                                   int(first_perm), int(n_perm), counts.ctypes.data), "gtx_perm_count_rank")
+        return counts
+
+    def statistic_approx(self, stat, under=False):
+        P = np.empty(self.table.n_cols, dtype=np.float64)
+        self._check(self._lib.gtx_perm_statistic_approx(self._h, STAT[stat], int(under), P.ctypes.data), "gtx_perm_statistic_approx")
+        return P
+
+    def count_rank_approx(self, stat, sorted_y, seed, first_perm, n_perm, under=False):
+        sorted_y = np.ascontiguousarray(sorted_y, dtype=np.float64)
+        counts = np.empty(self.table.n_cols, dtype=np.uint64)
+        self._check(self._lib.gtx_perm_count_rank_approx(self._h, STAT[stat], int(under), sorted_y.ctypes.data, int(seed), int(first_perm),
+                                                         int(n_perm), counts.ctypes.data), "gtx_perm_count_rank_approx")
         return counts
 
     def permutation(self, seed, q):

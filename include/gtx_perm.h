@@ -5,7 +5,7 @@
  *   StringSets::Calc*Statistic     :280-545   (per-category statistic over the membership lists B[c][*])
  *   StringSets::RunPermutations    :555-572   (P x { permute, statistic, pval[c] += Y_random[c] >= Y[c] })
  *   StringSets::RunApproxPermutations :606-640 (P x { permute, approximate p-values, merge into the sorted
- *                                               observed ones }) for `-S n`
+ *                                               observed ones }) for `-S n`, ratio, t, corr
  * Everything else of that tool (reading the table, p-value -> FDR -> adjusted p-value arithmetic,
  * printing) is host C++ above this boundary (ibm-cbc-genomic-tools_amd/csrc/permutation_test.cpp).
  *
@@ -85,6 +85,24 @@ int gtx_perm_count_ge(gtx_perm *p, int stat, int under, const double *Y, uint64_
  * reference's sort + two-pointer merge produces (before its running sum, :631-634). */
 int gtx_perm_count_rank(gtx_perm *p, int under, const int64_t *tab_ptr, const double *tab, const double *sortedY, uint64_t seed,
                         int64_t first_perm, int64_t n_perm, uint64_t *counts);
+
+/* -a for ratio (without totals), t and corr (Calc*Statistic(approx = true) :305-308, :336-339, :447-451, :542 and the same
+ * RunApproxPermutations loop).  The reference turns the statistic into a p-value with gsl_cdf_ugaussian_Q / gsl_cdf_tdist_Q; GSL is
+ * not linked here, the two tails are DEFINED as
+ *   gauss_Q(x) = erfc(x / sqrt 2) / 2
+ *   tdist_Q(t, nu) = I_x(nu/2, 1/2) / 2 for t >= 0, 1 - that for t < 0, x = nu / (nu + t^2); NaN for nu <= 0 or t NaN; 0 / 1 at +-inf
+ * with the regularised incomplete beta function I_x(a, b) = x^a (1-x)^b / (a B(a, b)) * cf(a, b, x) by its continued fraction
+ * (modified Lentz), evaluated on the side of (a + 1) / (a + b + 2) where it converges fast (the other side through I_x(a, b) =
+ * 1 - I_(1-x)(b, a)); ln B by lgamma.  Against the exact function: ~1e-9 relative for nu <= 1e6 (tolerance parity with GSL by
+ * construction, like every tail probability of this build).  The degrees of freedom of t are `(long)floor(..)` there: a quotient
+ * that is NaN or out of range takes the `df < 0 ? 1.0` branch, as the conversion does on x86-64.
+ * gtx_perm_statistic_approx: P[c] = that p-value of the table as given -- computed on the device, so that an observed value and a
+ * permutation that reproduces its statistic compare equal.  gtx_perm_count_rank_approx: the histogram of gtx_perm_count_rank over
+ * the approximate p-values of the permutations (a NaN p-value has no smaller observed one: it falls at the front).
+ * GTX_E_ARG for sum / sens / spec / ratio with totals (the reference: "not implemented yet") and for `n` (by table, above). */
+int gtx_perm_statistic_approx(gtx_perm *p, int stat, int under, double *P);
+int gtx_perm_count_rank_approx(gtx_perm *p, int stat, int under, const double *sortedY, uint64_t seed, int64_t first_perm, int64_t n_perm,
+                               uint64_t *counts);
 
 /* out[r] = pi_q(r), r < n_rows of the current table (tests; the definition above) */
 int gtx_perm_permutation(gtx_perm *p, uint64_t seed, int64_t q, int32_t *out);

@@ -636,8 +636,15 @@ static int scan_unsorted(orc_chroms *chroms, orc_source *src, const orc_bounds *
 
 /* SortedGenomicRegionSetScanner::Next :4928-4957, restated as a generator that reports
  * (value, bounds index, strand, start, stop) rows through a callback.  Regions are pulled with the
- * sort check of GenomicRegionSet::Next(sorted_by_strand,...) (:3873-3882).  Only -op 1 is
- * restated: 'c' is rejected by the reference here (:4944) and 'p' advances twice (:4940,:4945). */
+ * sort check of GenomicRegionSet::Next(sorted_by_strand,...) (:3873-3882).  'c' is rejected by the
+ * reference here (:4944).  'p' (:4939-4942, the mappability input of `peaks`) adds the part of the
+ * region that lies in the micro-window and, as written there, moves on TWICE after a region that ends
+ * inside the micro-window (:4940 and again :4945 -- the region behind it is never looked at) and ONCE
+ * after a region that reaches beyond it, whose start it has set to stop + 1 by then (:4941): the rest of
+ * that region is dropped, and the order check of the pull (:3879) compares the next region with the
+ * moved start.  One case is left undefined by the reference: when the first of the two pulls meets the
+ * end of the stream the second one deletes the last region again (:3880 on a pointer :3858 no longer
+ * owns); here the walk simply ends. */
 typedef void (*orc_emit_fn)(void *ctx, long value, int bidx, char strand, long start, long stop);
 static int g_scan_err_at_open;                 /* the error came from the constructor's first read (:4882), not from a Next() */
 
@@ -660,7 +667,6 @@ static int scan_sorted(orc_chroms *chroms, orc_source *src, const orc_bounds *b,
                        int ignore_strand, char prep, orc_emit_fn emit, void *ctx)
 {
   if (size % step) { FAIL("Error: window size must be a multiple of window step in 'GenomicRegionSetScanner'!"); return -1; }
-  if (prep != '1') { FAIL("Error: [SortedGenomicRegionSetScanner] preprocess operator '%c' not supported!", prep); return -1; }
   long comb = size / step;
   long *ring = xmalloc(sizeof(long) * comb);
   orc_pull p; memset(&p, 0, sizeof p); p.chroms = chroms; p.src = src; p.by_strand = !ignore_strand;
@@ -682,7 +688,13 @@ static int scan_sorted(orc_chroms *chroms, orc_source *src, const orc_bounds *b,
         sum -= ring[k]; ring[k] = 0;
         while (p.have && chrom_cmp(chroms, p.cur.chrom, b->chrom[bi]) == 0 && (ignore_strand || p.cur.strand == strand) && front_start(&p.cur) <= stop) {
           if (p.cur.n_iv != 1) { FAIL("\nError: Line %ld: single-interval regions expected for this operation!\n", p.cur.n_line); rc = -1; break; }
-          ring[k] += label_value(&p.cur, max_label_value);
+          if (prep == 'p') {
+            long *iv = p.cur.iv1;
+            if (iv[1] <= stop) { ring[k] += iv[1] - iv[0] + 1; pull_next(&p); if (p.err) { rc = -1; break; } if (!p.have) break; }
+            else { ring[k] += stop - iv[0] + 1; iv[0] = stop + 1; }
+          }
+          else if (prep == '1') ring[k] += label_value(&p.cur, max_label_value);
+          else { FAIL("Error: [SortedGenomicRegionSetScanner] preprocess operator '%c' not supported!", prep); rc = -1; break; }
           pull_next(&p);
           if (p.err) { rc = -1; break; }
         }
@@ -962,21 +974,21 @@ static long count_regions(orc_chroms *ch, const char *file, long mlv)
 
 /* `late` (sorted scanners only): an error that one of the scanner's Next() calls meets does not end the run here -- its message
  * is kept in late[] and the windows returned before it in *out, for the caller to raise it at the call that meets it */
-static void scan_file(orc_chroms *ch, const orc_bounds *b, const char *file, int sorted, long dist, long win, long mlv, int ign, win_list *out, char *late)
+static void scan_file(orc_chroms *ch, const orc_bounds *b, const char *file, int sorted, char prep, long dist, long win, long mlv, int ign, win_list *out, char *late)
 {
   memset(out, 0, sizeof *out);
   if (late) late[0] = 0;
   orc_reader rd; if (reader_open(&rd, file)) die();
   orc_source src; memset(&src, 0, sizeof src); src.chroms = ch; src.rd = &rd;
   if (sorted) {
-    if (scan_sorted(ch, &src, b, dist, win, mlv, ign, '1', collect_emit, out)) {
+    if (scan_sorted(ch, &src, b, dist, win, mlv, ign, prep, collect_emit, out)) {
       if (!late || g_scan_err_at_open) die();
       snprintf(late, sizeof g_err, "%s", g_err); g_failed = 0; g_err[0] = 0;
     }
   }
   else {
     uint64_t **v;
-    if (scan_unsorted(ch, &src, b, dist, win, mlv, ign, 'c', &v)) die();
+    if (scan_unsorted(ch, &src, b, dist, win, mlv, ign, prep, &v)) die();
     int ns = ign ? 1 : 2;
     for (int i = 0; i < b->n; i++) for (int z = 0; z < ns; z++) {
       uint64_t *arr = v[i * ns + z];
@@ -1020,30 +1032,49 @@ static double compute_q_values(const double *pval, const double *pval_rnd, long 
 
 static double max_d(double x, double y) { return x > y ? x : y; }
 
-static int run_peaks(orc_chroms *ch, const orc_bounds *b, const char *signal, const char *control, int sorted, long dist, long win, long mlv,
+/* CalcRegSize (genomic_intervals.cpp:6032-6040): the sizes of the regions' intervals, summed over the file by the plain reader */
+static unsigned long reg_size(orc_chroms *ch, const char *file)
+{
+  orc_reader rd; if (reader_open(&rd, file)) die();
+  orc_source src; memset(&src, 0, sizeof src); src.chroms = ch; src.rd = &rd;
+  orc_region r; int k; unsigned long n = 0;
+  while ((k = source_next(&src, &r)) == 1) { const long *iv = RIV(&r); for (int i = 0; i < r.n_iv; i++) n += (unsigned long)(iv[2 * i + 1] - iv[2 * i] + 1); region_free(&r); }
+  if (k < 0) die();
+  reader_close(&rd);
+  return n;
+}
+
+static int run_peaks(orc_chroms *ch, const orc_bounds *b, const char *signal, const char *control, const char *uniq, int sorted, long dist, long win, long mlv,
                      int ign, long min_reads, const char *method, int norm, int cmp, double pval_cut, double qval_cut)
 {
   if (!control) { fprintf(stderr, "oracle: peaks without a control draws random numbers (genomic_scans.cpp:299) and is not restated\n"); return 2; }
-  unsigned long eff = 0; for (int i = 0; i < b->n; i++) eff += (unsigned long)b->len[i];            /* CalcBoundSize */
+  const char prep = (sorted || uniq) ? '1' : 'c';                                                   /* :236-237 */
+  unsigned long eff = 0;
+  if (uniq) eff = reg_size(ch, uniq);                                                               /* :242 */
+  else for (int i = 0; i < b->n; i++) eff += (unsigned long)b->len[i];                              /* CalcBoundSize */
   fprintf(stderr, "* Effective genome size = %lu\n", eff);
   long n_signal = count_regions(ch, signal, mlv);
   double p_signal = (double)n_signal / eff;
   /* the scanners advance in lockstep (:302-303, signal first): an input error of a sorted scanner surfaces at the Next() call that
    * reads the offending line, behind the three lines below; the other scanner's may come first */
-  static char s_late[sizeof g_err], c_late[sizeof g_err];
-  win_list S, C; scan_file(ch, b, signal, sorted, dist, win, mlv, ign, &S, s_late);
+  static char s_late[sizeof g_err], c_late[sizeof g_err], u_late[sizeof g_err];
+  win_list S, C, U; scan_file(ch, b, signal, sorted, prep, dist, win, mlv, ign, &S, s_late);
   long n_control = count_regions(ch, control, mlv);
   double p_control = (double)n_control / eff;
-  scan_file(ch, b, control, sorted, dist, win, mlv, ign, &C, c_late);
+  scan_file(ch, b, control, sorted, prep, dist, win, mlv, ign, &C, c_late);
   double p_ratio = p_signal / p_control;
   fprintf(stderr, "* Signal input file = %s (reads = %lu; background probability = %.2e)\n", signal, n_signal, p_signal);
   fprintf(stderr, "* Control input file = %s (reads = %lu; background probability = %.2e)\n", control, n_control, p_control);
   fprintf(stderr, "* Signal/Control background probability = %f\n", p_ratio);
+  /* the mappability track: always the sorted scanner, operator 'p', label values not used (:266-267); its first read happens here */
+  memset(&U, 0, sizeof U); u_late[0] = 0;
+  if (uniq) scan_file(ch, b, uniq, 1, 'p', dist, win, 1, ign, &U, u_late);
   long cap = 1024, n = 0; double *p1 = xmalloc(sizeof(double) * cap), *p2 = xmalloc(sizeof(double) * cap); long *idx = xmalloc(sizeof(long) * cap);
   for (long t = 0; ; t++) {
     if (t == S.n) { if (s_late[0]) { snprintf(g_err, sizeof g_err, "%s", s_late); die(); } break; }
     if (t == C.n && c_late[0]) { snprintf(g_err, sizeof g_err, "%s", c_late); die(); }
-    long v1 = S.w[t].value, v2 = C.w[t].value, v0 = win;
+    if (uniq && t == U.n && u_late[0]) { snprintf(g_err, sizeof g_err, "%s", u_late); die(); }
+    long v1 = S.w[t].value, v2 = C.w[t].value, v0 = uniq ? U.w[t].value : win;                      /* :300 */
     if (v1 > v0) v1 = v0;
     if (v2 > v0) v2 = v0;
     if (norm) { if (p_ratio < 1.0) v2 = (long)floor((float)v2 * p_ratio); else v1 = (long)floor((float)v1 / p_ratio); }
@@ -1184,8 +1215,8 @@ int main(int argc, char **argv)
       long tl = b.len[j]; b.len[j] = b.len[j - 1]; b.len[j - 1] = tl;
     }
   if (is_peaks) {
-    if (argc - a < 1) { fprintf(stderr, "usage: gtx_oracle peaks [OPTIONS] SIGNAL-REG-FILE CONTROL-REG-FILE\n"); return 1; }
-    return run_peaks(&ch, &b, argv[a], a + 1 < argc ? argv[a + 1] : NULL, sorted, dist, win, mlv, ign, min_reads, method, norm, cmp, pval_cut, qval_cut);
+    if (argc - a < 1) { fprintf(stderr, "usage: gtx_oracle peaks [OPTIONS] SIGNAL-REG-FILE CONTROL-REG-FILE [GENOME-UNIQ-REG-FILE]\n"); return 1; }
+    return run_peaks(&ch, &b, argv[a], a + 1 < argc ? argv[a + 1] : NULL, a + 2 < argc ? argv[a + 2] : NULL, sorted, dist, win, mlv, ign, min_reads, method, norm, cmp, pval_cut, qval_cut);
   }
   orc_reader rd; if (reader_open(&rd, a < argc ? argv[a] : NULL)) die();
   orc_source src; memset(&src, 0, sizeof src); src.chroms = &ch; src.rd = &rd;

@@ -162,7 +162,67 @@ static void mt_shuffle_idx(mt_state *s, int32_t *x, long n)
  * ------------------------------------------------------------------------------------------- */
 enum { STAT_SUM = 0, STAT_N, STAT_SENS, STAT_SPEC, STAT_RATIO, STAT_T, STAT_CORR };
 
-void porc_statistic(int stat, int under, int use_totals, int64_t n_rows, int64_t n_cols, const int64_t *col_ptr, const int32_t *rows,
+/* The distribution functions of -a for ratio / t / corr: gsl_cdf_ugaussian_Q and gsl_cdf_tdist_Q (permutation_test.cpp:307, :338, :450,
+ * :542).  GSL is an un-vendored dependency (gtools/Makefile:15, version unpinned) and absent here; what is restated is the published
+ * definition of the two tails: Q(x) = erfc(x / sqrt 2) / 2, and for Student's t with nu degrees of freedom
+ * Q(t) = I_x(nu/2, 1/2) / 2 for t >= 0 (1 minus that for t < 0), x = nu / (nu + t^2), with the regularised incomplete beta function
+ * by its continued fraction (modified Lentz) on the side of (a + 1) / (a + b + 2) where it converges fast.  GSL evaluates the same
+ * function by other routes (a Cornish-Fisher expansion for nu > 30): agreement with it is a matter of tolerance (~1e-10 relative),
+ * not of bits -- parity unpinned, like everything of this tool that touches GSL. */
+static double beta_cf(double a, double b, double x)
+{
+  const double tiny = 1e-300;
+  const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+  double c = 1.0, d = 1.0 - qab * x / qap;
+  if (fabs(d) < tiny) d = tiny;
+  d = 1.0 / d;
+  double h = d;
+  for (int m = 1; m <= 100000; m++) {
+    const double m2 = 2.0 * m;
+    double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+    d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+    c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+    d = 1.0 / d; h *= d * c;
+    aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+    d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+    c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+    d = 1.0 / d;
+    const double del = d * c;
+    h *= del;
+    if (fabs(del - 1.0) <= 2.220446049250313e-16) break;
+  }
+  return h;
+}
+/* I_x(a, b) with y = 1 - x given by the caller (no cancellation near x = 1) */
+static double ibeta_reg(double a, double b, double x, double y)
+{
+  if (!(x > 0.0)) return 0.0;
+  if (!(y > 0.0)) return 1.0;
+  const double lx = x < 0.5 ? log(x) : log1p(-y), ly = y < 0.5 ? log(y) : log1p(-x);
+  const double pre = exp(lgamma(a + b) - lgamma(a) - lgamma(b) + a * lx + b * ly);
+  if (x < (a + 1.0) / (a + b + 2.0)) return pre * beta_cf(a, b, x) / a;
+  return 1.0 - pre * beta_cf(b, a, y) / b;
+}
+double porc_tdist_Q(double t, double nu)
+{
+  if (t != t || !(nu > 0.0)) return NAN;
+  if (isinf(t)) return t > 0 ? 0.0 : 1.0;
+  const double t2 = t * t, den = nu + t2;
+  const double tail = 0.5 * ibeta_reg(0.5 * nu, 0.5, nu / den, t2 / den);
+  return t >= 0 ? tail : 1.0 - tail;
+}
+double porc_gauss_Q(double x) { return 0.5 * erfc(x / M_SQRT2); }
+
+/* (long int)floor(x) of :306 / :337 followed by `df < 0 ? 1.0 : tdist_Q(Y, df)`: a NaN or an out-of-range quotient converts to
+ * LONG_MIN on x86-64 (cvttsd2si), i.e. to the `1.0` branch */
+static double welch_tail(double y, double s0, long n0, double s1, long n1)
+{
+  const double dfd = floor(pow(s0 + s1, 2.0) / (pow(s0, 2.0) / (n0 - 1) + pow(s1, 2.0) / (n1 - 1)));
+  if (!(dfd >= 0.0) || dfd >= 9223372036854775808.0) return 1.0;
+  return porc_tdist_Q(y, (double)(long)dfd);
+}
+
+static void statistic_impl(int approx, int stat, int under, int use_totals, int64_t n_rows, int64_t n_cols, const int64_t *col_ptr, const int32_t *rows,
                     const float *V, const float *Vt, const double *sums, double *Y)
 {
   const double Vsum = sums[0], VsumZ = sums[1], Vsum2 = sums[2], Vtotal_sum = sums[3];
@@ -195,8 +255,14 @@ void porc_statistic(int stat, int under, int use_totals, int64_t n_rows, int64_t
         for (long z = 0; z < nc; z++) { int32_t r = B[z]; n[1]++; mean[1] += V[r]; var[1] += V[r] * V[r]; }   /* float product, as there */
         n[0] = n_rows - n[1]; mean[0] = Vsum - mean[1]; var[0] = Vsum2 - var[1];
         for (int k = 0; k <= 1; k++) { mean[k] /= n[k]; var[k] = var[k] / n[k] - mean[k] * mean[k]; }
-        if (stat == STAT_RATIO) Y[c] = under ? mean[0] / mean[1] : mean[1] / mean[0];
-        else { double y = (mean[1] - mean[0]) / sqrt(var[1] / n[1] + var[0] / n[0]); Y[c] = under ? -y : y; }
+        if (stat == STAT_RATIO) {
+          Y[c] = under ? mean[0] / mean[1] : mean[1] / mean[0];
+          if (approx) { double m = Vsum / n_rows, v = Vsum2 / n_rows; Y[c] = porc_gauss_Q((m * Y[c] - m) / sqrt(v * pow(Y[c], 2.0) + v)); }   /* :447-451 */
+        }
+        else {
+          double y = (mean[1] - mean[0]) / sqrt(var[1] / n[1] + var[0] / n[0]); Y[c] = under ? -y : y;
+          if (approx) Y[c] = welch_tail(Y[c], var[0] / n[0], n[0], var[1] / n[1], n[1]);                                                 /* :305-308 */
+        }
       } else if (stat == STAT_RATIO) {
         long n1 = 0; double sum[2] = {0, 0}, total[2] = {0, 0}, mean[2];
         for (long z = 0; z < nc; z++) { int32_t r = B[z]; n1++; sum[1] += V[r]; total[1] += Vt[r]; }
@@ -213,6 +279,7 @@ void porc_statistic(int stat, int under, int use_totals, int64_t n_rows, int64_t
         for (int k = 0; k <= 1; k++) { mean[k] = sum[k] / total[k]; varZ[k] = sumqZ[k] / n[k] - pow((double)sumZ[k] / n[k], 2.0); }
         double y = (mean[1] - mean[0]) / sqrt(varZ[1] / n[1] + varZ[0] / n[0]);
         Y[c] = under ? -y : y;
+        if (approx) Y[c] = welch_tail(Y[c], varZ[0] / n[0], n[0], varZ[1] / n[1], n[1]);                                                 /* :336-339 */
       }
       break;
     case STAT_CORR: {                                                                                    /* :527-545, core.cpp:1535-1558 */
@@ -224,10 +291,24 @@ void porc_statistic(int stat, int under, int use_totals, int64_t n_rows, int64_t
       Ex = Ex / C; Ey = Ey / C; Ex2 = Ex2 / C; Ey2 = Ey2 / C; Exy = Exy / C;
       double y = (Exy - Ex * Ey) / sqrt((Ex2 - pow(Ex, 2.0)) * (Ey2 - pow(Ey, 2.0)));
       y = fabs(y); Y[c] = under ? 1.0 - y : y;
+      if (approx) Y[c] = porc_tdist_Q(Y[c] * sqrt((nc - 2) / (1 - pow(Y[c], 2.0))), (double)(nc - 2));                                  /* :542 */
       break;
     }
     }
   }
+}
+
+void porc_statistic(int stat, int under, int use_totals, int64_t n_rows, int64_t n_cols, const int64_t *col_ptr, const int32_t *rows,
+                    const float *V, const float *Vt, const double *sums, double *Y)
+{
+  statistic_impl(0, stat, under, use_totals, n_rows, n_cols, col_ptr, rows, V, Vt, sums, Y);
+}
+
+/* Calc*Statistic(approx = true) for the statistics that have a distribution there: ratio without totals, t, corr */
+void porc_statistic_approx(int stat, int under, int use_totals, int64_t n_rows, int64_t n_cols, const int64_t *col_ptr, const int32_t *rows,
+                           const float *V, const float *Vt, const double *sums, double *P)
+{
+  statistic_impl(1, stat, under, use_totals, n_rows, n_cols, col_ptr, rows, V, Vt, sums, P);
 }
 
 /* hypergeometric upper tail P(X > k), X = successes in t draws from n1 successes + n2 failures
@@ -340,6 +421,29 @@ void porc_count_rank(int under, int64_t n_rows, int64_t n_cols, const int64_t *c
     }
   }
   free(Vp); free(idx); free(Yr); free(ps.cur);
+}
+
+/* the same for ratio / t / corr with -a (:612-627): the approximate p-values of every permutation, sorted, merged into the observed ones */
+void porc_count_rank_approx(int stat, int under, int use_totals, int64_t n_rows, int64_t n_cols, const int64_t *col_ptr, const int32_t *rows,
+                            const float *V, const float *Vt, const double *sums, const double *sortedY, int source, uint64_t seed,
+                            int64_t first_perm, int64_t n_perm, uint64_t *counts)
+{
+  float *Vp = malloc(sizeof(float) * (size_t)(n_rows + 1)), *Vtp = malloc(sizeof(float) * (size_t)(n_rows + 1));
+  int32_t *idx = malloc(sizeof(int32_t) * (size_t)(n_rows + 1));
+  double *Yr = malloc(sizeof(double) * (size_t)(n_cols + 1));
+  perm_src ps; ps.use_mt = source; ps.seed = seed; ps.cur = NULL;
+  if (source) { mt_seed(&ps.mt, (unsigned long)seed); ps.cur = malloc(sizeof(int32_t) * (size_t)(n_rows + 1)); for (int64_t r = 0; r < n_rows; r++) ps.cur[r] = (int32_t)r; }
+  for (int64_t c = 0; c < n_cols; c++) counts[c] = 0;
+  for (int64_t p = 0; p < n_perm; p++) {
+    apply_perm(&ps, first_perm + p, n_rows, V, Vt, Vp, Vtp, idx);
+    statistic_impl(1, stat, under, use_totals, n_rows, n_cols, col_ptr, rows, Vp, Vt ? Vtp : NULL, sums, Yr);
+    qsort(Yr, (size_t)n_cols, sizeof(double), cmp_double_ref);
+    for (int64_t z = 0, c = 0; z < n_cols && c < n_cols; c++) {
+      while (z < n_cols && sortedY[z] < Yr[c]) z++;
+      if (z < n_cols) counts[z]++;
+    }
+  }
+  free(Vp); free(Vtp); free(idx); free(Yr); free(ps.cur);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -534,14 +638,17 @@ int main(int argc, char **argv)
   else if (!strcmp(statistic, "corr")) stat = STAT_CORR;
   else { fprintf(stderr, "Error: unknown statistic '%s'!\n", statistic); return 1; }
   if (stat == STAT_CORR && !T.use_totals) { fprintf(stderr, "Error: this operation is not permitted!\n"); return 1; }
-  if (approx && stat != STAT_N) { fprintf(stderr, "Error: -a is restated for -S n only (the others need GSL distribution functions)\n"); return 1; }
+  /* -a where the reference has no distribution (:364, :387, :475, :502, :514: raised inside the first category's turn) */
+  if (approx && T.n_cols > 0 && (stat == STAT_SUM || stat == STAT_SENS || stat == STAT_SPEC || (stat == STAT_RATIO && T.use_totals))) { fprintf(stderr, "Error: not implemented yet!\n"); return 1; }
+  const int by_table = approx && stat == STAT_N;
 
   const long nc = T.n_cols;
   double *VAL = malloc(sizeof(double) * (size_t)(nc + 1)), *PVAL = malloc(sizeof(double) * (size_t)(nc + 1));
   const float *Vt = T.Vt;
   porc_statistic(stat, under, T.use_totals, T.n_rows, nc, T.col_ptr, T.rows, T.V, Vt, T.sums, VAL);
   int64_t *tab_ptr = NULL; double *tab = NULL;
-  if (approx) {
+  if (approx && !by_table) porc_statistic_approx(stat, under, T.use_totals, T.n_rows, nc, T.col_ptr, T.rows, T.V, Vt, T.sums, PVAL);
+  else if (approx) {
     tab_ptr = malloc(sizeof(int64_t) * (size_t)(nc + 1)); tab_ptr[0] = 0;
     for (long c = 0; c < nc; c++) tab_ptr[c + 1] = tab_ptr[c] + (T.col_ptr[c + 1] - T.col_ptr[c]) + 1;
     tab = malloc(sizeof(double) * (size_t)(tab_ptr[nc] + 1));
@@ -563,7 +670,8 @@ int main(int argc, char **argv)
   if (nc > 0) {
     if (approx) {                                                                     /* :612-640 */
       uint64_t *counts = malloc(sizeof(uint64_t) * (size_t)(nc + 1));
-      porc_count_rank(under, T.n_rows, nc, T.col_ptr, T.rows, T.V, tab_ptr, tab, SP, source, seed, 0, n_perm, counts);
+      if (by_table) porc_count_rank(under, T.n_rows, nc, T.col_ptr, T.rows, T.V, tab_ptr, tab, SP, source, seed, 0, n_perm, counts);
+      else porc_count_rank_approx(stat, under, T.use_totals, T.n_rows, nc, T.col_ptr, T.rows, T.V, Vt, T.sums, SP, source, seed, 0, n_perm, counts);
       for (long k = 1, c = 0; c < nc; c++, k++) { FDR[c] = (double)(int)counts[c] / n_perm / k; if (c + 1 < nc) counts[c + 1] += counts[c]; }
       free(counts);
     } else for (long k = 1, c = 0; c < nc; c++, k++) FDR[c] = SP[c] * nc / k;        /* :789-790 */

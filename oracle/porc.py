@@ -27,6 +27,12 @@ def lib():
         L.porc_statistic.argtypes = [_int, _int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
         L.porc_count_ge.argtypes = [_int, _int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _i64, _i64, _vp]
         L.porc_count_rank.argtypes = [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _i64, _i64, _vp]
+        L.porc_statistic_approx.argtypes = [_int, _int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.porc_count_rank_approx.argtypes = [_int, _int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _int, _u64, _i64, _i64, _vp]
+        L.porc_tdist_Q.restype = ctypes.c_double
+        L.porc_tdist_Q.argtypes = [ctypes.c_double, ctypes.c_double]
+        L.porc_gauss_Q.restype = ctypes.c_double
+        L.porc_gauss_Q.argtypes = [ctypes.c_double]
         L.porc_hypergeom_Q.restype = ctypes.c_double
         L.porc_hypergeom_Q.argtypes = [ctypes.c_long] * 4
         L.porc_hypergeom_table.argtypes = [_int, _i64, _i64, _vp, _vp, _vp, _vp]
@@ -73,6 +79,31 @@ def count_rank(t, tab_ptr, tab, sorted_y, seed, first_perm, n_perm, under=False,
                           tab_ptr.ctypes.data, tab.ctypes.data, sorted_y.ctypes.data, int(source), int(seed), int(first_perm),
                           int(n_perm), counts.ctypes.data)
     return counts
+
+
+def statistic_approx(t, stat, under=False):
+    """Calc*Statistic(approx = true) of ratio (without totals) / t / corr: the statistic's p-value under its distribution"""
+    P = np.empty(t.n_cols, dtype=np.float64)
+    lib().porc_statistic_approx(STAT[stat], int(under), int(t.use_totals), t.n_rows, t.n_cols, t.col_ptr.ctypes.data, t.rows.ctypes.data,
+                                t.V.ctypes.data, t.Vtotal.ctypes.data, t.sums.ctypes.data, P.ctypes.data)
+    return P
+
+
+def count_rank_approx(t, stat, sorted_y, seed, first_perm, n_perm, under=False, source=BIJECTION):
+    sorted_y = np.ascontiguousarray(sorted_y, dtype=np.float64)
+    counts = np.empty(t.n_cols, dtype=np.uint64)
+    lib().porc_count_rank_approx(STAT[stat], int(under), int(t.use_totals), t.n_rows, t.n_cols, t.col_ptr.ctypes.data, t.rows.ctypes.data,
+                                 t.V.ctypes.data, t.Vtotal.ctypes.data, t.sums.ctypes.data, sorted_y.ctypes.data, int(source), int(seed),
+                                 int(first_perm), int(n_perm), counts.ctypes.data)
+    return counts
+
+
+def tdist_Q(t, nu):
+    return lib().porc_tdist_Q(float(t), float(nu))
+
+
+def gauss_Q(x):
+    return lib().porc_gauss_Q(float(x))
 
 
 def hypergeom_Q(k, n1, n2, t):

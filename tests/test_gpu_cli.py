@@ -341,6 +341,72 @@ def test_peaks_cli_equals_oracle_cli(beds, args):
             assert len(got[1].splitlines()) >= 10      # the planted clusters are found
 
 
+@pytest.fixture(scope="module")
+def tracks(beds):
+    """mappability tracks in the scaled genome of `beds`, for the sorted scanner's operator 'p' (genomic_intervals.cpp:4939-4942)"""
+    rng = np.random.default_rng(41)
+    names = synth.CHROM_NAMES
+    lens = synth.CHROM_LEN // 50
+    def track(seed, n, gap_lo, gap_hi, len_lo, len_hi, strands=False, extra=None, disjoint=True):
+        r = np.random.default_rng(seed)
+        rows = []
+        for c in np.argsort(np.array(names)):                                       # chromosomes in strcmp order
+            for st in (("+", "-") if strands else ("+",)):
+                pos = int(r.integers(1, 500))
+                for _ in range(n):
+                    ln = int(r.integers(len_lo, len_hi))
+                    rows.append("%s\t%d\t%d\tm\t0\t%s" % (names[c], pos - 1, pos + ln - 1, st))
+                    pos += int(r.integers(gap_lo, gap_hi)) + (ln if disjoint else 0)    # the gap to the next region, or the distance of the starts
+                    if pos < 1: pos = 1
+                    if pos > lens[c] + 2000: break
+        if extra: extra(rows)
+        return "\n".join(rows) + "\n"
+    (beds / "uniq_disjoint.bed").write_text(track(1, 3000, 1, 4000, 5, 3000))            # regions that do not overlap
+    (beds / "uniq_dense.bed").write_text(track(2, 4000, 0, 40, 1, 300))                  # short regions side by side: most of them end inside their micro-window, every other one is never looked at
+    (beds / "uniq_overlapping.bed").write_text(track(3, 500, 1, 60, 20, 400, disjoint=False))   # sooner or later a moved start lies behind the next region's: the order error
+    (beds / "uniq_strand.bed").write_text(track(4, 1500, 1, 5000, 5, 3000, strands=True))
+    def bed12_mid(rows):                                                              # a spliced region in place of the middle row, same chromosome and start
+        f = rows[len(rows) // 2].split("\t")
+        rows[len(rows) // 2] = "%s\t%s\t%d\tx\t0\t+\t%s\t%d\t0\t2\t100,200\t0,600" % (f[0], f[1], int(f[1]) + 800, f[1], int(f[1]) + 800)
+    (beds / "uniq_bed12.bed").write_text(track(5, 600, 1, 5000, 5, 3000, extra=bed12_mid))
+    def unknown(rows):                                                                # two regions of a chromosome the genome file does not have, where they sort
+        k = next(i for i, l in enumerate(rows) if l.startswith("chr2\t"))
+        rows[k:k] = ["chr1_unplaced\t2\t300\tm\t0\t+", "chr1_unplaced\t5\t500\tm\t0\t+"]
+    (beds / "uniq_unknown_chrom.bed").write_text(track(6, 800, 1, 5000, 5, 3000, extra=unknown))
+    return beds
+
+
+MAPPABILITY_RUNS = [
+    (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "1000", "-min", "0", "uniq_disjoint.bed"]),
+    (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "500", "-d", "25", "-min", "1", "uniq_disjoint.bed"]),
+    (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "2000", "-d", "500", "-min", "0", "uniq_dense.bed"]),
+    (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "300", "-d", "100", "-min", "0", "uniq_overlapping.bed"]),     # the order error of a moved start, windows in front of it printed
+    (["counts", "-S", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "250", "-min", "1", "uniq_strand.bed"]),
+    (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "250", "-min", "1", "uniq_strand.bed"]),           # '-' regions behind '+' ones: not sorted by position
+    (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "500", "-min", "0", "uniq_bed12.bed"]),             # a spliced region: the error if the walk looks at it, nothing if it is skipped
+    (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "200", "-min", "0", "uniq_bed12.bed"]),
+    (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "500", "-min", "0", "uniq_unknown_chrom.bed"]),
+    (["counts", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "500", "-min", "0", "uniq_disjoint.bed"]),                # the unsorted scanner refuses the operator
+    (["peaks", "-i", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed", "uniq_disjoint.bed"]),
+    (["peaks", "-S", "-i", "-g", "genome.bed", "-w", "1000", "-d", "250", "-min", "5", "peaks_signal.bed", "peaks_control.bed", "uniq_dense.bed"]),
+    (["peaks", "-i", "-cmp", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed", "uniq_disjoint.bed"]),
+    (["peaks", "-g", "genome.bed", "-min", "6", "peaks_signal.bed", "peaks_control.bed", "uniq_strand.bed"]),
+    (["peaks", "-i", "-g", "genome.bed", "-w", "300", "-d", "100", "peaks_signal.bed", "peaks_control.bed", "uniq_overlapping.bed"]),   # the track's order error ends the run, behind the report lines
+]
+
+
+@pytest.mark.parametrize("args", MAPPABILITY_RUNS, ids=[" ".join(a) for a in MAPPABILITY_RUNS])
+def test_mappability_operator_equals_oracle_cli(tracks, args):
+    """the sorted scanner's operator 'p' -- `genomic_scans counts -S -op p` and the third input of `peaks` -- with the walk the
+    reference wrote (two pulls after a region that ends inside the micro-window, the moved start in the order check): stdout, stderr
+    and exit code of the oracle CLI"""
+    want = oracle(args, cwd=tracks)
+    got = product("scans", args, cwd=tracks)
+    assert got[0] == want[0], (got[2], want[2])
+    assert got[1] == want[1]
+    assert got[2].strip() == want[2].strip()
+
+
 def test_small_host_batches_give_the_same_output(beds, monkeypatch):
     """GTX_HOST_BATCH_READS=700: the input sets go to the device in dozens of batches through two buffers that are used in turn --
     totals that are summed over the batches (the label sums behind the background probability of `peaks`, the read count of `rpkm`)

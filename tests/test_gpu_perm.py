@@ -164,6 +164,50 @@ def test_approx_rank_histogram(pe, under):
     assert got.sum() <= 300 * t.n_cols
 
 
+def without_small_categories(t, kmin=5):
+    """the table without the categories of fewer than kmin rows (what -kmin does in the tool): t / corr have no degrees of freedom there"""
+    keep = [c for c in range(t.n_cols) if t.col_ptr[c + 1] - t.col_ptr[c] >= kmin]
+    col_ptr = np.zeros(len(keep) + 1, dtype=np.int64)
+    rows = []
+    for i, c in enumerate(keep):
+        rows.append(t.rows[t.col_ptr[c]:t.col_ptr[c + 1]]); col_ptr[i + 1] = col_ptr[i] + len(rows[-1])
+    return perm.PermTable(t.n_rows, col_ptr, np.concatenate(rows).astype(np.int32), t.V, t.Vtotal if t.has_totals else None, use_totals=t.use_totals)
+
+
+APPROX_CASES = [("t", "one-value"), ("t", "totals"), ("t", "normalised"), ("ratio", "normalised"), ("corr", "totals"), ("t", "signed")]
+
+
+@pytest.mark.parametrize("under", [False, True])
+@pytest.mark.parametrize("stat,shape", APPROX_CASES, ids=["%s-%s" % c for c in APPROX_CASES])
+def test_approximate_p_values_and_their_rank_histogram(pe, stat, shape, under):
+    """-a for ratio / t / corr (Calc*Statistic(approx = true) + RunApproxPermutations, permutation_test.cpp:305-308, :336-339, :447-451,
+    :542, :612-627): the observed p-values within 1e-12 of the oracle's (same arithmetic; the device's log / exp / lgamma / erfc differ
+    from the host's in the last bits), the rank histogram of 200 permutations against the oracle's sort + merge.  The histogram is
+    compared bin for bin: a p-value of a permutation would have to fall within those last bits of an observed one to move."""
+    t = without_small_categories(dict(tables())[shape])
+    pe.set_table(t)
+    want = porc.statistic_approx(t, stat, under)
+    got = pe.statistic_approx(stat, under)
+    assert not np.isnan(want).any()
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300)
+    sorted_y = np.sort(want, kind="stable")
+    h = pe.count_rank_approx(stat, sorted_y, 29, 0, 200, under)
+    np.testing.assert_array_equal(h, porc.count_rank_approx(t, stat, sorted_y, 29, 0, 200, under))
+    assert 0 < h.sum() <= 200 * t.n_cols
+    # shards of the permutation range add up
+    np.testing.assert_array_equal(pe.count_rank_approx(stat, sorted_y, 29, 0, 64, under) + pe.count_rank_approx(stat, sorted_y, 29, 64, 136, under), h)
+
+
+def test_approx_refused_where_the_reference_has_no_distribution(pe):
+    t = dict(tables())["totals"]
+    pe.set_table(t)
+    for stat in ("sum", "sens", "spec", "n", "ratio"):
+        with pytest.raises(Exception):
+            pe.statistic_approx(stat)
+        with pytest.raises(Exception):
+            pe.count_rank_approx(stat, np.zeros(t.n_cols), 1, 0, 10)
+
+
 def test_p_values_estimate_the_exact_hypergeometric_tail(pe):
     """-S n: P(k_perm >= k_obs) is a hypergeometric tail; 20000 permutations must land within 5 binomial
     standard errors of it for every category (statistical check of the permutation source on the device)."""
@@ -196,6 +240,8 @@ def run_both(args, seed):
     ["-S", "t", "-p", "150"],
     ["-h", "-S", "n", "-a", "-p", "200", "-q", "0.05"],
     ["-S", "n", "-a", "-u", "-p", "100"],
+    ["-h", "-S", "t", "-a", "-p", "150"],
+    ["-S", "t", "-a", "-u", "-p", "100", "-f"],
 ])
 def test_cli_matches_oracle_cli_one_value_table(args):
     a, b = run_both(args + [os.path.join(GOLD, "perm_go.txt")], seed=42)
@@ -213,6 +259,12 @@ def test_cli_matches_oracle_cli_one_value_table(args):
     ["-norm", "-S", "t", "-p", "100"],
     ["-norm", "-S", "ratio", "-p", "100"],
     ["-norm", "-S", "sum", "-v", "-p", "64"],
+    ["-S", "t", "-a", "-p", "100"],
+    ["-S", "corr", "-a", "-p", "100"],
+    ["-S", "corr", "-a", "-u", "-p", "64", "-f"],
+    ["-norm", "-S", "t", "-a", "-p", "100"],
+    ["-norm", "-S", "ratio", "-a", "-p", "100"],
+    ["-norm", "-S", "ratio", "-a", "-u", "-p", "100", "-q", "0.9"],
 ])
 def test_cli_matches_oracle_cli_two_value_table(args):
     a, b = run_both(args + [os.path.join(GOLD, "perm_go2.txt")], seed=7)
@@ -239,8 +291,9 @@ def test_cli_errors_like_the_reference():
     assert a.returncode == 1 and a.stderr == b.stderr == b"Error: unknown statistic 'bogus'!\n"
     a, b = run_both(["-norm", "-S", "corr", os.path.join(GOLD, "perm_go2.txt")], 1)
     assert a.returncode == 1 and a.stderr == b.stderr == b"Error: this operation is not permitted!\n"
-    a, _ = run_both(["-S", "sum", "-a", f], 1)
-    assert a.returncode == 1 and a.stderr == b"Error: not implemented yet!\n"
+    for args in (["-S", "sum", "-a", f], ["-S", "sens", "-a", f], ["-S", "ratio", "-a", os.path.join(GOLD, "perm_go2.txt")]):
+        a, b = run_both(args, 1)
+        assert a.returncode == 1 and a.stderr == b.stderr == b"Error: not implemented yet!\n"
 
 
 def test_cli_reader_rules_match_oracle(tmp_path):

@@ -158,6 +158,63 @@ def test_hypergeometric_tail_against_scipy():
     assert porc.hypergeom_Q(5, 5, 10, 7) == 0.0 and porc.hypergeom_Q(7, 9, 10, 7) == 0.0
 
 
+def test_student_and_normal_tails_against_scipy():
+    """the tails -a turns ratio / t / corr into p-values with (gsl_cdf_tdist_Q, gsl_cdf_ugaussian_Q there; defined in
+    include/gtx_perm.h here): within 1e-8 relative of scipy's over the range of degrees of freedom a table can produce"""
+    for nu in (1, 2, 3, 7, 29, 30, 31, 100, 999, 19990, 250000, 1e6):
+        for t in (-40, -3.3, -1.0, -1e-3, 0.0, 1e-9, 0.2, 1.0, 1.96, 3.0, 6.5, 25.0, 400.0):
+            want = stats.t.sf(t, nu)
+            assert porc.tdist_Q(t, nu) == pytest.approx(want, rel=1e-8, abs=1e-300), (t, nu)
+    assert porc.tdist_Q(float("inf"), 5) == 0.0 and porc.tdist_Q(float("-inf"), 5) == 1.0
+    assert np.isnan(porc.tdist_Q(1.0, 0)) and np.isnan(porc.tdist_Q(float("nan"), 3))
+    for x in (-8.0, -1.0, 0.0, 0.5, 2.0, 6.0, 30.0):
+        assert porc.gauss_Q(x) == pytest.approx(stats.norm.sf(x), rel=1e-12, abs=1e-300)
+
+
+def test_approximate_p_values_by_hand():
+    """Calc*Statistic(approx = true), permutation_test.cpp:305-308 (Welch's degrees of freedom, floored, then the t tail), :447-451
+    (ratio: a normal tail of (m Y - m) / sqrt(v Y^2 + v)), :542 (corr: t = r sqrt((n - 2) / (1 - r^2)) with n - 2 degrees of freedom),
+    evaluated here with numpy / scipy from the table's values"""
+    t = perm.PermTable.synthetic(400, 12, 30, seed=21, values="gamma")
+    tn = perm.PermTable(t.n_rows, t.col_ptr, t.rows, t.V, None, use_totals=False)
+    V = tn.V.astype(np.float64)
+    got_t, got_r = porc.statistic_approx(tn, "t"), porc.statistic_approx(tn, "ratio")
+    Vsum, Vsum2 = float(tn.sums[0]), float(tn.sums[2])
+    for c in range(tn.n_cols):
+        m = tn.rows[tn.col_ptr[c]:tn.col_ptr[c + 1]]
+        n1, n0 = len(m), tn.n_rows - len(m)
+        s1, q1 = V[m].sum(), (tn.V[m] * tn.V[m]).astype(np.float64).sum()
+        mean1, mean0 = s1 / n1, (Vsum - s1) / n0
+        var1, var0 = q1 / n1 - mean1 ** 2, (Vsum2 - q1) / n0 - mean0 ** 2
+        y = (mean1 - mean0) / np.sqrt(var1 / n1 + var0 / n0)
+        df = np.floor((var0 / n0 + var1 / n1) ** 2 / ((var0 / n0) ** 2 / (n0 - 1) + (var1 / n1) ** 2 / (n1 - 1)))
+        assert got_t[c] == pytest.approx(stats.t.sf(y, df), rel=1e-7)
+        r = mean1 / mean0
+        mm, vv = Vsum / tn.n_rows, Vsum2 / tn.n_rows
+        assert got_r[c] == pytest.approx(stats.norm.sf((mm * r - mm) / np.sqrt(vv * r * r + vv)), rel=1e-7)
+    t2 = perm.PermTable.synthetic(300, 10, 25, seed=22, values="normal", totals=True)
+    got_c = porc.statistic_approx(t2, "corr")
+    for c in range(t2.n_cols):
+        m = t2.rows[t2.col_ptr[c]:t2.col_ptr[c + 1]]
+        r = abs(np.corrcoef(t2.V[m].astype(np.float64), t2.Vtotal[m].astype(np.float64))[0, 1])
+        n = len(m)
+        if n <= 2: assert np.isnan(got_c[c]); continue                  # (no degrees of freedom left: 0/0 under the root, NaN as there)
+        assert got_c[c] == pytest.approx(stats.t.sf(r * np.sqrt((n - 2) / (1 - r * r)), n - 2), rel=1e-6)
+
+
+def test_rank_histogram_of_approximate_p_values_counts_every_pair_once():
+    """RunApproxPermutations :612-627 over t's approximate p-values: every (permutation, category) pair lands in one bin or beyond
+    the last observed value; the identity-like check: a histogram against an observed vector of zeros puts nothing anywhere"""
+    t = perm.PermTable.synthetic(500, 20, 30, seed=23, values="gamma")
+    tn = perm.PermTable(t.n_rows, t.col_ptr, t.rows, t.V, None, use_totals=False)
+    P = np.sort(porc.statistic_approx(tn, "t"), kind="stable")
+    h = porc.count_rank_approx(tn, "t", P, 5, 0, 50)
+    assert 0 < h.sum() <= 50 * tn.n_cols
+    # p-values of random permutations are roughly uniform: about half of them lie below the median observed one... of a uniform sample
+    assert porc.count_rank_approx(tn, "t", np.full(tn.n_cols, 2.0), 5, 0, 50)[0] == 50 * tn.n_cols      # everything is below 2: all in the first bin
+    assert porc.count_rank_approx(tn, "t", np.full(tn.n_cols, -1.0), 5, 0, 50).sum() == 0                # nothing is <= -1: beyond the last
+
+
 def test_permutation_p_values_estimate_exact_tail_with_both_sources():
     t = perm.PermTable.synthetic(1500, 60, 30, seed=3, values="binary")
     k = porc.statistic(t, "n")
