@@ -552,16 +552,22 @@ bool WriteGtx(LineSource *src, const char *out_path, PackError *err)
     any_label |= f.label != nullptr;
     n++;
   }
+  return WriteGtxColumns(out_path, names, n, cidx.data(), st.data(), en.data(), minus.data(), any_label ? lab.data() : nullptr, err);
+}
+
+bool WriteGtxColumns(const char *out_path, const std::vector<std::string> &names, uint64_t n, const uint16_t *cidx, const int32_t *st, const int32_t *en,
+                     const uint8_t *minus, const int32_t *lab, PackError *err)
+{
   FILE *o = fopen(out_path, "wb");
   if (!o) { SetErrPublic(err, 0, std::string("Error: cannot create file '") + out_path + "'!", true); return false; }
-  const uint32_t n_chrom = (uint32_t)names.size(), flags = any_label ? 1u : 0u;
+  const uint32_t n_chrom = (uint32_t)names.size(), flags = lab ? 1u : 0u;
   size_t off = 0;
   auto put = [&](const void *p, size_t bytes) { if (bytes) fwrite(p, 1, bytes, o); off += bytes; };
   auto pad = [&]() { static const char z[8] = {0}; const size_t k = Pad8(off) - off; if (k) put(z, k); };
   put(kGtxMagic, 8); put(&n_chrom, 4); put(&flags, 4); put(&n, 8);
   for (const std::string &nm : names) { const uint16_t len = (uint16_t)nm.size(); put(&len, 2); put(nm.data(), len); }
-  pad(); put(cidx.data(), 2 * n); pad(); put(st.data(), 4 * n); pad(); put(en.data(), 4 * n); pad(); put(minus.data(), minus.size()); pad();
-  if (any_label) { put(lab.data(), 4 * n); pad(); }
+  pad(); put(cidx, 2 * n); pad(); put(st, 4 * n); pad(); put(en, 4 * n); pad(); put(minus, (size_t)((n + 7) / 8)); pad();
+  if (lab) { put(lab, 4 * n); pad(); }
   const bool ok = fclose(o) == 0;
   if (!ok) SetErrPublic(err, 0, std::string("Error: cannot write file '") + out_path + "'!", true);
   return ok;

@@ -207,6 +207,9 @@ struct PackedBatch {
 
 // text -> packed file; lines are validated like GenomicRegionBED (token count, strand); returns false with *err set
 bool WriteGtx(LineSource *src, const char *out_path, PackError *err);
+// the same file from columns the caller holds (minus: one bit per record; lab may be NULL)
+bool WriteGtxColumns(const char *out_path, const std::vector<std::string> &names, uint64_t n, const uint16_t *cidx, const int32_t *st, const int32_t *en,
+                     const uint8_t *minus, const int32_t *lab, PackError *err);
 
 // Packs blocks of lines from `src` until about `target_reads` reads are in `out` or the input ends.
 // Returns false when the input is exhausted (out may still hold reads).  The first error in file

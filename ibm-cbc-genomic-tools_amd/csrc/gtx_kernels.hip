@@ -999,8 +999,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
 {
   count_walk_body<false, 4, false, true>(reads, weights, n, a);
 }
-// weighted reads: steps of 4 x 64 with the weights' prefix sums in LDS (walk_flipw4); the general code takes what does not qualify
-__global__ __launch_bounds__(256) void count_walk_kernel_weighted(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
+// weighted reads: steps of 4 x 64 with the weights' prefix sums in LDS (walk_flipw4); the general code takes what does not qualify.
+// (93 VGPRs = 5 waves per SIMD left alone; 80 = 6 without a spill when told to: 0.272 -> 0.268 ms on one box; 7 waves spill: 0.39)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(6, 6))) void count_walk_kernel_weighted(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CountArgs a)
 {
   count_walk_body<true, 4, true>(reads, weights, n, a);
 }
@@ -1273,9 +1274,8 @@ __device__ __forceinline__ void cov_chunk(CovState<WEIGHTED> &st, const CoverArg
   }
 }
 
-// (5 waves per SIMD at 90 VGPRs; forcing 6-8 with launch bounds + an SGPR cap spills and measured 3-8 % slower)
 template <bool WEIGHTED>
-__global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CoverArgs a)
+__device__ __forceinline__ void coverage_walk_body(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, const CoverArgs &a)
 {
   const int lane = threadIdx.x & 63;
   const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + rfl(threadIdx.x >> 6);
@@ -1395,6 +1395,19 @@ __global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restric
     if (st.nNoClass) atomicAdd((u64 *)&a.info->n_no_class, (u64)st.nNoClass);
     if (st.nDegen) { atomicAdd((u64 *)&a.info->n_degenerate, (u64)st.nDegen); atomicMin((i64 *)&a.info->first_degenerate, st.firstDegen + a.indexBase); }
   }
+}
+
+// Residency (same-box A/B, 100 M x 1 M, round 4): the unweighted kernel takes 92 VGPRs = 5 waves per SIMD left alone; forced to 6 it
+// spills four registers inside the loop and is 10 % SLOWER (0.363 against 0.327 ms), at 7 more so.  The weighted one takes 104 = 4
+// waves left alone and fits 80 without a spill when told to: 0.577 -> 0.504 ms.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void coverage_walk_kernel(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CoverArgs a)
+{
+  coverage_walk_body<WEIGHTED>(reads, weights, n, a);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(6, 6))) void coverage_walk_kernel_weighted(const Tri *__restrict__ reads, const int *__restrict__ weights, i64 n, CoverArgs a)
+{
+  coverage_walk_body<true>(reads, weights, n, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2027,7 +2040,7 @@ hipError_t launch_coverage(const void *reads, const void *weights, i64 n, const 
   if (n <= 0) return hipSuccess;
   const i64 waves = a.sched.nWaves;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  if (weights) coverage_walk_kernel<true><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
+  if (weights) coverage_walk_kernel_weighted<<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   else coverage_walk_kernel<false><<<grid, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a);
   return hipGetLastError();
 }

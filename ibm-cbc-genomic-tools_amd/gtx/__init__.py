@@ -92,6 +92,8 @@ ABI = {
     "gtx_scan_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]),
     "gtx_scan_add_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "gtx_scan_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_sort": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "gtx_sort_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "gtx_group_count_add_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "gtx_group_coverage_add_text": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "gtx_group_text_result": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -296,6 +298,18 @@ class Engine:
         info = CountInfo()
         self._chk(self.lib.gtx_last_info(self.ctx, ctypes.byref(info)))
         return info.as_dict()
+
+    def sort(self, reads, n_classes, want_sorted=True):
+        """gtx_sort: (order, sorted triples or None) under (class, start, stop descending, input order)"""
+        reads = _triples(reads)
+        order = np.empty(reads.shape[0], dtype=np.uint32)
+        out = np.empty_like(reads) if want_sorted else None
+        self._chk(self.lib.gtx_sort(self.ctx, _ptr(reads), reads.shape[0], int(n_classes), _ptr(order), _ptr(out)))
+        return order, out
+
+    def sort_device(self, d_reads, n_reads, n_classes, d_order, d_sorted=None):
+        """raw device addresses; returns when the result is complete"""
+        self._chk(self.lib.gtx_sort_device(self.ctx, _ptr(d_reads), int(n_reads), int(n_classes), _ptr(d_order), _ptr(d_sorted)))
 
     def scan(self, reads, class_len, win_step, win_size, preprocess="1", weights=None, flags=0):
         reads = _triples(reads)

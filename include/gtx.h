@@ -359,6 +359,17 @@ int gtx_group_count_add_text(gtx_group *g, const char *text, size_t bytes, int64
 int gtx_group_coverage_add_text(gtx_group *g, const char *text, size_t bytes, int64_t n_lines, const gtx_text_rules *rules, uint32_t flags, int *ticket);
 int gtx_group_text_result(gtx_group *g, int ticket, int *needs_host);
 
+/* Regions into position order on the device: what the reference's bin/sortbed (`sort -k1,1 -k2,2n`, or
+ * `-k1,1 -k6,6 -k2,2n`) and `genomic_regions gsort` (RunGlobalSort genomic_intervals.cpp:4547-4570 over BinGenomicRegions :6095-6150
+ * and CompareBinnedGenomicRegions :6044-6048) are run for -- the input order the sorted merge (:5807-5937) and the sorted scanner
+ * (:4928-4957) insist on.  order[i] = the input ordinal of the region that comes i-th under (class ascending, start ascending, stop
+ * DESCENDING, input order): gsort's order when the caller folds the chromosome's strcmp rank -- and, sorting by strand, the strand
+ * below it -- into the class.  sorted (may be NULL) receives the triples in that order.  n_reads < 2^32; a class id outside
+ * [0, n_classes) is GTX_E_RANGE.  No reference set is needed.  gtx_sort_device: reads, order (uint32[n_reads]) and sorted in the
+ * context's HBM; the call returns when the result is complete. */
+int gtx_sort(gtx_ctx *ctx, const int32_t *read_triples, int64_t n_reads, int32_t n_classes, uint32_t *order_out, int32_t *sorted_out);
+int gtx_sort_device(gtx_ctx *ctx, const void *d_reads, int64_t n_reads, int32_t n_classes, void *d_order, void *d_sorted);
+
 /* genomic_scans counts fed as a stream (UnsortedGenomicRegionSetScanner ctor genomic_intervals.cpp:5019-5080, sorted scanner :4928-4957):
  * gtx_scan_begin fixes the geometry (arguments as gtx_scan; flags: GTX_ZERO_LENGTH_OK = the sorted scanner's rule; weighted != 0: every
  * batch brings label weights), gtx_scan_add adds packed reads from host memory (flags: GTX_READS_UNSORTED as a hint), gtx_scan_add_text a

@@ -18,6 +18,9 @@
  *     hypergeometric tail.
  * The -a approximation of `-S n` needs gsl_cdf_hypergeometric_Q; porc_hypergeom_Q restates its
  * published algorithm (pmf from log-gamma, tail summed by the term ratio): tolerance parity only.
+ * -a for ratio / t / corr needs gsl_cdf_ugaussian_Q / gsl_cdf_tdist_Q: porc_gauss_Q / porc_tdist_Q hold the
+ * published definitions (erfc; the regularised incomplete beta function by its continued fraction), checked
+ * against scipy in tests/test_perm_oracle.py: tolerance parity only, again.
  */
 #include <math.h>
 #include <stdint.h>

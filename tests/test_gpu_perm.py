@@ -183,16 +183,19 @@ def test_approximate_p_values_and_their_rank_histogram(pe, stat, shape, under):
     """-a for ratio / t / corr (Calc*Statistic(approx = true) + RunApproxPermutations, permutation_test.cpp:305-308, :336-339, :447-451,
     :542, :612-627): the observed p-values within 1e-12 of the oracle's (same arithmetic; the device's log / exp / lgamma / erfc differ
     from the host's in the last bits), the rank histogram of 200 permutations against the oracle's sort + merge.  The histogram is
-    compared bin for bin: a p-value of a permutation would have to fall within those last bits of an observed one to move."""
+    compared bin for bin: a p-value of a permutation would have to fall within those last bits of an observed one WITHOUT being the
+    same statistic to move."""
     t = without_small_categories(dict(tables())[shape])
     pe.set_table(t)
     want = porc.statistic_approx(t, stat, under)
     got = pe.statistic_approx(stat, under)
     assert not np.isnan(want).any()
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300)
-    sorted_y = np.sort(want, kind="stable")
+    # each side ranks against ITS OWN observed values: a permutation that reproduces an observed statistic then gives exactly that
+    # p-value on either side (the tool takes the observed ones from the device for this reason)
+    sorted_y = np.sort(got, kind="stable")
     h = pe.count_rank_approx(stat, sorted_y, 29, 0, 200, under)
-    np.testing.assert_array_equal(h, porc.count_rank_approx(t, stat, sorted_y, 29, 0, 200, under))
+    np.testing.assert_array_equal(h, porc.count_rank_approx(t, stat, np.sort(want, kind="stable"), 29, 0, 200, under))
     assert 0 < h.sum() <= 200 * t.n_cols
     # shards of the permutation range add up
     np.testing.assert_array_equal(pe.count_rank_approx(stat, sorted_y, 29, 0, 64, under) + pe.count_rank_approx(stat, sorted_y, 29, 64, 136, under), h)
