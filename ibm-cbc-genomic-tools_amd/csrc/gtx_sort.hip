@@ -61,34 +61,35 @@ int sort_on_device(gtx_ctx *ctx, const int *d_tri, i64 n, int nClasses, uint32_t
 #define SCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gtxi_set_error(ctx, hipGetErrorString(e_)); return GTX_E_HIP; } } while (0)
   hipStream_t st = gtxi_stream(ctx);
   SCHK(hipSetDevice(gtxi_device(ctx)));
-  Scratch s;
-  u64 *key = nullptr, *key2 = nullptr, *key3 = nullptr; uint32_t *ks = nullptr, *ks2 = nullptr, *ord = nullptr, *ord2 = nullptr; unsigned *bad = nullptr;
-  SCHK(hipMalloc(&s.p[0], sizeof(u64) * n)); key = (u64 *)s.p[0];
-  SCHK(hipMalloc(&s.p[1], sizeof(u64) * n)); key2 = (u64 *)s.p[1];
-  SCHK(hipMalloc(&s.p[2], sizeof(uint32_t) * n)); ks = (uint32_t *)s.p[2];
-  SCHK(hipMalloc(&s.p[3], sizeof(uint32_t) * n)); ks2 = (uint32_t *)s.p[3];
-  SCHK(hipMalloc(&s.p[4], sizeof(uint32_t) * n)); ord = (uint32_t *)s.p[4];
-  SCHK(hipMalloc(&s.p[5], sizeof(uint32_t) * n)); ord2 = (uint32_t *)s.p[5];
-  SCHK(hipMalloc(&s.p[6], sizeof(unsigned))); bad = (unsigned *)s.p[6];
+  // one block of the context's scratch (kept between calls: a call of 100 M reads would otherwise spend more time giving 4 GB back to
+  // the driver than sorting), carved into the key, ordinal and digit-pass arrays
+  int classBits = 0;
+  while (classBits < 31 && (1ll << classBits) < (i64)nClasses) classBits++;
+  size_t t1 = 0, t2 = 0;
+  SCHK(rocprim::radix_sort_pairs(nullptr, t1, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, 32u, st));
+  SCHK(rocprim::radix_sort_pairs(nullptr, t2, (u64 *)nullptr, (u64 *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, 32u + (unsigned)classBits, st));
+  const size_t tmpBytes = t1 > t2 ? t1 : t2;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t k8 = up(sizeof(u64) * (size_t)n), k4 = up(sizeof(uint32_t) * (size_t)n);
+  char *blk = nullptr;
+  { void *q = nullptr; if (int rc = gtxi_scratch(ctx, 2 * k8 + 4 * k4 + up(tmpBytes) + 256, &q)) return rc; blk = (char *)q; }
+  u64 *key = (u64 *)blk, *key2 = (u64 *)(blk + k8), *key3 = nullptr;
+  uint32_t *ks = (uint32_t *)(blk + 2 * k8), *ks2 = (uint32_t *)(blk + 2 * k8 + k4), *ord = (uint32_t *)(blk + 2 * k8 + 2 * k4), *ord2 = (uint32_t *)(blk + 2 * k8 + 3 * k4);
+  void *tmp = blk + 2 * k8 + 4 * k4;
+  unsigned *bad = (unsigned *)(blk + 2 * k8 + 4 * k4 + up(tmpBytes));
   SCHK(hipMemsetAsync(bad, 0, sizeof(unsigned), st));
   const unsigned grid = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
   sort_keys_kernel<<<grid, 256, 0, st>>>(d_tri, n, nClasses, key, ks, ord, bad);
   SCHK(hipGetLastError());
-  int classBits = 0;
-  while (classBits < 31 && (1ll << classBits) < (i64)nClasses) classBits++;
-  size_t t1 = 0, t2 = 0;
-  SCHK(rocprim::radix_sort_pairs(nullptr, t1, ks, ks2, ord, ord2, (size_t)n, 0u, 32u, st));
-  SCHK(rocprim::radix_sort_pairs(nullptr, t2, key2, key, ord2, d_order, (size_t)n, 0u, 32u + (unsigned)classBits, st));
-  SCHK(hipMalloc(&s.p[7], t1 > t2 ? t1 : t2));
-  SCHK(rocprim::radix_sort_pairs(s.p[7], t1, ks, ks2, ord, ord2, (size_t)n, 0u, 32u, st));                 // by stop, descending
+  SCHK(rocprim::radix_sort_pairs(tmp, t1, ks, ks2, ord, ord2, (size_t)n, 0u, 32u, st));                 // by stop, descending
   sort_rekey_kernel<<<grid, 256, 0, st>>>(key, ord2, n, key2);
   SCHK(hipGetLastError());
   key3 = key;                                                                                            // (its keys are in key2 now)
-  SCHK(rocprim::radix_sort_pairs(s.p[7], t2, key2, key3, ord2, d_order, (size_t)n, 0u, 32u + (unsigned)classBits, st));   // by (class, start); stable
+  SCHK(rocprim::radix_sort_pairs(tmp, t2, key2, key3, ord2, d_order, (size_t)n, 0u, 32u + (unsigned)classBits, st));   // by (class, start); stable
   if (d_sorted) { sort_gather_kernel<<<grid, 256, 0, st>>>(d_tri, d_order, n, d_sorted); SCHK(hipGetLastError()); }
   unsigned h_bad = 0;
   SCHK(hipMemcpyAsync(&h_bad, bad, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-  SCHK(hipStreamSynchronize(st));                                                                        // (the scratch goes away with this frame)
+  SCHK(hipStreamSynchronize(st));
   if (h_bad) { gtxi_set_error(ctx, "gtx_sort: a class id outside [0, n_classes)"); return GTX_E_RANGE; }
   return GTX_OK;
 #undef SCHK

@@ -199,33 +199,52 @@ int main(int argc, char **argv)
   }
 
   if (out_gtx) {
-    // the sorted regions as a packed file: BED fields of every line, in the new order
-    std::vector<std::string> names; std::map<std::string, int> nameOf;
+    // the sorted regions as a packed file: BED fields of every line, in the new order (parsed by the threads, pieces of a multiple of
+    // eight records each: a strand bit per record)
     std::vector<uint16_t> cidx(n); std::vector<int32_t> st(n), en(n), lab(n); std::vector<uint8_t> minus((n + 7) / 8, 0);
-    bool any_label = false;
-    std::string copy;
-    for (size_t i = 0; i < n; i++) {
-      const Line &l = lines[order[i]];
-      copy.assign(l.p, l.len);
-      BedFields f; char *bad = nullptr;
-      const BedStatus s = ParseBedLine(&copy[0], &f, &bad);
-      const long line_no = (long)order[i] + 1;
-      if (s == BED_TOO_FEW_TOKENS) { fprintf(stderr, "\nError: Line %ld: number of tokens should be at least 3 for BED format!\n", line_no); return 1; }
-      if (s == BED_BAD_STRAND) { fprintf(stderr, "Error: invalid strand '%s'!\n", bad); return 1; }
-      if (f.n_tokens == 12) { fprintf(stderr, "\nError: Line %ld: multi-interval (BED12) regions do not fit a packed region file!\n", line_no); return 1; }
-      const long v = f.label ? atol(f.label) : 0;
-      if (f.start >= INT_MAX - 1 || f.stop >= INT_MAX - 1 || f.start <= INT_MIN + 1 || f.stop <= INT_MIN + 1 || v > INT_MAX || v < INT_MIN) {
-        fprintf(stderr, "\nError: Line %ld: coordinate or label value does not fit the packed 32-bit representation of the MI355X path!\n", line_no); return 1;
+    std::vector<std::vector<std::string>> localNames((size_t)T);
+    std::vector<uint32_t> localIdx(n);
+    struct Bad { long line = -1; std::string msg; };
+    std::vector<Bad> bad((size_t)T);
+    std::vector<char> anyLabel((size_t)T, 0);
+    auto piece = [&](int t) { return std::min(n, ((n * (size_t)t / T) + 7) & ~(size_t)7); };
+    ParallelFor(T, [&](int t) {
+      std::map<std::string, uint32_t> nameOf;
+      std::string copy;
+      const size_t lo = piece(t), hi = t + 1 == T ? n : piece(t + 1);
+      for (size_t i = lo; i < hi; i++) {
+        const Line &l = lines[order[i]];
+        copy.assign(l.p, l.len);
+        BedFields f; char *badTok = nullptr;
+        const BedStatus s = ParseBedLine(&copy[0], &f, &badTok);
+        const long line_no = (long)order[i] + 1;
+        auto fail = [&](const std::string &m) { if (bad[(size_t)t].line < 0) { bad[(size_t)t].line = line_no; bad[(size_t)t].msg = m; } };
+        if (s == BED_TOO_FEW_TOKENS) { fail("number of tokens should be at least 3 for BED format!"); return; }
+        if (s == BED_BAD_STRAND) { fail(std::string("invalid strand '") + badTok + "'!"); return; }
+        if (f.n_tokens == 12) { fail("multi-interval (BED12) regions do not fit a packed region file!"); return; }
+        const long v = f.label ? atol(f.label) : 0;
+        if (f.start >= INT_MAX - 1 || f.stop >= INT_MAX - 1 || f.start <= INT_MIN + 1 || f.stop <= INT_MIN + 1 || v > INT_MAX || v < INT_MIN) { fail("coordinate or label value does not fit the packed 32-bit representation of the MI355X path!"); return; }
+        auto it = nameOf.find(f.chrom);
+        if (it == nameOf.end()) { it = nameOf.emplace(f.chrom, (uint32_t)localNames[(size_t)t].size()).first; localNames[(size_t)t].push_back(f.chrom); }
+        localIdx[i] = it->second; st[i] = (int32_t)f.start; en[i] = (int32_t)f.stop; lab[i] = (int32_t)v;
+        if (f.strand == '-') minus[i >> 3] |= (uint8_t)(1u << (i & 7));
+        if (f.label) anyLabel[(size_t)t] = 1;
       }
-      auto it = nameOf.find(f.chrom);
-      if (it == nameOf.end()) {
-        if (names.size() >= 65535) { fprintf(stderr, "\nError: Line %ld: too many chromosomes for a packed region file!\n", line_no); return 1; }
-        it = nameOf.emplace(f.chrom, (int)names.size()).first; names.push_back(f.chrom);
+    });
+    for (const Bad &b : bad) if (b.line >= 0) { fprintf(stderr, "\nError: Line %ld: %s\n", b.line, b.msg.c_str()); return 1; }
+    std::vector<std::string> names; std::map<std::string, int> nameOf;
+    std::vector<std::vector<uint16_t>> toGlobal((size_t)T);
+    for (int t = 0; t < T; t++)
+      for (const std::string &nm : localNames[(size_t)t]) {
+        auto it = nameOf.find(nm);
+        if (it == nameOf.end()) {
+          if (names.size() >= 65535) { fprintf(stderr, "Error: too many chromosomes for a packed region file!\n"); return 1; }
+          it = nameOf.emplace(nm, (int)names.size()).first; names.push_back(nm);
+        }
+        toGlobal[(size_t)t].push_back((uint16_t)it->second);
       }
-      cidx[i] = (uint16_t)it->second; st[i] = (int32_t)f.start; en[i] = (int32_t)f.stop; lab[i] = (int32_t)v;
-      if (f.strand == '-') minus[i >> 3] |= (uint8_t)(1u << (i & 7));
-      any_label |= f.label != nullptr;
-    }
+    ParallelFor(T, [&](int t) { const size_t lo = piece(t), hi = t + 1 == T ? n : piece(t + 1); for (size_t i = lo; i < hi; i++) cidx[i] = toGlobal[(size_t)t][localIdx[i]]; });
+    bool any_label = false; for (char c : anyLabel) any_label |= c != 0;
     PackError e;
     if (!WriteGtxColumns(out_gtx, names, (uint64_t)n, cidx.data(), st.data(), en.data(), minus.data(), any_label ? lab.data() : nullptr, &e)) { fprintf(stderr, "%s\n", e.msg.c_str()); return 1; }
   } else {
