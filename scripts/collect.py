@@ -32,9 +32,9 @@ for t in ("share_timing.txt", "share_timing_1g.txt", "share_streams.txt", "membe
         shutil.copy(src + t, R + "profiles/%s_%s" % (rnd, t))
 if os.path.exists(src + "wave_trace.txt"):
     open(R + "profiles/%s_wave_trace.txt" % rnd, "w").write("".join(l for l in open(src + "wave_trace.txt") if l.startswith(("{", "alive", "streaming"))))
-for log in ("bench_bucket.log", "bench_cov.log", "bench_scan.log", "bench_covshuf.log", "bench_scanshuf.log", "bench_pairs.log"):
+for log in ("bench_bucket.log", "bench_cov.log", "bench_scan.log", "bench_covshuf.log", "bench_scanshuf.log", "bench_pairs.log", "bench_weighted.log", "bench_covw.log", "bench_sort.log"):
     if os.path.exists(src + log):
-        keep = [l for l in open(src + log) if ("bucket path" in l or "coverage:" in l or "coverage, " in l or "scan -w" in l or "bit-equal" in l or "per call" in l or "gtx_set_ref_blocks" in l or "gtx_count_add_regions" in l)]
+        keep = [l for l in open(src + log) if ("bucket path" in l or "coverage:" in l or "coverage, " in l or "scan -w" in l or "bit-equal" in l or "per call" in l or "gtx_set_ref_blocks" in l or "gtx_count_add_regions" in l or "weighted" in l or "gtx_sort_device" in l or "sortbed" in l or "LC_ALL" in l or l.startswith("sorted:"))]
         open(R + "profiles/%s_%s.txt" % (rnd, log[:-4]), "w").write("".join(keep))
 
 

@@ -28,6 +28,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_cov -- python
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_scanfine -- python3 scripts/bench_scan.py > $out/bench_scan.log 2>&1 && echo "scan geometry stats ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_covshuf -- python3 scripts/bench_cov_shuffled.py > $out/bench_covshuf.log 2>&1 && echo "coverage (shuffled reads) stats ok"
 python3 scripts/bench_scan_shuffled.py > $out/bench_scanshuf.log 2>&1 && echo "scans (shuffled reads) ok"
+python3 scripts/bench_weighted.py > $out/bench_weighted.log 2>&1 && echo "weighted count ok"
+python3 tests/tools/bench_coverage_weighted.py > $out/bench_covw.log 2>&1 && echo "weighted coverage ok"
+python3 scripts/bench_sort.py > $out/bench_sort.log 2>&1 && echo "sort ok"
 fi
 if want pmc; then
 step "pmc"
