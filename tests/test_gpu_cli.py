@@ -373,6 +373,12 @@ def tracks(beds):
         k = next(i for i, l in enumerate(rows) if l.startswith("chr2\t"))
         rows[k:k] = ["chr1_unplaced\t2\t300\tm\t0\t+", "chr1_unplaced\t5\t500\tm\t0\t+"]
     (beds / "uniq_unknown_chrom.bed").write_text(track(6, 800, 1, 5000, 5, 3000, extra=unknown))
+    # lines the reader refuses, in the middle of a track: met when the walk PULLS them (as the region behind one it looks at, or as the
+    # one its second pull steps over), with the windows in front of that point printed
+    def bad_strand(rows): rows[len(rows) * 3 // 5] = rows[len(rows) * 3 // 5].rsplit("\t", 1)[0] + "\tx"
+    (beds / "uniq_bad_strand.bed").write_text(track(7, 700, 1, 5000, 5, 3000, extra=bad_strand))
+    def two_columns(rows): rows[len(rows) * 3 // 10] = "\t".join(rows[len(rows) * 3 // 10].split("\t")[:2])
+    (beds / "uniq_two_columns.bed").write_text(track(8, 700, 1, 5000, 5, 3000, extra=two_columns))
     return beds
 
 
@@ -386,6 +392,8 @@ MAPPABILITY_RUNS = [
     (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "500", "-min", "0", "uniq_bed12.bed"]),             # a spliced region: the error if the walk looks at it, nothing if it is skipped
     (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "200", "-min", "0", "uniq_bed12.bed"]),
     (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "500", "-min", "0", "uniq_unknown_chrom.bed"]),
+    (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "500", "-min", "0", "uniq_bad_strand.bed"]),
+    (["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "250", "-min", "1", "uniq_two_columns.bed"]),
     (["counts", "-i", "-op", "p", "-g", "genome.bed", "-w", "1000", "-d", "500", "-min", "0", "uniq_disjoint.bed"]),                # the unsorted scanner refuses the operator
     (["peaks", "-i", "-g", "genome.bed", "peaks_signal.bed", "peaks_control.bed", "uniq_disjoint.bed"]),
     (["peaks", "-S", "-i", "-g", "genome.bed", "-w", "1000", "-d", "250", "-min", "5", "peaks_signal.bed", "peaks_control.bed", "uniq_dense.bed"]),
