@@ -415,6 +415,31 @@ def test_mappability_operator_equals_oracle_cli(tracks, args):
     assert got[2].strip() == want[2].strip()
 
 
+def test_mappability_track_of_a_million_regions(tmp_path):
+    """the operator 'p' at the size of a real track: 1 M regions over 24 chromosomes of the hg38 lengths (strcmp order), two window
+    geometries; stdout of the oracle CLI byte for byte (3.1 M and 12.4 M lines)"""
+    rng = np.random.default_rng(77)
+    names = np.array(synth.CHROM_NAMES)
+    order = np.argsort(names)
+    with open(tmp_path / "genome.bed", "w") as f:
+        for c in order:
+            f.write("%s\t0\t%d\n" % (names[c], synth.CHROM_LEN[c]))
+    with open(tmp_path / "track.bed", "w") as f:
+        for c in order:
+            n = int(1_000_000 * synth.CHROM_LEN[c] / synth.CHROM_LEN.sum())
+            gaps = rng.integers(1, 2 * int(synth.CHROM_LEN[c]) // n - 1200, size=n)
+            lens = rng.integers(1, 2400, size=n)
+            starts = np.cumsum(gaps + np.concatenate([[0], lens[:-1]]))
+            keep = starts + lens < synth.CHROM_LEN[c]
+            f.write("".join("%s\t%d\t%d\n" % (names[c], s, s + l) for s, l in zip(starts[keep], lens[keep])))
+    for geom in (["-w", "1000", "-d", "1000"], ["-w", "1000", "-d", "250"]):
+        args = ["counts", "-S", "-i", "-op", "p", "-g", "genome.bed"] + geom + ["-min", "0", "track.bed"]
+        want = oracle(args, cwd=tmp_path)
+        got = product("scans", args, cwd=tmp_path)
+        assert got[0] == want[0] == 0, (got[2], want[2])
+        assert got[1] == want[1] and len(got[1].splitlines()) > 3_000_000
+
+
 def test_small_host_batches_give_the_same_output(beds, monkeypatch):
     """GTX_HOST_BATCH_READS=700: the input sets go to the device in dozens of batches through two buffers that are used in turn --
     totals that are summed over the batches (the label sums behind the background probability of `peaks`, the read count of `rpkm`)

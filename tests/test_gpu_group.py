@@ -154,6 +154,11 @@ def test_cli_ngpu(tmp_path):
     one = run("genomic_scans", sargs, {})
     assert len(one) > 1000
     assert run("genomic_scans", [sargs[0], "--ngpu", "3"] + sargs[1:], {"GTX_GROUP_REHEARSE": "1"}) == one
+    # the sorted scanner's operator 'p' (a mappability track): the walk is the host's, its contributions are weighted point reads for the members
+    pargs = ["counts", "-S", "-i", "-op", "p", "-g", "genome.bed", "-w", "2000", "-d", "500", "-min", "1", "refs.bed"]
+    one = run("genomic_scans", pargs, {})
+    assert len(one) > 1000
+    assert run("genomic_scans", [pargs[0], "--ngpu", "3"] + pargs[1:], {"GTX_GROUP_REHEARSE": "1"}) == one
 
 
 # ---- round 3: HBM-resident group calls, members finalize their own share, pieces to member 0 -----------------------------

@@ -201,6 +201,28 @@ def test_approximate_p_values_and_their_rank_histogram(pe, stat, shape, under):
     np.testing.assert_array_equal(pe.count_rank_approx(stat, sorted_y, 29, 0, 64, under) + pe.count_rank_approx(stat, sorted_y, 29, 64, 136, under), h)
 
 
+def test_approx_rank_histogram_at_the_config5_table(pe):
+    """-S t -a at BASELINE config 5's table (20 k rows x 5 k categories): the rank histogram of 10 k permutations adds up over the
+    ranges a multi-GPU run deals out, a 16-permutation range against the oracle's sort + merge bin for bin, and every (category,
+    permutation) pair is counted once or falls beyond the largest observed value"""
+    t = without_small_categories(perm.PermTable.synthetic(20000, 5000, 200, seed=1, values="gamma"))
+    tn = perm.PermTable(t.n_rows, t.col_ptr, t.rows, t.V, None, use_totals=False)
+    pe.set_table(tn)
+    got = pe.statistic_approx("t")
+    want = porc.statistic_approx(tn, "t")
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-300)
+    sorted_y = np.sort(got, kind="stable")
+    whole = pe.count_rank_approx("t", sorted_y, 77, 0, 10000).astype(np.int64)
+    cuts = [0, 1250, 2563, 5000, 9999, 10000]
+    parts = sum(pe.count_rank_approx("t", sorted_y, 77, a, b - a).astype(np.int64) for a, b in zip(cuts[:-1], cuts[1:]))
+    np.testing.assert_array_equal(whole, parts)
+    assert 0 < whole.sum() <= 10000 * tn.n_cols
+    # p-values of random arrangements are close to uniform: about half of the pairs lie below the median observed p-value... of a
+    # uniform sample; here the observed ones are themselves a sample of the null, so the histogram's total is a large share of all pairs
+    assert whole.sum() > 0.5 * 10000 * tn.n_cols
+    np.testing.assert_array_equal(pe.count_rank_approx("t", sorted_y, 77, 5000, 16), porc.count_rank_approx(tn, "t", np.sort(want, kind="stable"), 77, 5000, 16))
+
+
 def test_approx_refused_where_the_reference_has_no_distribution(pe):
     t = dict(tables())["totals"]
     pe.set_table(t)
