@@ -123,19 +123,18 @@ __global__ __launch_bounds__(256) void perm_apply_kernel(const float *__restrict
 // -- against two 32-bit multiplies, a multiply-high and the shifts of fmix32 per round, which is what bounds perm_apply_kernel
 // (VALU).  Same arithmetic, same cycle walking: bit-identical images (include/gtx_perm.h).  lane = permutation (a row is one
 // coalesced 256-byte store of the tile), a wave takes kTabRows rows at a time so that their chains of LDS reads overlap.
-// 20 k rows x 10 k permutations: 0.67 ms against 0.75 for perm_apply_kernel -- ~80 vector instructions per row and lane instead of
-// ~145, but ten dependent LDS byte reads in their place; 2, 4 or 8 rows in flight per wave make no difference.
-// Layout: entry (round i, coordinate x, lane j) sits in word ((i * T + x) / 2) * 32 + j % 32, byte 2 * (x & 1) + j / 32 (T even):
-// a lane always reads bank j % 32, so the 32 lanes of a half-wave never meet in a bank whatever their coordinates are.
+// 20 k rows x 10 k permutations: 0.59 ms against 0.75 for perm_apply_kernel; 2, 4 or 8 rows in flight per wave make no difference.
+// Layout: a 32-bit word holds, for ONE coordinate x and a PAIR of rounds (2p, 2p + 1), the entries of lanes j % 32 and j % 32 + 32:
+// entry (round i, coordinate x, lane j) at byte ((i / 2 * T + x) * 32 + j % 32) * 4 + 2 (i & 1) + j / 32.  A lane always reads bank
+// j % 32 -- the 32 lanes of a half-wave never meet in a bank whatever their coordinates are -- and the address is linear in x: one
+// shift-add per lookup.  (Round 3 paired the coordinates 2x, 2x + 1 in a word instead: the same banks, but two more vector
+// instructions per lookup for the parity of x -- in a loop that is bound by their number: 0.65 ms.  One byte per entry in plain
+// [x][lane] order has the one-instruction address too and meets in banks: 0.59 ms.)
 constexpr int kTabMaxSide = 192, kTabRows = 4;
 
 __device__ __forceinline__ uint32_t tab_step(const unsigned char *__restrict__ tab, uint32_t base, uint32_t x)
 {
-  // ((x >> 1) << 7) + ((x & 1) << 1) + base = base + (x << 6) - 62 (x & 1): and, shift-add, multiply-add (written out: the compiler
-  // turns the product into a compare and a select, two more instructions in a loop that is bound by their number)
-  uint32_t at;
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(at) : "v"(x & 1u), "s"(-62), "v"((x << 6) + base));
-  return tab[at];
+  return tab[(x << 7) + base];                                       // one shift-add (the layout below)
 }
 
 __global__ __launch_bounds__(1024) void perm_apply_tab_kernel(const float *__restrict__ V, const float *__restrict__ Vt, float *__restrict__ Vp,
@@ -154,21 +153,32 @@ __global__ __launch_bounds__(1024) void perm_apply_tab_kernel(const float *__res
   for (uint32_t idx = threadIdx.x; idx < 64u * kRounds * T; idx += blockDim.x) {
     const uint32_t j = idx & 63u, y = idx >> 6, i = y / T, x = y - i * T;
     const uint32_t side = (i & 1) ? g.b : g.a;                        // even rounds move L (argument R < b), odd rounds move R (argument L < a)
-    tab[((y >> 1) * 32 + (j & 31u)) * 4 + ((y & 1u) << 1) + (j >> 5)] = (unsigned char)(((u64)fmix32(x + keys[j][i]) * side) >> 32);
+    tab[(((i >> 1) * T + x) << 7) + ((j & 31u) << 2) + ((i & 1u) << 1) + (j >> 5)] = (unsigned char)(((u64)fmix32(x + keys[j][i]) * side) >> 32);
   }
   __syncthreads();
   // (the wave's number as a scalar: the rows it takes, their grid cells and the addresses of their lines are then scalar work)
   const uint32_t lane = threadIdx.x & 63, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
   uint32_t base[kRounds];
 #pragma unroll
-  for (int i = 0; i < kRounds; i++) base[i] = (uint32_t)i * T * 64u + (lane & 31u) * 4u + (lane >> 5);
+  for (int i = 0; i < kRounds; i++) base[i] = (((uint32_t)i >> 1) * T << 7) + ((lane & 31u) << 2) + (((uint32_t)i & 1u) << 1) + (lane >> 5);
   const uint32_t r0 = blockIdx.y * rowsPerBlock, r1 = (uint32_t)min((u64)g.n, (u64)r0 + rowsPerBlock);
   const bool live = j0 + lane < nPerm;
   float *__restrict__ tile = Vp + (size_t)blockIdx.x * g.n * 64, *__restrict__ tileT = Vtp ? Vtp + (size_t)blockIdx.x * g.n * 64 : nullptr;
-  for (uint32_t rb = r0 + wv * kTabRows; rb < r1; rb += nw * kTabRows) {
+  // the grid cell of the wave's first row, stepped along with it (scalar work: no division per row)
+  const uint32_t stepRows = nw * kTabRows, stepL = stepRows / g.b, stepR = stepRows - stepL * g.b;
+  uint32_t cellL = (r0 + wv * kTabRows) / g.b, cellR = (r0 + wv * kTabRows) - cellL * g.b;
+  for (uint32_t rb = r0 + wv * kTabRows; rb < r1; rb += stepRows) {
     uint32_t L[kTabRows], R[kTabRows], x[kTabRows];
 #pragma unroll
-    for (int u = 0; u < kTabRows; u++) { const uint32_t r = min(rb + u, r1 - 1); L[u] = r / g.b; R[u] = r - L[u] * g.b; }
+    for (int u = 0; u < kTabRows; u++) {
+      // row rb + u = cell (cellL, cellR + u), one wrap at most (b >= 4 > u for n > 16); rows beyond the block's last stand in for row rb
+      const bool in = rb + u < r1;
+      uint32_t Ru = cellR + (in ? (uint32_t)u : 0u), Lu = cellL;
+      if (Ru >= g.b) { Ru -= g.b; Lu++; }
+      L[u] = Lu; R[u] = Ru;
+    }
+    cellR += stepR; cellL += stepL;
+    if (cellR >= g.b) { cellR -= g.b; cellL++; }
 #pragma unroll
     for (int i = 0; i < kRounds; i += 2) {
 #pragma unroll
@@ -196,6 +206,93 @@ __global__ __launch_bounds__(1024) void perm_apply_tab_kernel(const float *__res
       if (r < r1 && live) {
         tile[(size_t)r * 64 + lane] = V[x[u]];
         if (tileT) tileT[(size_t)r * 64 + lane] = Vt[x[u]];
+      }
+    }
+  }
+}
+
+// The slab writer once more, for value vectors that fit the LDS NEXT to the table: with the rounds tabulated, what is left of a row's
+// cost is the gather V[image] -- 64 lanes, 64 different cache lines of an 80 KB vector, one line per cycle through the CU's L1:
+// ~62 cycles per row and wave, more than the ten table reads and their arithmetic together.  So a block takes HALF a tile -- 32
+// permutations: the table is then 12 bytes per (coordinate, permutation) = 384 T bytes (54 KB at 20 k rows) -- and keeps the
+// whole value vector in LDS beside it (80 KB): the gather becomes one LDS read per row and lane.  A wave's lanes 0-31 hold one row
+// and lanes 32-63 the next (two 128-byte halves of two of the tile's lines per store).  Table layout: word ((i / 4) * T + x) * 32 + j
+// holds the entries of rounds 4 (i / 4) .. + 3 for coordinate x and permutation j: a lane reads bank j whatever x is, and the
+// address is linear in x.  Same arithmetic, same cycle walking: bit-identical slabs.  20 k rows x 10 k permutations, same box:
+// 0.48 ms against 0.60 for the 64-permutation table with the values gathered from memory (eight rows in flight per lane instead
+// of four: 0.52).
+__global__ __launch_bounds__(1024) void perm_apply_tabv_kernel(const float *__restrict__ V, const float *__restrict__ Vt, float *__restrict__ Vp,
+                                                               float *__restrict__ Vtp, PermGeom g, uint32_t rowsPerBlock, u64 seed,
+                                                               i64 firstPerm, i64 nPerm, uint32_t T)
+{
+  extern __shared__ unsigned char tabv[];                           // 3 * T * 128 bytes of table, then n floats
+  __shared__ uint32_t keys[32][kRounds];
+  constexpr uint32_t kGroups = (kRounds + 3) / 4;
+  float *__restrict__ Vs = (float *)(tabv + (size_t)kGroups * T * 128);
+  const i64 j0 = (i64)blockIdx.x * 32;
+  if (threadIdx.x < 32) {
+    PermKeys k; perm_keys_init(k, seed, (u64)(firstPerm + j0 + threadIdx.x), g.n);
+#pragma unroll
+    for (int i = 0; i < kRounds; i++) keys[threadIdx.x][i] = k.key[i];
+  }
+  for (uint32_t r = threadIdx.x; r < g.n; r += blockDim.x) Vs[r] = V[r];
+  __syncthreads();
+  for (uint32_t idx = threadIdx.x; idx < 32u * kRounds * T; idx += blockDim.x) {
+    const uint32_t j = idx & 31u, y = idx >> 5, i = y / T, x = y - i * T;
+    const uint32_t side = (i & 1) ? g.b : g.a;
+    tabv[(((i >> 2) * T + x) << 7) + (j << 2) + (i & 3u)] = (unsigned char)(((u64)fmix32(x + keys[j][i]) * side) >> 32);
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63, half = lane >> 5, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  uint32_t base[kRounds];
+#pragma unroll
+  for (int i = 0; i < kRounds; i++) base[i] = (((uint32_t)i >> 2) * T << 7) + ((lane & 31u) << 2) + ((uint32_t)i & 3u);
+  const uint32_t r0 = blockIdx.y * rowsPerBlock, r1 = (uint32_t)min((u64)g.n, (u64)r0 + rowsPerBlock);
+  const bool live = j0 + (lane & 31u) < nPerm;
+  const size_t tileOff = (size_t)(j0 >> 6) * g.n * 64 + (size_t)(j0 & 32) + (lane & 31u);     // (this lane's column of the 64-permutation tile)
+  float *__restrict__ tile = Vp + tileOff, *__restrict__ tileT = Vtp ? Vtp + tileOff : nullptr;
+  constexpr uint32_t kRowsPerStep = 2 * kTabRows;                   // rows a wave takes per step: slot u of a lane is row rb + 2 u + half
+  const uint32_t stepRows = nw * kRowsPerStep, stepL = stepRows / g.b, stepR = stepRows - stepL * g.b;
+  uint32_t cellL = (r0 + wv * kRowsPerStep) / g.b, cellR = (r0 + wv * kRowsPerStep) - cellL * g.b;
+  for (uint32_t rb = r0 + wv * kRowsPerStep; rb < r1; rb += stepRows) {
+    uint32_t L[kTabRows], R[kTabRows], x[kTabRows];
+#pragma unroll
+    for (int u = 0; u < kTabRows; u++) {
+      const uint32_t off = 2u * (uint32_t)u + half;                  // < 8 <= 2 b: two wraps at most (b >= 4 for n > 16)
+      uint32_t Ru = cellR + (rb + off < r1 ? off : 0u), Lu = cellL; // rows beyond the block's last stand in for row rb
+      if (Ru >= g.b) { Ru -= g.b; Lu++; }
+      if (Ru >= g.b) { Ru -= g.b; Lu++; }
+      L[u] = Lu; R[u] = Ru;
+    }
+    cellR += stepR; cellL += stepL;
+    if (cellR >= g.b) { cellR -= g.b; cellL++; }
+#pragma unroll
+    for (int i = 0; i < kRounds; i += 2) {
+#pragma unroll
+      for (int u = 0; u < kTabRows; u++) { L[u] += tab_step(tabv, base[i], R[u]); L[u] = min(L[u], L[u] - g.a); }
+#pragma unroll
+      for (int u = 0; u < kTabRows; u++) { R[u] += tab_step(tabv, base[i + 1], L[u]); R[u] = min(R[u], R[u] - g.b); }
+    }
+    bool spare = false;
+#pragma unroll
+    for (int u = 0; u < kTabRows; u++) { x[u] = L[u] * g.b + R[u]; spare |= x[u] >= g.n; }
+    if (__builtin_amdgcn_ballot_w64(spare)) {
+      for (int u = 0; u < kTabRows; u++) {
+        while (x[u] >= g.n) {                                         // cycle walking
+          for (int i = 0; i < kRounds; i += 2) {
+            L[u] += tab_step(tabv, base[i], R[u]); L[u] = min(L[u], L[u] - g.a);
+            R[u] += tab_step(tabv, base[i + 1], L[u]); R[u] = min(R[u], R[u] - g.b);
+          }
+          x[u] = L[u] * g.b + R[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kTabRows; u++) {
+      const uint32_t r = rb + 2u * (uint32_t)u + half;
+      if (r < r1 && live) {
+        tile[(size_t)r * 64] = Vs[x[u]];
+        if (tileT) tileT[(size_t)r * 64] = Vt[x[u]];
       }
     }
   }
@@ -764,21 +861,30 @@ static int run_batches(gtx_perm *p, int stat, int mode, StatArgs a, bool needVt,
     if (!noTab && g.n > 16 && T <= (uint32_t)kTabMaxSide) {
       // one block per tile of 64 permutations and row range (one block per CU at a time: the table takes most of the LDS); the number
       // of row ranges balances full rounds of blocks over the CUs against tabulating once more per range
-      const size_t lds = (size_t)64 * kRounds * T;
       static gtx::PerDevice attr;
-      PCHK(p, attr.once([] { return hipFuncSetAttribute((const void *)perm_apply_tab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); }));
-      const unsigned tiles = (unsigned)((cnt + 63) / 64);
+      PCHK(p, attr.once([] {
+        hipError_t e = hipFuncSetAttribute((const void *)perm_apply_tab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        return e != hipSuccess ? e : hipFuncSetAttribute((const void *)perm_apply_tabv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+      }));
+      // the value vector in LDS beside a 32-permutation table, where both fit (perm_apply_tabv_kernel)
+      const size_t ldsV = (size_t)((kRounds + 3) / 4) * T * 128 + sizeof(float) * (size_t)p->nRows;
+      const bool noV = getenv("GTX_PERM_NO_LDS_VALUES") != nullptr;                        // (the tests compare the writers)
+      const bool useV = !noV && ldsV <= 154 * 1024;
+      const size_t lds = useV ? ldsV : (size_t)64 * kRounds * T;
+      const unsigned tiles = useV ? (unsigned)((cnt + 31) / 32) : (unsigned)((cnt + 63) / 64);
       int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device);
       const unsigned maxChunks = (unsigned)std::max<i64>(1, p->nRows / 1024);
       unsigned chunks = 1; double best = 1e300;
       for (unsigned c = 1; c <= maxChunks && c <= 64; c++) {
         // rounds of blocks over the CUs x (rows of a block + what tabulating costs in rows: ~5.5 T by instruction count)
-        const double cost = ceil((double)tiles * c / cus) * ((double)p->nRows / c + 5.5 * T);
+        const double cost = ceil((double)tiles * c / cus) * ((double)p->nRows / c + (useV ? 2.75 * T + p->nRows / 40.0 : 5.5 * T));   // (staging the values: ~n / 40 rows' worth)
         if (cost < best) { best = cost; chunks = c; }
       }
       if (getenv("GTX_PERM_CHUNKS")) chunks = (unsigned)std::max(1, atoi(getenv("GTX_PERM_CHUNKS")));
       const uint32_t rpbT = (uint32_t)((p->nRows + chunks - 1) / chunks);
-      perm_apply_tab_kernel<<<dim3(tiles, (unsigned)((p->nRows + rpbT - 1) / rpbT)), 1024, lds, p->stream>>>(
+      if (useV) perm_apply_tabv_kernel<<<dim3(tiles, (unsigned)((p->nRows + rpbT - 1) / rpbT)), 1024, lds, p->stream>>>(
+          p->d_V, needVt ? p->d_Vt : nullptr, p->d_Vp, needVt ? p->d_Vtp : nullptr, g, rpbT, seed, first_perm + done, cnt, T);
+      else perm_apply_tab_kernel<<<dim3(tiles, (unsigned)((p->nRows + rpbT - 1) / rpbT)), 1024, lds, p->stream>>>(
           p->d_V, needVt ? p->d_Vt : nullptr, p->d_Vp, needVt ? p->d_Vtp : nullptr, g, rpbT, seed, first_perm + done, cnt, T);
     } else {
       uint32_t rpb = 128;                                              // rows per block; grid.y stays below 65536

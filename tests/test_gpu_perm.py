@@ -114,11 +114,15 @@ def test_tabulated_and_direct_slab_writers_agree(pe, monkeypatch, n_rows):
         for stat in ("sum", "t"):
             Y = pe.statistic(stat)
             monkeypatch.delenv("GTX_PERM_NO_TABLE", raising=False)
-            a = pe.count_ge(stat, Y, 31, 3, 333)
+            a = pe.count_ge(stat, Y, 31, 3, 333)                 # (value vector in LDS beside a 32-permutation table where both fit: 1500 and 20000 rows)
+            monkeypatch.setenv("GTX_PERM_NO_LDS_VALUES", "1")
+            c = pe.count_ge(stat, Y, 31, 3, 333)                 # (64-permutation table, values gathered from memory)
+            monkeypatch.delenv("GTX_PERM_NO_LDS_VALUES")
             monkeypatch.setenv("GTX_PERM_NO_TABLE", "1")
             b = pe.count_ge(stat, Y, 31, 3, 333)
             monkeypatch.delenv("GTX_PERM_NO_TABLE")
             np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(c, b)
             np.testing.assert_array_equal(pe.count_ge(stat, Y, 31, 3, 20), porc.count_ge(t, stat, Y, 31, 3, 20))
 
 
