@@ -1085,18 +1085,22 @@ __device__ __forceinline__ i64 prev64(i64 v) { return (i64)(((u64)(unsigned)lane
 // The same step for weighted reads: what a slot receives is the weight and the weight x key of its keys, so the LDS holds the
 // exclusive prefix sums of w (ldsW, stored once per step by the caller: both windows of a launch share it) and of
 // w x (key - kbase) (ldsWK, per window), in 64 bits -- no bound on the label values.
-template <class WIN>
+// SHIFTED (as cov_step4_run): this window's keys are the keys the other window has just staged plus the wave-uniform `shift`, so ldsK and
+// ldsWK are that window's and `run` its total (passed in); otherwise `run` goes out for such a second window.
+template <bool SHIFTED, class WIN>
 __device__ __forceinline__ void cov_step4_run_w(WIN &X, const Seg &sg, const int (&k)[4], const int (&w)[4], i64 totalW, int lane, bool &valid,
-                                                int *ldsK, const i64 *ldsW, i64 *ldsWK)
+                                                int *ldsK, const i64 *ldsW, i64 *ldsWK, i64 &run, int shift = 0)
 {
   const int kbase = rdlane(k[0], 0);
-  i64 run = 0;                                                   // sum of w x relative key of the registers below
+  if constexpr (!SHIFTED) {
+    run = 0;                                                     // sum of w x relative key of the registers below
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const i64 v = (i64)w[r] * (k[r] - kbase), p = (i64)wave_scan_add64((u64)v);
-    ldsK[64 * r + lane] = k[r];
-    ldsWK[64 * r + lane] = run + p - v;                          // exclusive prefix over all reads before this one
-    run += rd64(p, 63);
+    for (int r = 0; r < 4; ++r) {
+      const i64 v = (i64)w[r] * (k[r] - kbase), p = (i64)wave_scan_add64((u64)v);
+      ldsK[64 * r + lane] = k[r];
+      ldsWK[64 * r + lane] = run + p - v;                        // exclusive prefix over all reads before this one
+      run += rd64(p, 63);
+    }
   }
   if (WIN::below(rdlane(k[3], 63), X.curW)) {                    // the whole step stays in the current slot
     X.pend += totalW;
@@ -1110,7 +1114,7 @@ __device__ __forceinline__ void cov_step4_run_w(WIN &X, const Seg &sg, const int
   X.deposit(lane);                                               // what is pending belongs to the slot we are about to leave
   int adv = 0;
   for (;;) {
-    const int bnd = X.W;
+    const int bnd = SHIFTED ? __builtin_elementwise_sub_sat(X.W, shift) : X.W;
     int cnt = 0;
 #pragma unroll
     for (int half = 128; half >= 1; half >>= 1) cnt += WIN::below(ldsK[cnt + half - 1], bnd) ? half : 0;
@@ -1133,7 +1137,7 @@ __device__ __forceinline__ void cov_step4_run_w(WIN &X, const Seg &sg, const int
       valid = false;                                             // acc is empty and nothing is pending
 #pragma unroll 1
       for (int r = 0; r < 4; ++r) {                              // the keys not yet placed add themselves (key and weight back from LDS)
-        const int e = 64 * r + lane, kr = ldsK[e], wr = (int)(ldsW[e + 1] - ldsW[e]);
+        const int e = 64 * r + lane, kr = ldsK[e] + (SHIFTED ? shift : 0), wr = (int)(ldsW[e + 1] - ldsW[e]);
         const u64 m = __ballot(e >= top);
         if (m) X.lanes_add(sg, kr, wr, m, lane);
       }
@@ -1142,32 +1146,40 @@ __device__ __forceinline__ void cov_step4_run_w(WIN &X, const Seg &sg, const int
   }
 }
 
-template <class WIN>
-__device__ __forceinline__ void cov_step4_run(WIN &X, const Seg &sg, const int (&k)[4], int lane, bool &valid, int *ldsK, int *ldsP)
+// SHIFTED: the keys of this window are the keys ANOTHER window has just staged plus a wave-uniform `shift` (read ends of equal-length
+// reads behind their starts): their relative values, hence the prefix sums in ldsP, are the staged ones, and key <= W is staged key <=
+// W - shift (saturating: a sentinel stays one) -- nothing is staged again.  Returns whether ldsK / ldsP hold this step's keys.
+template <bool SHIFTED, class WIN>
+__device__ __forceinline__ bool cov_step4_run(WIN &X, const Seg &sg, const int (&k)[4], int lane, bool &valid, int *ldsK, int *ldsP, int shift = 0)
 {
   const int kbase = rdlane(k[0], 0);
   if (WIN::below(rdlane(k[3], 63), X.curW)) {                    // the whole step stays in the current slot
-    const int t = (k[0] - kbase) + (k[1] - kbase) + (k[2] - kbase) + (k[3] - kbase);
     X.pend += 256;
-    X.pend2 += (i64)kbase * 256 + rdlane(wave_scan_add(t), 63);
-    return;
+    if constexpr (SHIFTED) X.pend2 += (i64)kbase * 256 + rdlane(ldsP[256], 0);
+    else {
+      const int t = (k[0] - kbase) + (k[1] - kbase) + (k[2] - kbase) + (k[3] - kbase);
+      X.pend2 += (i64)kbase * 256 + rdlane(wave_scan_add(t), 63);
+    }
+    return SHIFTED;
   }
-  int run = 0;                                                   // sum of the relative keys of the registers below
+  if constexpr (!SHIFTED) {
+    int run = 0;                                                 // sum of the relative keys of the registers below
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int rel = k[r] - kbase, p = wave_scan_add(rel);
-    ldsK[64 * r + lane] = k[r];
-    ldsP[64 * r + lane] = run + p - rel;                         // exclusive prefix over all keys before this one
-    run += rdlane(p, 63);
+    for (int r = 0; r < 4; ++r) {
+      const int rel = k[r] - kbase, p = wave_scan_add(rel);
+      ldsK[64 * r + lane] = k[r];
+      ldsP[64 * r + lane] = run + p - rel;                       // exclusive prefix over all keys before this one
+      run += rdlane(p, 63);
+    }
+    if (lane == 0) ldsP[256] = run;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  if (lane == 0) ldsP[256] = run;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   X.deposit(lane);                                               // what is pending belongs to the slot we are about to leave
   int adv = 0;
   for (;;) {
-    const int bnd = X.W;
+    const int bnd = SHIFTED ? __builtin_elementwise_sub_sat(X.W, shift) : X.W;
     int cnt = 0;
 #pragma unroll
     for (int half = 128; half >= 1; half >>= 1) cnt += WIN::below(ldsK[cnt + half - 1], bnd) ? half : 0;
@@ -1181,7 +1193,7 @@ __device__ __forceinline__ void cov_step4_run(WIN &X, const Seg &sg, const int (
       // every key is placed; the slot of the last key is the one below the first boundary that has them all
       const int first = __ffsll((unsigned long long)__ballot(cnt == 256)) - 1;
       X.j = first - 1; X.prevW = rdlane(X.W, first - 1); X.curW = rdlane(X.W, first);
-      return;
+      return true;
     }
     // keys beyond the window: publish it and slide (lane 0 of the new window holds the old lane 63, so its count
     // is `top` and the differences above keep working)
@@ -1197,7 +1209,7 @@ __device__ __forceinline__ void cov_step4_run(WIN &X, const Seg &sg, const int (
         const u64 m = __ballot(64 * r + lane >= top);
         if (m) X.lanes_add(sg, kr, 1, m, lane);
       }
-      return;
+      return true;
     }
   }
 }
@@ -1371,11 +1383,24 @@ __device__ __forceinline__ void coverage_walk_body(const Tri *__restrict__ reads
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const i64 v = w4[r], pw = (i64)wave_scan_add64((u64)v); ldsW[wid][64 * r + lane] = runW + pw - v; runW += rd64(pw, 63); }
             if (lane == 0) ldsW[wid][256] = runW;
-            cov_step4_run_w(st.Ws, st.sg, ks, w4, runW, lane, st.vs, ldsK[wid], ldsW[wid], ldsWK[wid]);
-            cov_step4_run_w(st.We, st.sg, ke, w4, runW, lane, st.ve, ldsK[wid], ldsW[wid], ldsWK[wid]);
+            const int len0 = rdlane(ke[0] - ks[0], 0);             // reads of one length: the second window searches the keys the first one staged
+            bool uneven = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) uneven |= ke[r] - ks[r] != len0;
+            i64 runWK = 0;
+            cov_step4_run_w<false>(st.Ws, st.sg, ks, w4, runW, lane, st.vs, ldsK[wid], ldsW[wid], ldsWK[wid], runWK);
+            if (len0 >= 0 && __ballot(uneven) == 0) cov_step4_run_w<true>(st.We, st.sg, ke, w4, runW, lane, st.ve, ldsK[wid], ldsW[wid], ldsWK[wid], runWK, len0);
+            else cov_step4_run_w<false>(st.We, st.sg, ke, w4, runW, lane, st.ve, ldsK[wid], ldsW[wid], ldsWK[wid], runWK);
           } else {
-            cov_step4_run(st.Ws, st.sg, ks, lane, st.vs, ldsK[wid], ldsP[wid]);
-            cov_step4_run(st.We, st.sg, ke, lane, st.ve, ldsK[wid], ldsP[wid]);
+            // reads of one length (the usual case): the ends are the starts plus a constant -- the second window searches the keys the
+            // first one staged
+            const int len0 = rdlane(ke[0] - ks[0], 0);
+            bool uneven = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) uneven |= ke[r] - ks[r] != len0;
+            const bool staged = cov_step4_run<false>(st.Ws, st.sg, ks, lane, st.vs, ldsK[wid], ldsP[wid]);
+            if (staged && len0 >= 0 && __ballot(uneven) == 0) cov_step4_run<true>(st.We, st.sg, ke, lane, st.ve, ldsK[wid], ldsP[wid], len0);
+            else cov_step4_run<false>(st.We, st.sg, ke, lane, st.ve, ldsK[wid], ldsP[wid]);
           }
           at += 256;
           continue;

@@ -45,6 +45,24 @@ def test_multi_chrom_weights_and_unsorted(engine):
     check(engine, refs, reads[perm], w[perm], n_classes=24)
 
 
+@pytest.mark.parametrize("run", [64, 256, 300, 1000, 5000])
+def test_reads_of_one_length_in_runs(engine, run):
+    """sorted reads whose length is constant over runs of `run` reads and changes between them -- 1 bp, 36, 150, 5000, 100 kb, 1 Mb:
+    a step of 256 reads all of one length lets the second window of the streaming kernel search the keys the first one staged
+    (the ends are the starts plus a constant), a step that straddles two runs does not; dense and sparse reference sets, against both
+    restated algorithms"""
+    rng = np.random.default_rng(run)
+    n = 60_000
+    starts = np.sort(rng.integers(1, 40_000_000, size=n))
+    lens = np.repeat(rng.choice([1, 36, 150, 5000, 100_000, 1_000_000], size=n // run + 1), run)[:n]
+    reads = np.stack([np.zeros(n, dtype=np.int64), starts, starts + lens - 1], axis=1).astype(np.int32)
+    for m in (300, 60_000):
+        refs = synth.refs_single_chrom(m, seed=run + m, chrom_len=41_000_000, max_len=3000)
+        check(engine, refs, reads, n_classes=1)
+        check(engine, refs, reads, n_classes=1, algo=orc.SORTED_MERGE)
+        check(engine, refs, reads, weights=rng.integers(0, 9, size=n).astype(np.int32), n_classes=1)      # (the weighted step does the same)
+
+
 def test_regions_that_never_count(engine):
     refs = np.array([[0, 100, 200], [0, 300, 250], [0, 151, 150], [0, -5, 0]], dtype=np.int32)
     reads = np.array([[0, 1, 1000], [0, 150, 150], [0, 140, 160]], dtype=np.int32)
