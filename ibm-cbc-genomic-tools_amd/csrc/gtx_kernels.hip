@@ -2098,7 +2098,12 @@ hipError_t launch_scan_zero(void *micro, i64 bytes, const int *runIf, hipStream_
 hipError_t launch_scan_hist(const void *reads, const void *weights, i64 n, const ScanArgs &a, hipStream_t st, const int *runIf)
 {
   if (n <= 0) return hipSuccess;
-  i64 blocks = (n + 4095) / 4096; if (blocks > 256 * 16) blocks = 256 * 16;      // >= 4 steps per wave, <= 16 blocks per CU
+  // >= 4 steps per wave; unweighted <= 32 blocks per CU (four rounds of resident waves: the launch's tail is a quarter of a round of
+  // short spans; 100 M reads, same-box sweeps: 8 per CU 0.219 ms, 16: 0.205-0.211, 24-48: 0.200-0.207, 64: 0.204 -- 1-3 %), with
+  // label weights <= 16 (64-bit counters, twice the tile flushes per span: 0.324-0.329 at 16 against 0.334-0.341 at 32)
+  static const int perCuEnv = getenv("GTX_SCAN_BLOCKS_PER_CU") ? atoi(getenv("GTX_SCAN_BLOCKS_PER_CU")) : 0;
+  const int perCu = perCuEnv > 0 ? perCuEnv : (weights ? 16 : 32);
+  i64 blocks = (n + 4095) / 4096; if (blocks > 256 * (i64)perCu) blocks = 256 * (i64)perCu;
   if (weights) scan_hist_kernel<true><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a, runIf);
   else scan_hist_kernel<false><<<(unsigned)blocks, 256, 0, st>>>((const Tri *)reads, (const int *)weights, n, a, runIf);
   return hipGetLastError();

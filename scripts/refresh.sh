@@ -2,7 +2,7 @@
 # The round's measurement refresh on the GPU box, ONE command for every number DESIGN.md section 7 quotes: bench lines, rocprofv3 kernel
 # stats of the same commands, PMC passes (counters in their own runs, kernel-trace only: MI355X_MICROARCH.md "rocprofv3 PMC slots"), the
 # partition / coverage / scan / pair / permutation side benches, a group member's call at 1/8 of the reads, the bare load pattern.
-#   gpurun --timeout 1200 -- 'bash scripts/refresh.sh r04 [part ...]'      parts: bench stats pmc group (default: all four), perm
+#   gpurun --timeout 1200 -- 'bash scripts/refresh.sh r04 [part ...]'      parts: bench stats pmc group (default: all four), perm, scans
 # Everything lands under gpurun_out/refresh_<tag>/; `python scripts/collect.py <tag>` (here, afterwards) copies the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=${1:-r04}; shift; parts=${*:-bench stats pmc group}
@@ -46,6 +46,13 @@ pmc bucket_write WRITE_SIZE python3 scripts/bench_bucket.py
 pmc cov_fetch FETCH_SIZE python3 tests/tools/bench_coverage.py
 pmc cov_write WRITE_SIZE python3 tests/tools/bench_coverage.py
 grep -h "bucket path\|coverage:\|coverage, \|scan -w" $out/bench_bucket.log $out/bench_cov.log $out/bench_scan.log $out/bench_covshuf.log $out/bench_scanshuf.log
+fi
+if want scans; then
+step "genomic_scans only (bench line, kernel stats, geometries): after a change to the scan kernels"
+python3 bench.py --workload scans > $out/bench_scans_line.json 2>> $out/bench.err && echo "scans ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_scans -- python3 bench.py --workload scans --cpu-sample 0 --steps 20 --warmup 3 > /dev/null 2>> $out/rocprof.err && echo "scans stats ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_scanfine -- python3 scripts/bench_scan.py > $out/bench_scan.log 2>&1 && echo "scan geometry stats ok"
+python3 scripts/bench_scan_shuffled.py > $out/bench_scanshuf.log 2>&1 && echo "scans (shuffled reads) ok"
 fi
 if want perm; then
 step "permutation test only (bench line, kernel stats, PMC passes): after a change to gtx_perm.hip"
